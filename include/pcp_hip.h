@@ -1,0 +1,160 @@
+/* pcp_hip.h — C ABI of libpcp_hip.so, the MI355X (gfx950) propagation-fixpoint engine.
+ *
+ * Drop-in boundary.  The reference (ptal/pcp, libpcp 0.7.0, pure Rust) has no FFI;
+ * the seam it offers is the trait
+ *     kernel::Consistency<VStore>::consistency(&mut self, &mut VStore) -> SKleene
+ *                                                    (src/libpcp/kernel/consistency.rs:17-19)
+ * as implemented by propagation::store::Store       (src/libpcp/propagation/store.rs:240-258)
+ * and required of any constraint store by IntCStore  (src/libpcp/concept.rs:120-138).
+ * Every entry point below is what a Rust `GpuCStore: IntCStore<VStore>` would bind through
+ * `extern "C"` (the binding stub is in INTEGRATION.md); each cites the reference item it replaces.
+ *
+ * Conventions: plain pointers and sizes; no exceptions or aborts cross the boundary; every call
+ * returns PCP_OK (0) or a negative pcp_err.  Where the reference panics on a contract violation
+ * (assert!), this library returns PCP_ERR_CONTRACT.  A pcp_ctx is used from one host thread at a
+ * time; distinct contexts are independent.  There is NO CPU fallback: if no HIP device is present
+ * pcp_ctx_create fails with PCP_ERR_NODEVICE.
+ */
+#ifndef PCP_HIP_H
+#define PCP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCP_ABI_VERSION 1
+
+/* Operand encodings for pcp_prop.var[i]. */
+#define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
+#define PCP_NOVAR 0xFFFFFFFEu /* operand slot unused (var[2] of the binary kinds)                          */
+
+/* Interval bounds and offsets must stay inside [-PCP_BOUND_MAX, PCP_BOUND_MAX] so that no filter can
+ * overflow i32 (the reference wraps in release and panics in debug; SURVEY.md §7 "i32 overflow"). */
+#define PCP_BOUND_MAX 0x3FFFFFFF
+
+typedef enum {
+  PCP_OK = 0,
+  PCP_ERR_ARG = -1,         /* null pointer, bad size, bad enum                                         */
+  PCP_ERR_CONTRACT = -2,    /* a reference assert! would fire: empty initial domain (variable/store.rs:136),
+                               var >= n_vars (variable/store.rs:176-179), same var twice in one propagator
+                               (reactors/indexed_deps.rs:69-77), bound/offset out of PCP_BOUND_MAX        */
+  PCP_ERR_HIP = -3,         /* a HIP runtime call failed; pcp_last_error() has the text                   */
+  PCP_ERR_NOMEM = -4,
+  PCP_ERR_UNSUPPORTED = -5, /* e.g. set_words != 0 (set-mode domains are not built yet)                   */
+  PCP_ERR_NODEVICE = -6     /* no HIP device: the engine never falls back to a CPU path                   */
+} pcp_err;
+
+/* Elementary propagator kinds.  X, Y, Z are views: Identity(var) (term/identity.rs:47-70),
+ * Addition(var, off) (term/addition.rs:80-110) or Constant(off) (term/constant.rs:43-68). */
+typedef enum {
+  PCP_NEQ = 0,  /* XNeqY            propagators/cmp/x_neq_y.rs:66-104                                   */
+  PCP_EQ = 1,   /* XEqY             propagators/cmp/x_eq_y.rs:67-116                                    */
+  PCP_LT = 2,   /* XLessY           propagators/cmp/x_less_y.rs:67-117 (x>y, x>=y, x<=y are ctor sugar,
+                                    propagators/cmp/mod.rs:34-60)                                        */
+  PCP_LT3 = 3,  /* XLessYPlusZ      propagators/cmp/x_less_y_plus_z.rs:75-128                           */
+  PCP_GT3 = 4,  /* XGreaterYPlusZ   propagators/cmp/x_greater_y_plus_z.rs:75-128                        */
+  PCP_EQ3 = 5,  /* XEqYPlusZ = GT3(x+1,y,z) && LT3(x-1,y,z), one propagator
+                                    propagators/cmp/x_eq_y_plus_z.rs:31-105                              */
+  PCP_MUL3 = 6  /* XEqYMulZ         propagators/cmp/x_eq_y_mul_z.rs:68-115 (narrows x only)             */
+} pcp_kind;
+
+/* SKleene as returned by Consistency::consistency (trilean::SKleene; propagation/store.rs:247-257). */
+typedef enum { PCP_FALSE = 0, PCP_TRUE = 1, PCP_UNKNOWN = 2 } pcp_status;
+
+/* One elementary filter.  A *unit* is what the reference stores as ONE Box<dyn PropagatorConcept>
+ * (one index in Store::propagators, one bit of Store::active, propagation/store.rs:33-38):
+ *   group_kind == 0 : the prop is a unit by itself;
+ *   group_kind == 1 : consecutive props carrying the same `group` value form ONE unit — a
+ *                     logic::Conjunction (logic/conjunction.rs:77-119);
+ *   group_kind == 2 : the same, built by Distinct::new (propagators/distinct.rs:63-83); it differs from
+ *                     1 only in the ORDER of its reactor subscriptions (distinct.rs:117-124), which no
+ *                     fixpoint depends on.  join_distinct (distinct.rs:26-45) instead pushes its pairs
+ *                     as standalone units.
+ * Units are numbered in push order; bit u of an `active` row is unit u. */
+typedef struct {
+  uint8_t kind;       /* pcp_kind */
+  uint8_t group_kind; /* 0 standalone, 1 Conjunction member, 2 Distinct member */
+  uint16_t reserved;  /* must be 0 */
+  uint32_t group;     /* Conjunction id (only compared for equality with the previous prop) */
+  uint32_t var[3];    /* variable index, PCP_CONST, or PCP_NOVAR */
+  int32_t off[3];     /* Addition offset (0 = Identity) or the Constant's value */
+} pcp_prop;
+
+/* Counters.  A *filter step* = one evaluation of one elementary propagator's propagate()+is_subsumed()
+ * (one scheduler pop, propagation/store.rs:166-175).  The reference keeps no such
+ * counter.  Step counts are schedule-dependent: compare rates, never counts. */
+typedef struct {
+  uint64_t steps;        /* filter steps on binary kinds                        */
+  uint64_t steps3;       /* filter steps on ternary kinds (LT3/GT3/EQ3/MUL3)    */
+  uint64_t narrowings;   /* domain writes that strictly shrank a domain         */
+  uint64_t waves;        /* sum over nodes of fixpoint waves (>=1 per node)     */
+  uint64_t failed_nodes; /* nodes that ended PCP_FALSE                          */
+  uint64_t nodes;        /* nodes propagated                                    */
+} pcp_stats;
+
+typedef struct pcp_ctx pcp_ctx;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* One context per CStore (the reference builds one Store per Space, search/space.rs:21-36). */
+int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out);
+void pcp_ctx_destroy(pcp_ctx* ctx);
+const char* pcp_last_error(const pcp_ctx* ctx); /* text of the last failing call on ctx (never NULL) */
+const char* pcp_strerror(int32_t err);
+uint32_t pcp_abi_version(void);
+
+/* ---- model (≡ the immutable part of Store: `propagators`) ------------------------------------------ */
+/* ≡ Store::empty() (propagation/store.rs:40-54) over a VStore of n_vars variables.  set_words must be 0
+ * (Interval<i32> domains, variable/mod.rs:36 VStoreFD); bitset domains return PCP_ERR_UNSUPPORTED. */
+int32_t pcp_model_reset(pcp_ctx* ctx, uint32_t n_vars, uint32_t set_words);
+/* ≡ Store::alloc, append-only (propagation/store.rs:223-230). */
+int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
+/* ≡ FrozenStore::restore's `propagators.truncate(label.0)` (propagation/store.rs:319-323); n_units counts
+ * units, not elementary props. */
+int32_t pcp_model_truncate(pcp_ctx* ctx, uint32_t n_units);
+int32_t pcp_model_n_units(const pcp_ctx* ctx, uint32_t* n_units, uint32_t* n_props);
+
+/* ---- propagation (≡ Consistency::consistency, propagation/store.rs:247-257) ---------------------------- */
+/* Host-buffer form: n_nodes independent spaces sharing the model.
+ *   lb, ub  : [n_nodes][n_vars] i32, node-major, in/out (Interval<i32> bounds).
+ *   bits    : must be NULL (set mode).
+ *   active  : [n_nodes][ceil(n_units/64)] u64 in/out; bit u == Store::active of unit u.  NULL = every unit
+ *             active on entry, result not returned.
+ *   status  : [n_nodes] out, pcp_status.
+ *   stats   : nullable; counters of THIS call.
+ * Post-condition: for status != PCP_FALSE, (lb,ub) are the reference's fixpoint domains and
+ * `active` has lost exactly the entailed units; for PCP_FALSE nodes domains/active are unspecified. */
+int32_t pcp_propagate(pcp_ctx* ctx, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* bits,
+                      uint64_t* active, uint8_t* status, pcp_stats* stats);
+
+/* Device-resident form: all pointers are HIP device pointers on ctx's device; work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the null stream) and NOT synchronised.  *_out may alias *_in.
+ * active_in NULL = all units active; active_out NULL = do not write the mask back. */
+typedef struct {
+  const int32_t* lb_in;
+  const int32_t* ub_in;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  const uint64_t* active_in;
+  uint64_t* active_out;
+  uint8_t* status;
+} pcp_device_batch;
+int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
+
+/* Counters accumulate on the device across pcp_propagate_device calls. */
+int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
+int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */
+
+/* Timing of the LAST pcp_propagate_device call's kernels, measured with HIP events recorded on the
+ * stream the kernels were launched on (bench.py's roofline leg).  Synchronises on the stop event. */
+int32_t pcp_last_kernel_ms(pcp_ctx* ctx, float* ms);
+
+/* Tuning knobs (all optional).  key: "block_threads", "nodes_per_block", "force_path" (0 auto, 1 batch
+ * LDS kernel, 2 team/global kernel).  Unknown key -> PCP_ERR_ARG. */
+int32_t pcp_set_option(pcp_ctx* ctx, const char* key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCP_HIP_H */

@@ -1,0 +1,308 @@
+// pcp_oracle_capi.cpp — C entry points over the CPU oracle (pcp_oracle.hpp) for ctypes.
+// TEST INFRASTRUCTURE ONLY: loaded by tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke().
+// Models are described with the same pcp_prop records as the HIP ABI (include/pcp_hip.h) so that one
+// lowered model feeds both sides of a parity test.
+#include "pcp_oracle.hpp"
+
+#include <cstring>
+
+#include "../include/pcp_hip.h"
+
+using namespace orc;
+
+namespace {
+
+thread_local std::string g_err;
+
+Var make_view(uint32_t var, int32_t off, uint32_t n_vars) {
+  if (var == PCP_CONST) return std::make_unique<Constant>(off);
+  if (var >= n_vars) throw Panic("variable index out of range");
+  Var id = std::make_unique<Identity>(var);
+  if (off != 0) return std::make_unique<Addition>(std::move(id), off);
+  return id;
+}
+
+Formula make_elementary(const pcp_prop& p, uint32_t n_vars) {
+  auto v = [&](int i) { return make_view(p.var[i], p.off[i], n_vars); };
+  switch (p.kind) {
+    case PCP_NEQ: return std::make_unique<XNeqY>(v(0), v(1));
+    case PCP_EQ: return std::make_unique<XEqY>(v(0), v(1));
+    case PCP_LT: return std::make_unique<XLessY>(v(0), v(1));
+    case PCP_LT3: return std::make_unique<XLessYPlusZ>(v(0), v(1), v(2));
+    case PCP_GT3: return std::make_unique<XGreaterYPlusZ>(v(0), v(1), v(2));
+    case PCP_EQ3: return std::make_unique<XEqYPlusZ>(v(0), v(1), v(2));
+    case PCP_MUL3: return std::make_unique<XEqYMulZ>(v(0), v(1), v(2));
+    default: throw Panic("unknown propagator kind");
+  }
+}
+
+// A Distinct-ordered conjunction: Conjunction semantics, Distinct's dependency order (distinct.rs:117-124).
+struct DistinctGroup final : Propagator {
+  std::unique_ptr<Conjunction> conj;
+  Deps deps;  // Inner on each var, order of first appearance, no dedup beyond first appearance
+  DistinctGroup(std::unique_ptr<Conjunction> c, Deps d) : conj(std::move(c)), deps(std::move(d)) {}
+  bool propagate(VStore& s) override { return conj->propagate(s); }
+  SKleene is_subsumed(const VStore& s) const override { return conj->is_subsumed(s); }
+  Deps dependencies() const override { return deps; }
+  Formula bclone() const override {
+    auto cj = std::unique_ptr<Conjunction>(static_cast<Conjunction*>(conj->bclone().release()));
+    return std::make_unique<DistinctGroup>(std::move(cj), deps);
+  }
+  uint64_t num_elementary() const override { return conj->num_elementary(); }
+};
+
+struct Model {
+  uint32_t n_vars = 0;
+  std::vector<pcp_prop> props;
+  std::vector<Formula> units;  // one per reference-level propagator
+  // pending group
+  void rebuild() {
+    units.clear();
+    size_t i = 0;
+    while (i < props.size()) {
+      const pcp_prop& p = props[i];
+      if (p.group_kind == 0) { units.push_back(make_elementary(p, n_vars)); ++i; continue; }
+      size_t j = i;
+      std::vector<Formula> fs;
+      Deps ddeps;
+      while (j < props.size() && props[j].group_kind == p.group_kind && props[j].group == p.group) {
+        fs.push_back(make_elementary(props[j], n_vars));
+        for (int k = 0; k < 3; ++k) {
+          uint32_t v = props[j].var[k];
+          if (v == PCP_CONST || v == PCP_NOVAR) continue;
+          bool seen = false;
+          for (auto& d : ddeps) if (d.first == v) { seen = true; break; }
+          if (!seen) ddeps.emplace_back(v, Inner);
+        }
+        ++j;
+      }
+      auto conj = std::make_unique<Conjunction>(std::move(fs));
+      if (p.group_kind == 2) units.push_back(std::make_unique<DistinctGroup>(std::move(conj), std::move(ddeps)));
+      else units.push_back(std::move(conj));
+      i = j;
+    }
+  }
+};
+
+template <class F>
+int guard(F&& f) {
+  try { f(); return 0; }
+  catch (const Panic& e) { g_err = e.what(); return PCP_ERR_CONTRACT; }
+  catch (const std::exception& e) { g_err = e.what(); return PCP_ERR_ARG; }
+}
+
+void fill_cstore(CStore& cs, const Model& m) {
+  cs.propagators.clear();
+  for (auto& u : m.units) cs.propagators.push_back(u->bclone());
+}
+
+void set_active(CStore& cs, const uint64_t* row, size_t n_units) {
+  cs.active = BitSet();
+  for (size_t u = 0; u < n_units; ++u)
+    if (!row || ((row[u >> 6] >> (u & 63)) & 1)) cs.active.insert(u);
+}
+void get_active(const CStore& cs, uint64_t* row, size_t n_units) {
+  size_t words = (n_units + 63) / 64;
+  for (size_t w = 0; w < words; ++w) row[w] = 0;
+  for (size_t u = 0; u < n_units; ++u)
+    if (cs.active.contains(u)) row[u >> 6] |= 1ull << (u & 63);
+}
+
+}  // namespace
+
+extern "C" {
+
+struct orc_stats_c { uint64_t steps, pops, narrowings, nodes, failed_nodes, subscriptions; };
+struct orc_search_stats_c { uint64_t num_solution, num_failed_node, num_prune, num_nodes; uint32_t end_of_search; };
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+void* orc_model_new(uint32_t n_vars) { auto* m = new Model(); m->n_vars = n_vars; return m; }
+void orc_model_free(void* h) { delete static_cast<Model*>(h); }
+int orc_model_push_props(void* h, uint32_t n, const pcp_prop* props) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    size_t old = m->props.size();
+    m->props.insert(m->props.end(), props, props + n);
+    try { m->rebuild(); } catch (...) { m->props.resize(old); m->rebuild(); throw; }
+  });
+}
+uint32_t orc_model_n_units(void* h) { return (uint32_t)static_cast<Model*>(h)->units.size(); }
+
+// ≡ Consistency::consistency on n_nodes independent spaces (same contract as pcp_propagate).
+int orc_consistency(void* h, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* active, uint8_t* status,
+                    orc_stats_c* stats, int check_dup) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    Stats st;
+    CStore cs;
+    cs.check_dup = check_dup != 0;
+    cs.stats = &st;
+    fill_cstore(cs, *m);
+    size_t nu = m->units.size(), words = (nu + 63) / 64;
+    for (uint32_t n = 0; n < n_nodes; ++n) {
+      VStore vs;
+      for (uint32_t v = 0; v < m->n_vars; ++v) vs.alloc(Interval{lb[(size_t)n * m->n_vars + v], ub[(size_t)n * m->n_vars + v]});
+      set_active(cs, active ? active + (size_t)n * words : nullptr, nu);
+      SKleene k = cs.consistency(vs);
+      status[n] = (uint8_t)k;
+      for (uint32_t v = 0; v < m->n_vars; ++v) {
+        lb[(size_t)n * m->n_vars + v] = vs.memory[v].lb;
+        ub[(size_t)n * m->n_vars + v] = vs.memory[v].ub;
+      }
+      if (active) get_active(cs, active + (size_t)n * words, nu);
+    }
+    if (stats) *stats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
+  });
+}
+
+// The reference's test fixture propagators/mod.rs:108-129 (test_propagation) on ONE unit:
+// is_subsumed before, one propagate(), the drained delta (ascending var), is_subsumed after, final domains.
+int orc_kat(uint32_t n_vars, int32_t* lb, int32_t* ub, uint32_t n_props, const pcp_prop* props, uint8_t* before,
+            uint8_t* ok, uint8_t* after, uint32_t* delta_n, uint32_t* delta_var, uint8_t* delta_ev) {
+  return guard([&] {
+    Model m;
+    m.n_vars = n_vars;
+    m.props.assign(props, props + n_props);
+    m.rebuild();
+    if (m.units.size() != 1) throw Panic("orc_kat expects exactly one unit");
+    VStore vs;
+    for (uint32_t v = 0; v < n_vars; ++v) vs.alloc(Interval{lb[v], ub[v]});
+    Propagator& p = *m.units[0];
+    *before = (uint8_t)p.is_subsumed(vs);
+    bool r = p.propagate(vs);
+    *ok = r ? 1 : 0;
+    *delta_n = 0;
+    if (r) {
+      for (auto& [v, ev] : vs.drain_delta()) { delta_var[*delta_n] = (uint32_t)v; delta_ev[*delta_n] = (uint8_t)ev; ++*delta_n; }
+    }
+    *after = (uint8_t)p.is_subsumed(vs);
+    for (uint32_t v = 0; v < n_vars; ++v) { lb[v] = vs.memory[v].lb; ub[v] = vs.memory[v].ub; }
+  });
+}
+
+// variable/store.rs test_op (:369-393): one update on a one-variable store; returns update() and the event (-1 none).
+int orc_vstore_update(int32_t lb, int32_t ub, int32_t nlb, int32_t nub, uint8_t* ok, int32_t* event) {
+  return guard([&] {
+    VStore vs;
+    vs.alloc(Interval{lb, ub});
+    bool r = vs.update(0, Interval{nlb, nub});
+    *ok = r;
+    *event = -1;
+    for (auto& [v, ev] : vs.drain_delta()) { (void)v; *event = ev; }
+  });
+}
+// Interval ops used by the store tests (variable/store.rs:467-525): 0 shrink_left, 1 shrink_right, 2 intersection, 3 difference(value a)
+int orc_interval_op(int op, int32_t lb, int32_t ub, int32_t a, int32_t b, int32_t* rlb, int32_t* rub) {
+  return guard([&] {
+    Interval x{lb, ub}, r{0, 0};
+    switch (op) {
+      case 0: r = x.shrink_left(a); break;
+      case 1: r = x.shrink_right(a); break;
+      case 2: r = x.intersection(Interval{a, b}); break;
+      case 3: r = x.difference(a); break;
+      case 4: r = x.strict_shrink_left(a); break;
+      case 5: r = x.strict_shrink_right(a); break;
+      default: throw Panic("bad op");
+    }
+    *rlb = r.lb; *rub = r.ub;
+  });
+}
+
+// IndexedDeps / RelaxedFifo handles for the table tests (indexed_deps.rs:159-231, relaxed_fifo.rs:78-132).
+void* orc_reactor_new(uint32_t num_vars) { return new IndexedDeps(num_vars, kNumEvents, true); }
+void orc_reactor_free(void* r) { delete static_cast<IndexedDeps*>(r); }
+int orc_reactor_subscribe(void* r, uint32_t var, uint32_t ev, uint32_t prop) { return guard([&] { static_cast<IndexedDeps*>(r)->subscribe(var, (FDEvent)ev, prop); }); }
+int orc_reactor_unsubscribe(void* r, uint32_t var, uint32_t ev, uint32_t prop) {
+  return guard([&] {
+    auto* x = static_cast<IndexedDeps*>(r);
+    if (x->num_subscriptions == 0) throw Panic("attempt to subtract with overflow");  // Rust debug: usize underflow panics first
+    x->unsubscribe(var, (FDEvent)ev, prop);
+  });
+}
+int orc_reactor_react(void* r, uint32_t var, uint32_t ev, uint32_t* out, uint32_t cap, uint32_t* n) {
+  return guard([&] {
+    auto v = static_cast<IndexedDeps*>(r)->react(var, (FDEvent)ev);
+    *n = (uint32_t)v.size();
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = (uint32_t)v[i];
+  });
+}
+int orc_reactor_is_empty(void* r) { return static_cast<IndexedDeps*>(r)->is_empty(); }
+
+void* orc_fifo_new(uint32_t cap) { return new RelaxedFifo(cap); }
+void orc_fifo_free(void* f) { delete static_cast<RelaxedFifo*>(f); }
+int orc_fifo_schedule(void* f, uint32_t i) { return guard([&] { static_cast<RelaxedFifo*>(f)->schedule(i); }); }
+int orc_fifo_unschedule(void* f, uint32_t i) { return guard([&] { static_cast<RelaxedFifo*>(f)->unschedule(i); }); }
+int64_t orc_fifo_pop(void* f) { auto r = static_cast<RelaxedFifo*>(f)->pop(); return r ? (int64_t)*r : -1; }
+int orc_fifo_is_empty(void* f) { return static_cast<RelaxedFifo*>(f)->is_empty(); }
+
+int32_t orc_middle_val(int32_t lb, int32_t ub) { return middle_val(Interval{lb, ub}); }
+int64_t orc_first_smallest_var(uint32_t n, const int32_t* lb, const int32_t* ub) {
+  VStore vs;
+  try {
+    for (uint32_t i = 0; i < n; ++i) vs.alloc(Interval{lb[i], ub[i]});
+    return (int64_t)first_smallest_var(vs);
+  } catch (const Panic& e) { g_err = e.what(); return -1; }
+}
+
+// DFS with the default engine (search/mod.rs:45-52), optionally AllSolution and StopNode(node_limit).
+// Records up to max_records explored nodes.  Recorded inputs are in the FOLDED form the HIP driver uses:
+// the branch propagator `x <= v` / `x > v` (binary_split.rs:46-57) is applied to x's bounds in lb_in/ub_in, and the
+// active rows cover the model's units only.  A node whose folded domain is empty is recorded with lb_in > ub_in.
+int orc_search(void* h, const int32_t* lb0, const int32_t* ub0, int all_solutions, uint64_t node_limit, int check_dup,
+               orc_search_stats_c* out, orc_stats_c* pstats, uint32_t max_records, int32_t* rec_lb_in, int32_t* rec_ub_in,
+               int32_t* rec_lb_out, int32_t* rec_ub_out, uint64_t* rec_active_in, uint64_t* rec_active_out,
+               uint8_t* rec_status, uint32_t* n_recorded, int32_t* first_solution) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    Stats st;
+    Space sp;
+    sp.cstore.check_dup = check_dup != 0;
+    sp.cstore.stats = &st;
+    for (uint32_t v = 0; v < m->n_vars; ++v) sp.vstore.alloc(Interval{lb0[v], ub0[v]});
+    for (auto& u : m->units) sp.cstore.alloc(u->bclone());
+    size_t nu = m->units.size(), words = (nu + 63) / 64, V = m->n_vars;
+    uint32_t nrec = 0;
+    bool have_solution = false;
+    SearchStats ss = dfs(sp, all_solutions != 0, node_limit,
+                         [&](const std::vector<Interval>& before, const BitSet& active_before, Space& s, SKleene k) {
+      if (k == SKleene::True && !have_solution && first_solution) {
+        have_solution = true;
+        for (size_t v = 0; v < V; ++v) first_solution[v] = s.vstore.memory[v].lb;
+      }
+      if (nrec >= max_records) return;
+      size_t r = nrec++;
+      for (size_t v = 0; v < V; ++v) { rec_lb_in[r * V + v] = before[v].lb; rec_ub_in[r * V + v] = before[v].ub; }
+      // fold the newest branch propagator (the last unit, if beyond the model) into the input domain
+      if (s.cstore.propagators.size() > nu) {
+        auto* br = dynamic_cast<XLessY*>(s.cstore.propagators.back().get());
+        if (!br) throw Panic("branch propagator is not XLessY");
+        // left: XLessY(Identity x, Addition(Constant v,1))  => x.ub = min(ub, v)
+        // right: XLessY(Constant v, Identity x)             => x.lb = max(lb, v+1)
+        if (auto* idx = dynamic_cast<Identity*>(br->x.get())) {
+          Interval y = br->y->read(s.vstore);  // {v+1}
+          size_t x = idx->idx;
+          rec_ub_in[r * V + x] = std::min(rec_ub_in[r * V + x], y.ub - 1);
+        } else {
+          auto* idy = dynamic_cast<Identity*>(br->y.get());
+          if (!idy) throw Panic("unexpected branch propagator shape");
+          Interval c = br->x->read(s.vstore);  // {v}
+          size_t x = idy->idx;
+          rec_lb_in[r * V + x] = std::max(rec_lb_in[r * V + x], c.lb + 1);
+        }
+      }
+      for (size_t w = 0; w < words; ++w) { rec_active_in[r * words + w] = 0; rec_active_out[r * words + w] = 0; }
+      for (size_t u = 0; u < nu; ++u) {
+        if (active_before.contains(u)) rec_active_in[r * words + (u >> 6)] |= 1ull << (u & 63);
+        if (s.cstore.active.contains(u)) rec_active_out[r * words + (u >> 6)] |= 1ull << (u & 63);
+      }
+      for (size_t v = 0; v < V; ++v) { rec_lb_out[r * V + v] = s.vstore.memory[v].lb; rec_ub_out[r * V + v] = s.vstore.memory[v].ub; }
+      rec_status[r] = (uint8_t)k;
+    });
+    if (n_recorded) *n_recorded = nrec;
+    if (out) *out = orc_search_stats_c{ss.num_solution, ss.num_failed_node, ss.num_prune, ss.num_nodes, ss.end_of_search ? 1u : 0u};
+    if (pstats) *pstats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
+  });
+}
+
+}  // extern "C"
