@@ -1,0 +1,477 @@
+// pcp_api.hip — the C ABI of libpcp_hip.so (include/pcp_hip.h): context, model lowering, launches.
+// Host code only; the kernels are in pcp_kernels.hip.  No CPU fallback exists anywhere in this library.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pcp_internal.h"
+
+using namespace pcp;
+
+struct pcp_ctx {
+  int device = 0;
+  int num_cu = 256;
+  size_t lds_max = 160 * 1024;
+  std::string err;
+
+  // host model
+  uint32_t n_vars = 0;
+  std::vector<pcp_prop> props;          // as pushed
+  std::vector<uint32_t> unit_of_prop;   // unit index of each prop
+  uint32_t n_units = 0;
+  bool has_groups = false;
+  bool dirty = true;
+
+  // device model
+  Rec* d_recs = nullptr;
+  uint32_t* d_adj_off = nullptr;
+  uint32_t* d_adj = nullptr;
+  int32_t* d_const = nullptr;
+  uint32_t n_slots = 0;
+  bool has_ternary = false;
+  size_t cap_recs = 0, cap_adj = 0, cap_adj_off = 0, cap_const = 0;
+
+  // scratch
+  pcp_stats* d_stats = nullptr;
+  uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
+  uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
+  // host-buffer path staging
+  void* d_stage = nullptr; size_t cap_stage = 0;
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool ev_valid = false;
+  int max_dyn_lds_set = 0;
+
+  // options
+  int64_t opt_block = 1024;
+  int64_t opt_nodes_per_block = 0;  // 0 = auto
+  int64_t opt_force_path = 0;       // 0 auto, 1 batch, 2 team
+  int64_t opt_team = 0;             // 0 = auto
+  int64_t opt_list_cap = 2048;
+};
+
+namespace {
+
+int32_t fail(pcp_ctx* c, int32_t code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+int32_t hip_fail(pcp_ctx* c, hipError_t e, const char* what) {
+  return fail(c, PCP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(c, call)                                     \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return hip_fail((c), e__, #call); \
+  } while (0)
+
+template <class T>
+int32_t ensure(pcp_ctx* c, T*& p, size_t& cap, size_t n) {
+  if (n <= cap && p) return PCP_OK;
+  if (p) { hipError_t e = hipFree(p); (void)e; p = nullptr; cap = 0; }
+  size_t want = std::max<size_t>(n, 16);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+  if (e != hipSuccess) return fail(c, PCP_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+  cap = want;
+  return PCP_OK;
+}
+
+int arity(uint8_t kind) { return kind <= PCP_LT ? 2 : 3; }
+
+// Reference-panic checks on one prop (SURVEY.md §8b "Error conventions").
+int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
+  if (p.kind > PCP_MUL3) return fail(c, PCP_ERR_ARG, "unknown propagator kind");
+  if (p.group_kind > 2 || p.reserved != 0) return fail(c, PCP_ERR_ARG, "bad group_kind/reserved");
+  const int n = arity(p.kind);
+  for (int i = 0; i < n; ++i) {
+    if (p.var[i] == PCP_NOVAR) return fail(c, PCP_ERR_ARG, "missing operand");
+    if (p.var[i] != PCP_CONST && p.var[i] >= c->n_vars)
+      return fail(c, PCP_ERR_CONTRACT, "variable index out of range (variable/store.rs:176-179)");
+    if (p.off[i] > PCP_BOUND_MAX || p.off[i] < -PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "offset outside +-PCP_BOUND_MAX");
+    for (int j = 0; j < i; ++j)
+      if (p.var[i] != PCP_CONST && p.var[i] == p.var[j])
+        return fail(c, PCP_ERR_CONTRACT, "propagator already subscribed to this variable (reactors/indexed_deps.rs:69-77)");
+  }
+  if (p.kind == PCP_MUL3)
+    for (int i = 1; i < 3; ++i)
+      if (p.var[i] != PCP_CONST && p.off[i] != 0)
+        return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ with Addition views on y or z is not supported");
+  return PCP_OK;
+}
+
+// Lower the host props to device records + CSR (done lazily, once per model change).
+int32_t finalize_model(pcp_ctx* c) {
+  if (!c->dirty) return PCP_OK;
+  const size_t P = c->props.size();
+  if (c->has_groups) return fail(c, PCP_ERR_UNSUPPORTED, "Conjunction/Distinct groups are not lowered yet");
+  std::map<int32_t, uint32_t> const_slot;
+  std::vector<int32_t> consts;
+  auto slot_of = [&](uint32_t var, int32_t value) -> uint32_t {
+    if (var != PCP_CONST) return var;
+    auto it = const_slot.find(value);
+    if (it != const_slot.end()) return it->second;
+    uint32_t s = c->n_vars + (uint32_t)consts.size();
+    const_slot.emplace(value, s);
+    consts.push_back(value);
+    return s;
+  };
+  std::vector<Rec> recs(P);
+  std::vector<uint32_t> deg(c->n_vars + 1, 0);
+  bool tern = false;
+  for (size_t r = 0; r < P; ++r) {
+    const pcp_prop& p = c->props[r];
+    const int n = arity(p.kind);
+    uint32_t s[3] = {0, 0, 0};
+    int64_t off[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+      // a Constant operand carries its value in off[i]; as a pseudo-variable its offset is 0
+      s[i] = slot_of(p.var[i], p.off[i]);
+      off[i] = (p.var[i] == PCP_CONST) ? 0 : p.off[i];
+    }
+    int64_t d;
+    if (n == 2) d = off[1] - off[0];              // X = x, Y = y + d
+    else if (p.kind == PCP_MUL3) d = off[0];      // X = x + d = y*z
+    else d = off[1] + off[2] - off[0];            // x  vs  y + z + d
+    if (d > PCP_BOUND_MAX || d < -PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "folded offset outside +-PCP_BOUND_MAX");
+    recs[r].xk = s[0] | ((uint32_t)p.kind << 28);
+    recs[r].y = s[1];
+    recs[r].z = (n == 3) ? s[2] : 0;
+    recs[r].d = (int32_t)d;
+    tern |= (n == 3);
+    for (int i = 0; i < n; ++i)
+      if (p.var[i] != PCP_CONST) ++deg[p.var[i]];
+  }
+  const uint32_t n_slots = c->n_vars + (uint32_t)consts.size();
+  if (n_slots >= kMaxSlots) return fail(c, PCP_ERR_UNSUPPORTED, "too many variables");
+  std::vector<uint32_t> adj_off(c->n_vars + 1, 0);
+  for (uint32_t v = 0; v < c->n_vars; ++v) adj_off[v + 1] = adj_off[v] + deg[v];
+  std::vector<uint32_t> adj(adj_off[c->n_vars]);
+  {
+    std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1);
+    for (size_t r = 0; r < P; ++r) {
+      const pcp_prop& p = c->props[r];
+      for (int i = 0; i < arity(p.kind); ++i)
+        if (p.var[i] != PCP_CONST) adj[fill[p.var[i]]++] = (uint32_t)r;
+    }
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t rc;
+  if ((rc = ensure(c, c->d_recs, c->cap_recs, P))) return rc;
+  if ((rc = ensure(c, c->d_adj_off, c->cap_adj_off, adj_off.size()))) return rc;
+  if ((rc = ensure(c, c->d_adj, c->cap_adj, adj.size()))) return rc;
+  if ((rc = ensure(c, c->d_const, c->cap_const, consts.size()))) return rc;
+  if (P) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), P * sizeof(Rec), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_adj_off, adj_off.data(), adj_off.size() * 4, hipMemcpyHostToDevice));
+  if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+  if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  c->n_slots = n_slots;
+  c->has_ternary = tern;
+  c->dirty = false;
+  return PCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t pcp_abi_version(void) { return PCP_ABI_VERSION; }
+
+const char* pcp_strerror(int32_t err) {
+  switch (err) {
+    case PCP_OK: return "ok";
+    case PCP_ERR_ARG: return "invalid argument";
+    case PCP_ERR_CONTRACT: return "contract violation (the reference would panic)";
+    case PCP_ERR_HIP: return "HIP runtime error";
+    case PCP_ERR_NOMEM: return "out of device memory";
+    case PCP_ERR_UNSUPPORTED: return "unsupported";
+    case PCP_ERR_NODEVICE: return "no HIP device";
+    default: return "unknown error";
+  }
+}
+
+const char* pcp_last_error(const pcp_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
+  if (!out) return PCP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return PCP_ERR_NODEVICE;  // fail loudly: there is no CPU path
+  if (hip_device < 0 || hip_device >= n) return PCP_ERR_ARG;
+  if (hipSetDevice(hip_device) != hipSuccess) return PCP_ERR_HIP;
+  pcp_ctx* c = new pcp_ctx();
+  c->device = hip_device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, hip_device) == hipSuccess) {
+    c->num_cu = prop.multiProcessorCount;
+    c->lds_max = (size_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
+  }
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(pcp_stats)) != hipSuccess ||
+      hipMemset(c->d_stats, 0, sizeof(pcp_stats)) != hipSuccess ||
+      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+    delete c;
+    return PCP_ERR_HIP;
+  }
+  *out = c;
+  return PCP_OK;
+}
+
+void pcp_ctx_destroy(pcp_ctx* c) {
+  if (!c) return;
+  hipError_t e = hipSetDevice(c->device);
+  (void)e;
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage};
+  for (void* p : ptrs)
+    if (p) { e = hipFree(p); (void)e; }
+  if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
+  if (c->ev_stop) { e = hipEventDestroy(c->ev_stop); (void)e; }
+  delete c;
+}
+
+int32_t pcp_model_reset(pcp_ctx* c, uint32_t n_vars, uint32_t set_words) {
+  if (!c) return PCP_ERR_ARG;
+  if (set_words != 0) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode (bitset) domains are not built yet");
+  if (n_vars >= kMaxSlots) return fail(c, PCP_ERR_UNSUPPORTED, "too many variables");
+  c->n_vars = n_vars;
+  c->props.clear();
+  c->unit_of_prop.clear();
+  c->n_units = 0;
+  c->has_groups = false;
+  c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_push_props(pcp_ctx* c, uint32_t n, const pcp_prop* props) {
+  if (!c || (n && !props)) return PCP_ERR_ARG;
+  for (uint32_t i = 0; i < n; ++i) {
+    int32_t rc = validate_prop(c, props[i]);
+    if (rc) return rc;
+  }
+  for (uint32_t i = 0; i < n; ++i) {
+    const pcp_prop& p = props[i];
+    bool same_unit = false;
+    if (p.group_kind != 0 && !c->props.empty()) {
+      const pcp_prop& q = c->props.back();
+      same_unit = q.group_kind == p.group_kind && q.group == p.group;
+    }
+    if (!same_unit) ++c->n_units;
+    if (p.group_kind != 0) c->has_groups = true;
+    c->props.push_back(p);
+    c->unit_of_prop.push_back(c->n_units - 1);
+  }
+  c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_truncate(pcp_ctx* c, uint32_t n_units) {
+  if (!c) return PCP_ERR_ARG;
+  if (n_units > c->n_units) return fail(c, PCP_ERR_ARG, "truncate beyond the current size");
+  size_t keep = 0;
+  while (keep < c->props.size() && c->unit_of_prop[keep] < n_units) ++keep;
+  c->props.resize(keep);
+  c->unit_of_prop.resize(keep);
+  c->n_units = n_units;
+  c->has_groups = false;
+  for (auto& p : c->props) c->has_groups |= p.group_kind != 0;
+  c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_n_units(const pcp_ctx* c, uint32_t* n_units, uint32_t* n_props) {
+  if (!c) return PCP_ERR_ARG;
+  if (n_units) *n_units = c->n_units;
+  if (n_props) *n_props = (uint32_t)c->props.size();
+  return PCP_OK;
+}
+
+int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
+  if (!c || !key) return PCP_ERR_ARG;
+  std::string k(key);
+  if (k == "block_threads") {
+    if (value != 256 && value != 512 && value != 1024) return fail(c, PCP_ERR_ARG, "block_threads must be 256, 512 or 1024");
+    c->opt_block = value;
+  } else if (k == "nodes_per_block") {
+    if (value < 0 || value > 32) return fail(c, PCP_ERR_ARG, "nodes_per_block must be in [0,32]");
+    c->opt_nodes_per_block = value;
+  } else if (k == "force_path") {
+    if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "force_path must be 0, 1 or 2");
+    c->opt_force_path = value;
+  } else if (k == "team") {
+    if (value < 0 || value > 4096) return fail(c, PCP_ERR_ARG, "team must be in [0,4096]");
+    c->opt_team = value;
+  } else if (k == "list_cap") {
+    if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
+    c->opt_list_cap = value;
+  } else {
+    return fail(c, PCP_ERR_ARG, "unknown option");
+  }
+  return PCP_OK;
+}
+
+int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batch* bt, void* hip_stream) {
+  if (!c || !bt) return PCP_ERR_ARG;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t rc = finalize_model(c);
+  if (rc) return rc;
+  c->ev_valid = false;
+  if (n_nodes == 0) return PCP_OK;
+  if (!bt->status) return fail(c, PCP_ERR_ARG, "status must not be null");
+  if (c->n_vars && (!bt->lb_in || !bt->ub_in || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "domain pointers must not be null");
+
+  const uint32_t P = (uint32_t)c->props.size();
+  const uint32_t words = (P + 63) / 64;
+  const uint32_t S = c->n_slots, Wv = (S + 31) / 32;
+  const uint32_t block = (uint32_t)c->opt_block;
+  const uint32_t list_cap = (uint32_t)c->opt_list_cap;
+
+  // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
+  uint32_t Bmax = 0;
+  for (uint32_t b = 32; b >= 1; --b)
+    if (size_t need = lds_bytes_for(S, b, list_cap, block); need && need <= c->lds_max) { Bmax = b; break; }
+  if (Bmax == 0) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large for the LDS-resident kernel");
+  const uint32_t slots = (uint32_t)c->num_cu;  // one resident workgroup per CU is what large tiles allow
+  uint32_t B = 1, team = 1;
+  bool use_team = false;
+  if (c->opt_force_path == 2) use_team = true;
+  else if (c->opt_force_path == 0) use_team = (n_nodes * 2 <= slots) && words >= 64;
+  if (use_team) {
+    uint32_t g = c->opt_team ? (uint32_t)c->opt_team : std::max<uint32_t>(1, (2 * slots) / n_nodes);
+    const uint32_t max_by_work = std::max<uint32_t>(1, words / 16);  // >= 16 words (1024 records) per slice
+    team = std::max<uint32_t>(1, std::min(g, max_by_work));
+  } else {
+    if (c->opt_nodes_per_block) B = std::min<uint32_t>((uint32_t)c->opt_nodes_per_block, Bmax);
+    else B = std::max<uint32_t>(1, std::min<uint32_t>(Bmax, (n_nodes + slots - 1) / slots));
+  }
+  LaunchPlan plan;
+  plan.block = block;
+  plan.lds_bytes = lds_bytes_for(S, B, list_cap, block);
+  plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
+
+  LaunchArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
+  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
+  a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap;
+  a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
+  a.live_in = bt->active_in;
+  a.status = bt->status;
+  a.stats = c->d_stats;
+  if (bt->active_out) a.live = bt->active_out;
+  else {
+    if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+    a.live = c->d_live;
+  }
+  if (team > 1) {
+    // per node: ticket, remaining, fail (3 words) + Wv changed words + 4 u64 counters
+    const size_t per_node_words = 4 + Wv + 8;
+    const size_t nwords = (size_t)n_nodes * per_node_words + 2;
+    if ((rc = ensure(c, c->d_team, c->cap_team, nwords))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->d_team, 0, nwords * 4, stream));
+    uint32_t* base = c->d_team;
+    a.team_counters = reinterpret_cast<uint64_t*>(base);                 // [n_nodes][4] u64 (8-byte aligned at base)
+    a.team_ticket = base + (size_t)n_nodes * 8;
+    a.team_remaining = a.team_ticket + n_nodes;
+    a.team_fail = a.team_remaining + n_nodes;
+    a.team_chg = a.team_fail + n_nodes + (n_nodes & 1);                  // keep alignment tidy
+    if (bt->lb_out != bt->lb_in && c->n_vars) {
+      HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
+      HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  HIP_TRY(c, launch_fixpoint(a, plan, stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  c->ev_valid = true;
+  return PCP_OK;
+}
+
+int32_t pcp_stats_reset(pcp_ctx* c, void* hip_stream) {
+  if (!c) return PCP_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcp_stats), reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
+}
+
+int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
+  if (!c || !out) return PCP_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof(pcp_stats), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
+  HIP_TRY(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
+}
+
+int32_t pcp_last_kernel_ms(pcp_ctx* c, float* ms) {
+  if (!c || !ms) return PCP_ERR_ARG;
+  if (!c->ev_valid) return fail(c, PCP_ERR_ARG, "no timed launch");
+  HIP_TRY(c, hipEventSynchronize(c->ev_stop));
+  HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+  return PCP_OK;
+}
+
+int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* bits, uint64_t* active,
+                      uint8_t* status, pcp_stats* stats) {
+  if (!c) return PCP_ERR_ARG;
+  if (bits) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode (bitset) domains are not built yet");
+  if (n_nodes && (!status || (c->n_vars && (!lb || !ub)))) return fail(c, PCP_ERR_ARG, "null buffer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t rc = finalize_model(c);
+  if (rc) return rc;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n_nodes == 0) return PCP_OK;
+  // The reference panics on an empty initial domain (variable/store.rs:136) and the build rejects bounds
+  // outside +-PCP_BOUND_MAX.
+  const size_t nv = (size_t)n_nodes * c->n_vars;
+  for (size_t i = 0; i < nv; ++i) {
+    if (lb[i] > ub[i]) return fail(c, PCP_ERR_CONTRACT, "empty initial domain (variable/store.rs:136)");
+    if (lb[i] < -PCP_BOUND_MAX || ub[i] > PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "bound outside +-PCP_BOUND_MAX");
+  }
+  const uint32_t words = ((uint32_t)c->n_units + 63) / 64;
+  const size_t dom_bytes = nv * 4, act_bytes = (size_t)n_nodes * words * 8;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_lb = 0, o_ub = up(o_lb + dom_bytes), o_act = up(o_ub + dom_bytes), o_st = up(o_act + act_bytes), total = up(o_st + n_nodes);
+  {
+    unsigned char* p = static_cast<unsigned char*>(c->d_stage);
+    size_t cap = c->cap_stage;
+    if ((rc = ensure(c, p, cap, total))) return rc;
+    c->d_stage = p; c->cap_stage = cap;
+  }
+  unsigned char* base = static_cast<unsigned char*>(c->d_stage);
+  hipStream_t stream = nullptr;
+  if (dom_bytes) {
+    HIP_TRY(c, hipMemcpyAsync(base + o_lb, lb, dom_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(base + o_ub, ub, dom_bytes, hipMemcpyHostToDevice, stream));
+  }
+  if (active && act_bytes) HIP_TRY(c, hipMemcpyAsync(base + o_act, active, act_bytes, hipMemcpyHostToDevice, stream));
+  pcp_stats before;
+  if (stats) { rc = pcp_stats_read(c, &before, stream); if (rc) return rc; }
+  pcp_device_batch bt;
+  bt.lb_in = reinterpret_cast<int32_t*>(base + o_lb); bt.ub_in = reinterpret_cast<int32_t*>(base + o_ub);
+  bt.lb_out = reinterpret_cast<int32_t*>(base + o_lb); bt.ub_out = reinterpret_cast<int32_t*>(base + o_ub);
+  bt.active_in = active ? reinterpret_cast<uint64_t*>(base + o_act) : nullptr;
+  bt.active_out = active ? reinterpret_cast<uint64_t*>(base + o_act) : nullptr;
+  bt.status = base + o_st;
+  rc = pcp_propagate_device(c, n_nodes, &bt, stream);
+  if (rc) return rc;
+  if (dom_bytes) {
+    HIP_TRY(c, hipMemcpyAsync(lb, base + o_lb, dom_bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(c, hipMemcpyAsync(ub, base + o_ub, dom_bytes, hipMemcpyDeviceToHost, stream));
+  }
+  if (active && act_bytes) HIP_TRY(c, hipMemcpyAsync(active, base + o_act, act_bytes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(c, hipMemcpyAsync(status, base + o_st, n_nodes, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(c, hipStreamSynchronize(stream));
+  if (stats) {
+    pcp_stats after;
+    rc = pcp_stats_read(c, &after, stream);
+    if (rc) return rc;
+    stats->steps = after.steps - before.steps; stats->steps3 = after.steps3 - before.steps3;
+    stats->narrowings = after.narrowings - before.narrowings; stats->waves = after.waves - before.waves;
+    stats->failed_nodes = after.failed_nodes - before.failed_nodes; stats->nodes = after.nodes - before.nodes;
+  }
+  return PCP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// pcp_internal.h — shared between the C-ABI host code (pcp_api.hip) and the gfx950 kernels (pcp_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcp_hip.h"
+
+namespace pcp {
+
+// One elementary filter as the kernels see it: 16 bytes, one dwordx4 load per lane.
+//   xk : operand-x slot | kind << 28          (slot = index into the node's extended domain array)
+//   y,z: operand slots (z unused for binary kinds)
+//   d  : the single folded offset.  Binary kinds relate  X = dom[x]  and  Y = dom[y] + d.
+//        Ternary kinds relate  x  and  y + z + d.   (EQ3: geq uses d-1, leq uses d+1.)
+// Constants are interned as pseudo-variables in slots [n_vars, n_slots): their domain is the singleton
+// {c}; narrowing it empties it, which is exactly Constant::update returning false (term/constant.rs:49-52).
+struct __attribute__((aligned(16))) Rec {
+  uint32_t xk;
+  uint32_t y;
+  uint32_t z;
+  int32_t d;
+};
+static_assert(sizeof(Rec) == 16, "Rec must be 16 bytes");
+
+constexpr uint32_t kSlotMask = 0x0FFFFFFFu;
+constexpr uint32_t kMaxSlots = 1u << 26;  // (node, slot) pairs are packed into 32 bits in the kernels
+
+struct ModelDev {
+  const Rec* recs;          // [n_recs]
+  const uint32_t* adj_off;  // [n_vars + 1]  CSR var -> incident record ids (constants have no adjacency)
+  const uint32_t* adj;      // [adj_off[n_vars]]
+  const int32_t* const_val; // [n_slots - n_vars]
+  uint32_t n_recs;
+  uint32_t n_vars;
+  uint32_t n_slots;  // n_vars + number of interned constants
+  uint32_t has_ternary;
+};
+
+// Per-launch arguments of the fixpoint kernel.
+struct LaunchArgs {
+  ModelDev m;
+  uint32_t n_nodes;
+  uint32_t nodes_per_block;  // B: nodes whose domains one workgroup keeps in LDS (team == 1)
+  uint32_t team;             // G: workgroups cooperating on ONE node (nodes_per_block == 1 when team > 1)
+  uint32_t list_cap;         // capacity of the per-round changed-(node,var) list in LDS
+  const int32_t* lb_in;
+  const int32_t* ub_in;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  const uint64_t* live_in;  // [n_nodes][words] or null = all live
+  uint64_t* live;           // [n_nodes][words] working + output live mask (never null)
+  uint8_t* status;
+  pcp_stats* stats;         // device counters
+  // team mode scratch (per node): arrival ticket, merged changed mask, remaining counter, fail flag
+  uint32_t* team_ticket;    // [n_nodes]
+  uint32_t* team_chg;       // [n_nodes][chg_words]
+  uint32_t* team_remaining; // [n_nodes]
+  uint32_t* team_fail;      // [n_nodes]
+  uint64_t* team_counters;  // [n_nodes][4] steps, steps3, narrowings (merged by the tail block)
+};
+
+struct LaunchPlan {
+  uint32_t grid;
+  uint32_t block;
+  size_t lds_bytes;
+};
+
+// Computes the dynamic-LDS footprint for (n_slots, B, list_cap); returns 0 if it cannot fit.
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block);
+
+hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);
+
+}  // namespace pcp

@@ -1,0 +1,557 @@
+// pcp_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the propagation fixpoint.
+//
+// Replaces, for a batch of independent search nodes, the reference's
+//   Store::consistency = prepare() + propagation_loop()      (propagation/store.rs:125-164, 247-257)
+// i.e. the Reactor/Scheduler loop that pops a propagator, runs propagate()+is_subsumed()
+// (store.rs:166-183), unlinks it when entailed (store.rs:200-207) and wakes the propagators of every
+// changed variable (store.rs:191-198, reactors/indexed_deps.rs:99-113).
+//
+// MI355X design:
+//  * one workgroup owns the domains of B nodes in LDS as (lb,ub) int2 pairs (ds_read_b64), narrowed with
+//    ds_max/ds_min atomics; the propagator table is streamed once per workgroup as 16-byte records
+//    (global_load_dwordx4, 1 KiB per wave instruction) and applied to all B nodes;
+//  * wave 0 is the reference's "schedule every active propagator" (store.rs:144-149) as a coalesced sweep;
+//    the 64 lanes of a wavefront hold 64 consecutive propagators = exactly one u64 word of the node's
+//    `active` BitSet, so entailment is published with one __ballot and one 8-byte store;
+//  * later waves visit only the propagators incident to changed variables (CSR var->records), found by a
+//    ballot/prefix-sum compaction of the per-node changed-variable bitmask — the IndexedDeps::react step;
+//  * when few nodes are in flight (the reference's one-node-per-call use) a node is split over a TEAM of
+//    workgroups: each sweeps a slice with a private LDS copy, merges narrowings with device-scope
+//    atomicMax/atomicMin, and the last arriver (ticket counter, agent-scope release/acquire) finishes
+//    the fixpoint alone — no grid barrier, no co-residency requirement.
+// Integer bound work only: no MFMA.  All filters are monotone and contracting, so the wave schedule reaches
+// the same greatest fixpoint as the reference's FIFO (SURVEY.md §7 "chaotic-iteration equivalence").
+#include "pcp_internal.h"
+
+namespace pcp {
+
+namespace {
+
+constexpr int kWave = 64;
+
+struct Ctr {  // per-thread counters, reduced once per block
+  uint32_t steps2 = 0, steps3 = 0, narrow = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Domain access policy: node-local (lb,ub) pairs in LDS.
+// ------------------------------------------------------------------------------------------------
+struct LdsDom {
+  int2* dom;       // [n_slots]
+  uint32_t* chg;   // next-wave changed bitmask [ceil(n_slots/32)]
+  uint32_t* fail;  // block fail mask
+  uint32_t fbit;   // this node's bit in *fail
+  Ctr* c;
+
+  __device__ __forceinline__ int2 load(uint32_t v) const { return dom[v]; }
+  __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
+  __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
+  // lb := max(lb, nlb).  Called only when nlb exceeds the lb this thread read.
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    int old = atomicMax(&dom[v].x, nlb);
+    if (old < nlb) {
+      ++c->narrow;
+      mark(v);
+      int ub = __hip_atomic_load(&dom[v].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (nlb > ub) set_fail();
+    }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    int old = atomicMin(&dom[v].y, nub);
+    if (old > nub) {
+      ++c->narrow;
+      mark(v);
+      int lb = __hip_atomic_load(&dom[v].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lb > nub) set_fail();
+    }
+  }
+};
+
+__device__ __forceinline__ int clamp_i32(long long v) {
+  const long long lo = -2147483647LL, hi = 2147483647LL;
+  return (int)(v < lo ? lo : (v > hi ? hi : v));
+}
+
+// x < y + z + d      (XLessYPlusZ::propagate, x_less_y_plus_z.rs:105-119; all three updates from pre-read values)
+template <class D>
+__device__ __forceinline__ void filter_lt3(int2& X, int2& Y, int2& Z, uint32_t x, uint32_t y, uint32_t z, long long d, const D& dm) {
+  int nxu = min(X.y, clamp_i32((long long)Y.y + Z.y + d - 1));
+  int nyl = max(Y.x, clamp_i32((long long)X.x - Z.y - d + 1));
+  int nzl = max(Z.x, clamp_i32((long long)X.x - Y.y - d + 1));
+  if (nxu < X.y) { X.y = nxu; dm.lower_ub(x, nxu); }
+  if (nyl > Y.x) { Y.x = nyl; dm.raise_lb(y, nyl); }
+  if (nzl > Z.x) { Z.x = nzl; dm.raise_lb(z, nzl); }
+  if (X.x > X.y || Y.x > Y.y || Z.x > Z.y) dm.set_fail();
+}
+// x > y + z + d      (XGreaterYPlusZ::propagate, x_greater_y_plus_z.rs:106-118)
+template <class D>
+__device__ __forceinline__ void filter_gt3(int2& X, int2& Y, int2& Z, uint32_t x, uint32_t y, uint32_t z, long long d, const D& dm) {
+  int nxl = max(X.x, clamp_i32((long long)Y.x + Z.x + d + 1));
+  int nyu = min(Y.y, clamp_i32((long long)X.y - Z.x - d - 1));
+  int nzu = min(Z.y, clamp_i32((long long)X.y - Y.x - d - 1));
+  if (nxl > X.x) { X.x = nxl; dm.raise_lb(x, nxl); }
+  if (nyu < Y.y) { Y.y = nyu; dm.lower_ub(y, nyu); }
+  if (nzu < Z.y) { Z.y = nzu; dm.lower_ub(z, nzu); }
+  if (X.x > X.y || Y.x > Y.y || Z.x > Z.y) dm.set_fail();
+}
+
+// One filter step = propagate() + is_subsumed() of one elementary propagator (store.rs:166-183).
+// Returns true when the propagator is entailed (SKleene::True) under the domains it leaves behind.
+template <class D>
+__device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
+  const uint32_t kind = rec.xk >> 28;
+  const uint32_t x = rec.xk & kSlotMask, y = rec.y;
+  const int d = rec.d;
+  if (kind <= PCP_LT) {
+    ++dm.c->steps2;
+    int2 X = dm.load(x), Y = dm.load(y);
+    int Yl = Y.x + d, Yu = Y.y + d;  // Y as seen through Addition(y, d)  (term/addition.rs:98)
+    if (kind == PCP_NEQ) {
+      // XNeqY::propagate (x_neq_y.rs:82-93) with Interval::difference removing a value only at a bound.
+      if (X.x == X.y) {
+        const int v = X.x;
+        if (v == Yl) { ++Yl; dm.raise_lb(y, Yl - d); }
+        else if (v == Yu) { --Yu; dm.lower_ub(y, Yu - d); }
+      } else if (Yl == Yu) {
+        const int v = Yl;
+        if (v == X.x) { ++X.x; dm.raise_lb(x, X.x); }
+        else if (v == X.y) { --X.y; dm.lower_ub(x, X.y); }
+      }
+      if (X.x > X.y || Yl > Yu) dm.set_fail();
+      // !XEqY::is_subsumed (x_neq_y.rs:71-73, x_eq_y.rs:87-93): True iff disjoint.
+      return (X.x > Yu) || (Yl > X.y);
+    } else if (kind == PCP_EQ) {
+      // XEqY::propagate (x_eq_y.rs:102-107): both become x ∩ y.
+      const int nl = max(X.x, Yl), nu = min(X.y, Yu);
+      if (nl > X.x) dm.raise_lb(x, nl);
+      if (nu < X.y) dm.lower_ub(x, nu);
+      if (nl > Yl) dm.raise_lb(y, nl - d);
+      if (nu < Yu) dm.lower_ub(y, nu - d);
+      if (nl > nu) dm.set_fail();
+      return nl == nu;  // x_eq_y.rs:87-88: both the same singleton
+    } else {
+      // XLessY::propagate (x_less_y.rs:104-109), both updates from the pre-read values.
+      const int nxu = min(X.y, Yu - 1);
+      const int nYl = max(Yl, X.x + 1);
+      if (nxu < X.y) dm.lower_ub(x, nxu);
+      if (nYl > Yl) dm.raise_lb(y, nYl - d);
+      if (X.x > nxu || nYl > Yu) dm.set_fail();
+      return nxu < nYl;  // x_less_y.rs:90-91: x.upper() < y.lower()
+    }
+  }
+  ++dm.c->steps3;
+  const uint32_t z = rec.z;
+  int2 X = dm.load(x), Y = dm.load(y), Z = dm.load(z);
+  if (kind == PCP_LT3) {
+    filter_lt3(X, Y, Z, x, y, z, (long long)d, dm);
+    return (long long)X.y < (long long)Y.x + Z.x + d;  // x_less_y_plus_z.rs:90-91
+  } else if (kind == PCP_GT3) {
+    filter_gt3(X, Y, Z, x, y, z, (long long)d, dm);
+    return (long long)X.x > (long long)Y.y + Z.y + d;  // x_greater_y_plus_z.rs:91-92
+  } else if (kind == PCP_EQ3) {
+    // XEqYPlusZ = geq.propagate() && leq.propagate() (x_eq_y_plus_z.rs:85-87): leq reads what geq left.
+    // geq: (x+1) > y+z  <=>  x > y+z+(d-1);   leq: (x-1) < y+z  <=>  x < y+z+(d+1)   (cmp/mod.rs:62-86)
+    filter_gt3(X, Y, Z, x, y, z, (long long)d - 1, dm);
+    filter_lt3(X, Y, Z, x, y, z, (long long)d + 1, dm);
+    const bool geq_true = (long long)X.x > (long long)Y.y + Z.y + d - 1;
+    const bool leq_true = (long long)X.y < (long long)Y.x + Z.x + d + 1;
+    return geq_true && leq_true;  // Kleene and (x_eq_y_plus_z.rs:65-67)
+  } else {
+    // XEqYMulZ (x_eq_y_mul_z.rs:99-105): x := x ∩ (y·z); here X = dom[x] + d (offsets on y,z are rejected on the host).
+    const long long p0 = (long long)Y.x * Z.x, p1 = (long long)Y.x * Z.y, p2 = (long long)Y.y * Z.x, p3 = (long long)Y.y * Z.y;
+    const long long pl = min(min(p0, p1), min(p2, p3)), pu = max(max(p0, p1), max(p2, p3));
+    const int nl = max(X.x, clamp_i32(pl - d)), nu = min(X.y, clamp_i32(pu - d));
+    if (nl > X.x) dm.raise_lb(x, nl);
+    if (nu < X.y) dm.lower_ub(x, nu);
+    if (nl > nu) dm.set_fail();
+    return pl == pu && nl == nu;  // x_eq_y_mul_z.rs:81-86
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-wide exclusive scan of one value per thread (wave shuffle scan + LDS for wave totals).
+// `tmp` has >= 33 words.  Returns the exclusive prefix; *total_out (LDS) holds the grand total after return.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* tmp, uint32_t* total_out) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    uint32_t t = __shfl_up(inc, o);
+    if (lane >= (uint32_t)o) inc += t;
+  }
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    uint32_t w = lane < nw ? tmp[lane] : 0u;
+    uint32_t winc = w;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      uint32_t t = __shfl_up(winc, o);
+      if (lane >= (uint32_t)o) winc += t;
+    }
+    if (lane < nw) tmp[lane] = winc - w;  // exclusive wave offsets
+    if (lane == nw - 1) *total_out = winc;
+  }
+  __syncthreads();
+  return tmp[wave] + inc - v;
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+}  // namespace
+
+// LDS carve (all offsets multiples of 16 bytes).
+struct Carve {
+  size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
+};
+__host__ __device__ inline Carve carve(uint32_t n_slots, uint32_t B, uint32_t list_cap) {
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t Wv = (n_slots + 31) / 32;
+  Carve c;
+  size_t o = 0;
+  c.dom = o; o = up(o + (size_t)B * n_slots * 8);
+  c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
+  c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
+  c.list_id = o; o = up(o + (size_t)list_cap * 4);
+  c.list_pre = o; o = up(o + ((size_t)list_cap + 1) * 4);
+  c.tmp = o; o = up(o + 40 * 4);
+  c.remaining = o; o = up(o + (size_t)B * 4);
+  c.misc = o; o = up(o + 16 * 4);
+  c.total = o;
+  return c;
+}
+
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block) {
+  (void)block;
+  Carve c = carve(n_slots, nodes_per_block, list_cap);
+  return c.total <= 160 * 1024 ? c.total : 0;
+}
+
+// misc[] indices
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_STEPS2 = 4, M_STEPS3 = 5, M_NARROW = 6, M_WAVES = 7, M_ROUNDMASK = 8 };
+
+// ------------------------------------------------------------------------------------------------
+// One pass over 64-record words [w0, w1) for the nb nodes of this block.
+//   FILTER == false : every live record (the reference's init_scheduler, store.rs:144-149)
+//   FILTER == true  : only live records touching a variable in `cur` (dense wake-up round)
+// The wavefront's 64 lanes hold 64 consecutive records == one u64 word of each node's live mask.
+// ------------------------------------------------------------------------------------------------
+template <bool FILTER>
+__device__ __forceinline__ void sweep_words(const LaunchArgs& a, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb, int2* dom,
+                                            uint32_t* cur, uint32_t* nxt, uint32_t* misc, const uint64_t* live_src, uint32_t& rem_acc,
+                                            Ctr& ctr) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t P = a.m.n_recs, words = (P + 63) >> 6, S = a.m.n_slots, Wv = (S + 31) >> 5;
+  const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
+  for (uint32_t w = w0 + wave; w < w1; w += nw) {
+    const uint32_t r = (w << 6) + lane;
+    Rec rec;
+    if (r < P) rec = a.m.recs[r];
+    else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
+    uint64_t my_word = 0;
+    if (lane < nb) {
+      my_word = live_src ? live_src[(size_t)(node0 + lane) * words + w] : ~0ull;
+      if (w == words - 1) my_word &= tail_mask;
+    }
+    const uint32_t failm = __hip_atomic_load(&misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t x = rec.xk & kSlotMask;
+    const bool tern = (rec.xk >> 28) > PCP_LT;
+    for (uint32_t b = 0; b < nb; ++b) {
+      const uint64_t word = readlane64(my_word, b);
+      if ((failm >> b) & 1u) continue;
+      uint64_t nword = word;
+      if (word != 0) {
+        bool mine = (word >> lane) & 1ull;
+        if (FILTER) {
+          const uint32_t* cb = cur + (size_t)b * Wv;
+          bool touched = ((cb[x >> 5] >> (x & 31)) & 1u) | ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u);
+          if (tern) touched |= (cb[rec.z >> 5] >> (rec.z & 31)) & 1u;
+          mine = mine && touched;
+        }
+        bool ent = false;
+        if (mine) {
+          LdsDom dm{dom + (size_t)b * S, nxt + (size_t)b * Wv, &misc[M_FAIL], 1u << b, &ctr};
+          ent = eval_record(rec, dm);
+        }
+        nword = word & ~__ballot(ent);
+      }
+      if (!FILTER) {
+        if (lane == b) rem_acc += __popcll(nword);
+        if (lane == 0 && (live_src != a.live || nword != word)) a.live[(size_t)(node0 + b) * words + w] = nword;
+      } else {
+        if (lane == b) rem_acc += __popcll(word) - __popcll(nword);  // newly entailed
+        if (lane == 0 && nword != word) a.live[(size_t)(node0 + b) * words + w] = nword;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
+  const uint32_t B = a.nodes_per_block, team = a.team, C = a.list_cap;
+  const Carve cv = carve(S, B, C);
+  int2* dom = reinterpret_cast<int2*>(smem + cv.dom);
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
+  uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
+  uint32_t* list_id = reinterpret_cast<uint32_t*>(smem + cv.list_id);
+  uint32_t* list_pre = reinterpret_cast<uint32_t*>(smem + cv.list_pre);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + cv.tmp);
+  uint32_t* remaining = reinterpret_cast<uint32_t*>(smem + cv.remaining);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+
+  uint32_t node0, nb, g;
+  if (team > 1) { node0 = blockIdx.x / team; g = blockIdx.x % team; nb = 1; }
+  else { node0 = blockIdx.x * B; g = 0; nb = min(B, a.n_nodes - node0); }
+
+  // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
+  if (tid < 16) misc[tid] = 0;
+  if (tid < B) remaining[tid] = 0;
+  for (uint32_t i = tid; i < B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
+  __syncthreads();
+  for (uint32_t b = 0; b < nb; ++b) {
+    const int32_t* lbp = a.lb_in + (size_t)(node0 + b) * V;
+    const int32_t* ubp = a.ub_in + (size_t)(node0 + b) * V;
+    // team > 1: the merged arrays (lb_out) are the ones every slice narrows with atomics; they were
+    // initialised from lb_in by the host before the launch, so read the inputs here.
+    bool bad = false;
+    for (uint32_t v = tid; v < S; v += nth) {
+      int2 d;
+      if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
+      else { d.x = d.y = a.m.const_val[v - V]; }
+      dom[(size_t)b * S + v] = d;
+    }
+    if (bad) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
+  }
+  __syncthreads();
+
+  Ctr ctr;
+  uint32_t rem_acc = 0;
+
+  // ---- phase 1: wave 0 = every live propagator once (slice of the table when team > 1) -------------------
+  {
+    uint32_t w0 = 0, w1 = words;
+    if (team > 1) { const uint32_t ws = (words + team - 1) / team; w0 = min(words, g * ws); w1 = min(words, w0 + ws); }
+    // sweep writes "next" bits into `cur` so that the first round reads them as its current set
+    sweep_words<false>(a, w0, w1, node0, nb, dom, nxt, cur, misc, a.live_in, rem_acc, ctr);
+    if (lane < nb && rem_acc) atomicAdd(&remaining[lane], rem_acc);
+    rem_acc = 0;
+  }
+  // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
+  // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase 2 (team mode): merge this slice into the node's global arrays; the last arriver continues ---
+  if (team > 1) {
+    int32_t* glb = a.lb_out + (size_t)node0 * V;
+    int32_t* gub = a.ub_out + (size_t)node0 * V;
+    uint32_t* gchg = a.team_chg + (size_t)node0 * Wv;
+    for (uint32_t w = tid; w < Wv; w += nth) {
+      uint32_t bits = cur[w];
+      if (bits) atomicOr(&gchg[w], bits);
+      while (bits) {
+        const uint32_t v = (w << 5) + __builtin_ctz(bits);
+        bits &= bits - 1;
+        if (v < V) { atomicMax(&glb[v], dom[v].x); atomicMin(&gub[v], dom[v].y); }
+      }
+    }
+    // block-reduce counters into the node's team counters (the tail block adds its own later)
+    for (int o = 32; o > 0; o >>= 1) {
+      ctr.steps2 += __shfl_down(ctr.steps2, o);
+      ctr.steps3 += __shfl_down(ctr.steps3, o);
+      ctr.narrow += __shfl_down(ctr.narrow, o);
+    }
+    if (lane == 0) {
+      if (ctr.steps2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], (unsigned long long)ctr.steps2);
+      if (ctr.steps3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], (unsigned long long)ctr.steps3);
+      if (ctr.narrow) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 2], (unsigned long long)ctr.narrow);
+    }
+    ctr = Ctr();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its merge atomics have been performed
+    __syncthreads();
+    if (tid == 0) {
+      if (remaining[0]) atomicAdd(&a.team_remaining[node0], remaining[0]);
+      if (misc[M_FAIL]) atomicOr(&a.team_fail[node0], 1u);
+      // publish: agent-scope release, drain, then take a ticket (MI355X_MICROARCH "valid forms")
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const uint32_t ticket = __hip_atomic_fetch_add(&a.team_ticket[node0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t last = (ticket == team - 1) ? 1u : 0u;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      misc[M_ISLAST] = last;
+    }
+    __syncthreads();
+    if (!misc[M_ISLAST]) return;
+    // tail block: reload the merged state
+    for (uint32_t v = tid; v < V; v += nth) {
+      int2 d;
+      d.x = __hip_atomic_load(&glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d.y = __hip_atomic_load(&gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dom[v] = d;
+    }
+    for (uint32_t w = tid; w < Wv; w += nth) {
+      cur[w] = __hip_atomic_load(&gchg[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nxt[w] = 0;
+    }
+    if (tid == 0) {
+      remaining[0] = __hip_atomic_load(&a.team_remaining[node0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      misc[M_FAIL] = __hip_atomic_load(&a.team_fail[node0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 3: wake-up rounds until no variable changes (IndexedDeps::react + RelaxedFifo, as waves) ------
+  uint32_t rounds = 0;
+  const uint32_t TW = nb * Wv;
+  for (;;) {
+    // (a) count changed (node,var) pairs of live nodes
+    const uint32_t failm = misc[M_FAIL];
+    uint32_t cnt = 0;
+    for (uint32_t w = tid; w < TW; w += nth) {
+      const uint32_t b = w / Wv;
+      if (!((failm >> b) & 1u)) {
+        const uint32_t bits = cur[w];
+        cnt += __popc(bits);
+        if (bits) atomicOr(&misc[M_ROUNDMASK], 1u << b);
+      }
+    }
+    uint32_t off = block_exclusive_scan(cnt, tmp, &misc[M_TOTAL]);
+    const uint32_t total = misc[M_TOTAL];
+    if (total == 0) break;
+    ++rounds;
+    if (total <= C) {
+      // (b) compact them into a list with each variable's degree, prefix-sum the degrees
+      for (uint32_t w = tid; w < TW; w += nth) {
+        const uint32_t b = w / Wv;
+        if ((failm >> b) & 1u) continue;
+        uint32_t bits = cur[w];
+        const uint32_t vbase = (w - b * Wv) << 5;
+        while (bits) {
+          const uint32_t v = vbase + __builtin_ctz(bits);
+          bits &= bits - 1;
+          list_id[off] = (b << 26) | v;
+          list_pre[off] = (v < V) ? (a.m.adj_off[v + 1] - a.m.adj_off[v]) : 0u;
+          ++off;
+        }
+      }
+      __syncthreads();
+      // exclusive scan of list_pre[0..total) in place, chunked per thread
+      {
+        const uint32_t per = (total + nth - 1) / nth;
+        const uint32_t s = min(total, tid * per), e = min(total, s + per);
+        uint32_t sum = 0;
+        for (uint32_t i = s; i < e; ++i) sum += list_pre[i];
+        uint32_t base = block_exclusive_scan(sum, tmp, &misc[M_ITEMS]);
+        for (uint32_t i = s; i < e; ++i) { const uint32_t dg = list_pre[i]; list_pre[i] = base; base += dg; }
+        if (tid == 0) list_pre[total] = misc[M_ITEMS];
+      }
+      __syncthreads();
+      const uint32_t T = misc[M_ITEMS];
+      // (c) one item = one (changed var, incident record): flat, load-balanced over the whole block
+      for (uint32_t i = tid; i < T; i += nth) {
+        uint32_t lo = 0, hi = total;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
+        const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
+        const uint32_t r = a.m.adj[a.m.adj_off[v] + (i - list_pre[lo])];
+        uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
+        const uint32_t bit = 1u << (r & 31);
+        if (!(__hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) continue;  // unlinked (store.rs:200-207)
+        const Rec rec = a.m.recs[r];
+        // RelaxedFifo dedup (relaxed_fifo.rs:42-48): a record woken by several changed variables runs once,
+        // from the lowest-numbered one.
+        const uint32_t* cb = cur + (size_t)b * Wv;
+        const uint32_t x = rec.xk & kSlotMask;
+        bool skip = false;
+        if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) skip = true;
+        if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) skip = true;
+        if ((rec.xk >> 28) > PCP_LT && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) skip = true;
+        if (skip) continue;
+        LdsDom dm{dom + (size_t)b * S, nxt + (size_t)b * Wv, &misc[M_FAIL], 1u << b, &ctr};
+        if (eval_record(rec, dm)) {
+          const uint32_t old = atomicAnd(lw, ~bit);
+          if (old & bit) atomicSub(&remaining[b], 1u);
+        }
+      }
+    } else {
+      // dense round: more changed variables than the list holds — stream the table again, filtered.
+      __syncthreads();
+      sweep_words<true>(a, 0, words, node0, nb, dom, cur, nxt, misc, a.live, rem_acc, ctr);
+      if (lane < nb && rem_acc) atomicSub(&remaining[lane], rem_acc);
+      rem_acc = 0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (uint32_t i = tid; i < TW; i += nth) cur[i] = 0;
+    uint32_t* t = cur; cur = nxt; nxt = t;
+    if (tid == 0) { misc[M_WAVES] += __popc(misc[M_ROUNDMASK]); misc[M_ROUNDMASK] = 0; }
+    __syncthreads();
+  }
+
+  // ---- phase 4: write back domains, status, counters ---------------------------------------------------
+  __syncthreads();
+  for (uint32_t b = 0; b < nb; ++b) {
+    int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
+    int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
+    bool bad = false;
+    for (uint32_t v = tid; v < S; v += nth) {
+      const int2 d = dom[(size_t)b * S + v];
+      bad |= d.x > d.y;
+      if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
+    }
+    if (bad) atomicOr(&misc[M_FAIL], 1u << b);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ctr.steps2 += __shfl_down(ctr.steps2, o);
+    ctr.steps3 += __shfl_down(ctr.steps3, o);
+    ctr.narrow += __shfl_down(ctr.narrow, o);
+  }
+  if (lane == 0) {
+    if (ctr.steps2) atomicAdd(&misc[M_STEPS2], ctr.steps2);
+    if (ctr.steps3) atomicAdd(&misc[M_STEPS3], ctr.steps3);
+    if (ctr.narrow) atomicAdd(&misc[M_NARROW], ctr.narrow);
+  }
+  __syncthreads();
+  if (tid < nb) {
+    const bool failed = (misc[M_FAIL] >> tid) & 1u;
+    // Consistency::consistency (store.rs:250-256): False if a propagate failed, True if no subscription
+    // remains (every live propagator got entailed), else Unknown.
+    a.status[node0 + tid] = failed ? (uint8_t)PCP_FALSE : (remaining[tid] == 0 ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
+  }
+  if (tid == 0) {
+    unsigned long long s2 = misc[M_STEPS2], s3 = misc[M_STEPS3], nr = misc[M_NARROW];
+    if (team > 1) {
+      s2 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s3 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nr += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    atomicAdd((unsigned long long*)&a.stats->steps, s2);
+    if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
+    if (nr) atomicAdd((unsigned long long*)&a.stats->narrowings, nr);
+    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[M_WAVES]));
+    atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
+    const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));
+    if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+  }
+  (void)rounds;
+}
+
+hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (p.lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(fixpoint_kernel, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace pcp

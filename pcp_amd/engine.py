@@ -1,0 +1,198 @@
+"""ctypes binding of libpcp_hip.so — the C ABI declared in include/pcp_hip.h.
+
+This is the product path: every call goes through the C-ABI into the hand-written gfx950 kernels.  There is
+no CPU fallback: importing works anywhere (so that the non-GPU tests can check the exported symbols), but
+``Context()`` raises ``EngineUnavailable`` when the library or a HIP device is missing.
+PyTorch is used only as plumbing (device buffers, streams); the ABI itself takes raw pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from .model import PROP_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcp_hip.so")
+
+PCP_OK = 0
+ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP_ERR_NOMEM", -5: "PCP_ERR_UNSUPPORTED", -6: "PCP_ERR_NODEVICE"}
+
+# Every symbol include/pcp_hip.h declares (tests/test_abi.py checks the .so exports each of them).
+ABI_SYMBOLS = [
+    "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
+    "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
+    "pcp_propagate", "pcp_propagate_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option",
+]
+
+
+class PcpStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("steps", "steps3", "narrowings", "waves", "failed_nodes", "nodes")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class DeviceBatch(C.Structure):
+    _fields_ = [("lb_in", C.c_void_p), ("ub_in", C.c_void_p), ("lb_out", C.c_void_p), ("ub_out", C.c_void_p),
+                ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p)]
+
+
+class EngineUnavailable(RuntimeError):
+    """libpcp_hip.so is missing or no HIP device is present.  There is deliberately no fallback."""
+
+
+class PcpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpcp_hip.so and declare the prototypes.  Raises EngineUnavailable if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineUnavailable(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # missing HIP runtime etc.
+        raise EngineUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    L.pcp_abi_version.restype = u32
+    L.pcp_strerror.restype = C.c_char_p
+    L.pcp_strerror.argtypes = [i32]
+    L.pcp_last_error.restype = C.c_char_p
+    L.pcp_last_error.argtypes = [vp]
+    L.pcp_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.pcp_ctx_destroy.argtypes = [vp]
+    L.pcp_ctx_destroy.restype = None
+    L.pcp_model_reset.argtypes = [vp, u32, u32]
+    L.pcp_model_push_props.argtypes = [vp, u32, vp]
+    L.pcp_model_truncate.argtypes = [vp, u32]
+    L.pcp_model_n_units.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.pcp_propagate.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
+    L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
+    L.pcp_stats_reset.argtypes = [vp, vp]
+    L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
+    L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
+              "pcp_propagate", "pcp_propagate_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option"):
+        getattr(L, f).restype = i32
+    _lib = L
+    return L
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One pcp_ctx == one constraint store (CStore) on one GPU."""
+
+    def __init__(self, device: int = 0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.pcp_ctx_create(device, C.byref(h))
+        if rc == -6:
+            raise EngineUnavailable("pcp_ctx_create: no HIP device (PCP_ERR_NODEVICE); the engine has no CPU path")
+        if rc != 0:
+            raise PcpError(rc, self._L.pcp_strerror(rc).decode())
+        self._h = h
+        self.device = device
+        self.n_vars = 0
+        self.n_units = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.pcp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise PcpError(rc, self._L.pcp_last_error(self._h).decode())
+
+    # ---- model ------------------------------------------------------------------------------------------
+    def set_model(self, n_vars: int, props: np.ndarray):
+        """pcp_model_reset + pcp_model_push_props."""
+        props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
+        self._check(self._L.pcp_model_reset(self._h, n_vars, 0))
+        self.n_vars = int(n_vars)
+        self.push_props(props)
+
+    def push_props(self, props: np.ndarray):
+        props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
+        if len(props):
+            self._check(self._L.pcp_model_push_props(self._h, len(props), _np_ptr(props)))
+        self._refresh()
+
+    def truncate(self, n_units: int):
+        self._check(self._L.pcp_model_truncate(self._h, n_units))
+        self._refresh()
+
+    def _refresh(self):
+        nu, npr = C.c_uint32(), C.c_uint32()
+        self._check(self._L.pcp_model_n_units(self._h, C.byref(nu), C.byref(npr)))
+        self.n_units, self.n_props = nu.value, npr.value
+        self.words = (self.n_units + 63) // 64
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.pcp_set_option(self._h, key.encode(), int(value)))
+
+    # ---- propagation, host buffers (pcp_propagate) ----------------------------------------------------------
+    def propagate(self, lb, ub, active: Optional[np.ndarray] = None, want_stats: bool = True):
+        """≡ Consistency::consistency on each row.  Returns (lb, ub, active, status, stats) as fresh arrays."""
+        lb = np.array(lb, dtype=np.int32, order="C")
+        ub = np.array(ub, dtype=np.int32, order="C")
+        n = lb.shape[0] if lb.ndim == 2 else 1
+        lb = lb.reshape(n, self.n_vars)
+        ub = ub.reshape(n, self.n_vars)
+        if active is not None:
+            active = np.array(active, dtype=np.uint64, order="C").reshape(n, self.words)
+        status = np.zeros(n, dtype=np.uint8)
+        st = PcpStats()
+        self._check(self._L.pcp_propagate(self._h, n, _np_ptr(lb), _np_ptr(ub), None, _np_ptr(active), _np_ptr(status),
+                                          C.byref(st) if want_stats else None))
+        return lb, ub, active, status, st.as_dict()
+
+    # ---- propagation, device-resident (pcp_propagate_device) ------------------------------------------------
+    def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0):
+        """All arguments are torch tensors on this context's device (or None for the optional masks); nothing is
+        synchronised.  Tensors: lb/ub int32 [n,V]; active int64/uint64 [n,words]; status uint8 [n]."""
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status))
+        self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
+
+    def stats_reset(self, stream_ptr: int = 0):
+        self._check(self._L.pcp_stats_reset(self._h, C.c_void_p(stream_ptr)))
+
+    def stats_read(self, stream_ptr: int = 0) -> dict:
+        st = PcpStats()
+        self._check(self._L.pcp_stats_read(self._h, C.byref(st), C.c_void_p(stream_ptr)))
+        return st.as_dict()
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self._L.pcp_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def full_active(n_nodes: int, n_units: int) -> np.ndarray:
+    """`active` rows with every unit set (Store::alloc inserts each new propagator, propagation/store.rs:227)."""
+    words = (n_units + 63) // 64
+    a = np.full((n_nodes, words), np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    if words and n_units % 64:
+        a[:, -1] = np.uint64((1 << (n_units % 64)) - 1)
+    return a

@@ -1,0 +1,182 @@
+"""Parity tests proper: the HIP engine, called through the C-ABI (pcp_amd.engine -> libpcp_hip.so), against
+the CPU oracle on the same seeded inputs.  Bar: status equal on every node; on nodes that are
+not False, (lb,ub) and `active` bit-exact.  Integer work: no tolerance anywhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from pcp_amd import model as M
+import pcp_amd.engine as E
+
+from util import assert_parity, random_active, random_csp, random_nodes
+from test_oracle_golden import build_unit
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = E.Context(0)
+    yield c
+    c.close()
+
+
+def both(ctx, n_vars, props, lb, ub, active, what, **opts):
+    om = orc.OracleModel(n_vars, props)
+    ref = om.consistency(lb, ub, active)
+    ctx.set_model(n_vars, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+        ctx.set_option(k, v)
+    got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
+    assert_parity(ref[:4], got[:4], what)
+    return ref, got
+
+
+def test_kat_inputs_as_one_node_fixpoints(ctx):
+    """Every transcribed reference KAT input (tests/golden/propagator_kats.json) as a one-unit store."""
+    data = json.load(open(os.path.join(GOLDEN, "propagator_kats.json")))
+    n_cases = 0
+    for s in data["suites"]:
+        if s["ctor"] == "Distinct":
+            continue  # Conjunction groups: covered once groups are lowered
+        for c in s["cases"]:
+            unit = build_unit(s, c)
+            n = len(c["doms"])
+            props = M.lower_units([unit], n)
+            lb = np.array([[d[0] for d in c["doms"]]], np.int32)
+            ub = np.array([[d[1] for d in c["doms"]]], np.int32)
+            ref, got = both(ctx, n, props, lb, ub, None, f"{s['name']}#{c['n']}")
+            # one propagate() that fails <=> the one-unit fixpoint is False
+            assert (ref[3][0] == M.FALSE) == (not c["ok"])
+            n_cases += 1
+    assert n_cases >= 80
+
+
+def test_engine_answers(ctx):
+    """The reference's (commented-out) engine tests: chained X1<...<Xn on [1,10] (propagation/store.rs:362-385)."""
+    g = json.load(open(os.path.join(GOLDEN, "engine_kats.json")))["engine"]
+    K = {"F": 0, "T": 1, "U": 2}
+    for n, exp in g["chained_lt"]["cases"]:
+        vs, cs = M.chained_lt(n)
+        lb, ub = vs.bounds()
+        props = cs.lower(n)
+        ref, got = both(ctx, n, props, lb[None], ub[None], None, f"chained_lt({n})")
+        assert got[3][0] == K[exp]
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("planted", [True, False])
+def test_random_csp_batch(ctx, seed, planted):
+    V, P, N = 40 + 13 * seed, 150 + 60 * seed, 96
+    props, lb, ub, sol = random_csp(1000 + seed, V, P, planted=planted)
+    L, U = random_nodes(2000 + seed, lb, ub, N, sol if planted else None)
+    act = random_active(3000 + seed, N, P, p_off=0.15)
+    both(ctx, V, props, L, U, act, f"csp seed={seed} planted={planted}")
+
+
+@pytest.mark.parametrize("opts", [
+    {"nodes_per_block": 1}, {"nodes_per_block": 3}, {"nodes_per_block": 32}, {"block_threads": 256}, {"block_threads": 512},
+    {"list_cap": 64}, {"force_path": 2, "team": 2}, {"force_path": 2, "team": 7}, {"force_path": 2, "team": 64},
+])
+def test_random_csp_launch_shapes(ctx, opts):
+    """Same answers whatever the launch geometry: tile size, block size, dense-round fallback, team size."""
+    V, P, N = 120, 900, 70
+    props, lb, ub, sol = random_csp(77, V, P, planted=True, dom=(0, 60))
+    L, U = random_nodes(78, lb, ub, N, sol)
+    act = random_active(79, N, P, p_off=0.05)
+    both(ctx, V, props, L, U, act, f"shapes {opts}", **opts)
+
+
+def test_long_cascade(ctx):
+    """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
+    n = 300
+    vs, cs = M.VStore(), M.CStore()
+    xs = [vs.alloc((0, n - 1)) for _ in range(n)]
+    for i in range(n - 1):
+        cs.alloc(M.XLessY(xs[i], xs[i + 1]))
+    lb, ub = vs.bounds()
+    for opts in ({}, {"force_path": 2, "team": 4}):
+        ref, got = both(ctx, n, cs.lower(n), lb[None], ub[None], None, "cascade", **opts)
+        assert got[3][0] == M.TRUE and np.array_equal(got[0][0], np.arange(n))
+
+
+@pytest.mark.parametrize("n", [8, 20, 50])
+def test_nqueens_dfs_nodes(ctx, n):
+    """The first K nodes of the reference's default DFS (FirstSmallestVar/MiddleVal/BinarySplit), each node's
+    folded input domains + active mask -> fixpoint, one launch for all of them, batch and team paths."""
+    props = M.nqueens_props(n)
+    om = orc.OracleModel(n, props)
+    K = 200
+    _, _, rec, _ = om.search(np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True, node_limit=K, max_records=K)
+    keep = (rec["lb_in"] <= rec["ub_in"]).all(axis=1)
+    ref = (rec["lb_out"][keep], rec["ub_out"][keep], rec["active_out"][keep], rec["status"][keep])
+    ctx.set_model(n, props)
+    for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 5}, {"force_path": 2, "team": 3}):
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(rec["lb_in"][keep], rec["ub_in"][keep], rec["active_in"][keep])
+        assert_parity(ref, got[:4], f"nqueens({n}) {opts}")
+    assert (ref[3] == 0).any() or n == 50
+
+
+def test_nqueens_1000_root_and_dive(ctx):
+    """BASELINE config 2 shape: V=1000, P=1 498 500.  Root node plus nodes with q0..q_{k-1} assigned along a
+    diagonal-free prefix; oracle run without the duplicate-subscription assert to stay within seconds."""
+    n = 1000
+    props = M.nqueens_props(n)
+    om = orc.OracleModel(n, props)
+    N = 6
+    L = np.ones((N, n), np.int32)
+    U = np.full((N, n), n, np.int32)
+    prefix = [1, 3, 5, 7, 9, 11, 13, 15]  # q_i = 2i+1: mutually non-attacking
+    for k in range(1, N):
+        for i in range(k + 1):
+            L[k, i] = U[k, i] = prefix[i]
+    ref = om.consistency(L, U, None, check_dup=False)
+    ctx.set_model(n, props)
+    for opts in ({"force_path": 1}, {"force_path": 2}):
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(L, U, E.full_active(N, om.n_units))
+        assert_parity(ref[:4], got[:4], f"nqueens1000 {opts}")
+        assert got[4]["steps"] >= N * om.n_units
+
+
+def test_contract_errors(ctx):
+    ctx.set_model(2, M.lower_units([M.XLessY(M.Identity(0), M.Identity(1))], 2))
+    with pytest.raises(E.PcpError) as e:
+        ctx.propagate(np.array([[3, 0]], np.int32), np.array([[2, 5]], np.int32))  # empty initial domain
+    assert e.value.code == -2
+    bad = M.lower_units([M.XLessY(M.Identity(0), M.Identity(1))], 2)
+    bad["var"][0][1] = 9
+    with pytest.raises(E.PcpError) as e:
+        ctx.set_model(2, bad)
+    assert e.value.code == -2
+    same = M.lower_units([M.XLessY(M.Identity(0), M.Identity(1))], 2)
+    same["var"][0][1] = 0
+    with pytest.raises(E.PcpError) as e:
+        ctx.set_model(2, same)
+    assert e.value.code == -2
+
+
+def test_truncate_mirrors_restore(ctx):
+    """pcp_model_truncate ≡ FrozenStore::restore's truncate (propagation/store.rs:319-323)."""
+    vs, cs = M.chained_lt(10)
+    props = cs.lower(10)
+    lb, ub = vs.bounds()
+    ctx.set_model(10, props)
+    full = ctx.propagate(lb[None], ub[None])
+    assert full[3][0] == M.TRUE
+    ctx.truncate(5)
+    om = orc.OracleModel(10, props[:5])
+    ref = om.consistency(lb[None], ub[None])
+    got = ctx.propagate(lb[None], ub[None], E.full_active(1, 5))
+    assert_parity(ref[:4], got[:4], "truncate")
+    ctx.push_props(props[5:])
+    again = ctx.propagate(lb[None], ub[None])
+    assert np.array_equal(again[0], full[0]) and again[3][0] == M.TRUE
