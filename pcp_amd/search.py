@@ -1,0 +1,142 @@
+"""Host-side search driver over the batched HIP engine — the *caller* side of the hot path.
+
+The reference keeps the search tree on the host (north_star) and calls ``Space::consistency`` once per node
+(search/propagation.rs:42-55).  This driver keeps that structure but hands the engine many open nodes per
+call.  Branching follows the reference's default engine (search/mod.rs:45-52):
+
+* variable  ``FirstSmallestVar``  (search/branching/first_smallest_var.rs:30-39): first index among the
+  variables of minimal size > 1;
+* value     ``MiddleVal``         (search/branching/middle_val.rs:25-27): (lb+ub)/2, truncating toward zero;
+* split     ``BinarySplit``       (search/branching/binary_split.rs:33-60): children ``x <= v`` and ``x > v``.
+
+A branch constraint is a var-vs-constant ``XLessY`` that narrows its one variable on its first run and is then
+entailed and unlinked (x_less_y.rs:87-93, propagation/store.rs:171), so it is folded into the child's bounds
+(SURVEY.md §8b "per-node propagators"); children inherit the parent's ``active`` row, exactly the cstore label
+``(len, active.clone())`` of propagation/store.rs:315-317.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .model import FALSE, TRUE, UNKNOWN
+
+
+def first_smallest_var(lb: np.ndarray, ub: np.ndarray) -> np.ndarray:
+    """Row-wise FirstSmallestVar.  Rows where every variable is assigned return -1 (the reference panics)."""
+    size = ub.astype(np.int64) - lb.astype(np.int64) + 1
+    big = np.iinfo(np.int64).max
+    key = np.where(size > 1, size, big)
+    idx = key.argmin(axis=1)  # argmin returns the FIRST minimum, as min_by_key does
+    none = key[np.arange(key.shape[0]), idx] == big
+    return np.where(none, -1, idx)
+
+
+def middle_val(lb: np.ndarray, ub: np.ndarray) -> np.ndarray:
+    s = lb.astype(np.int64) + ub.astype(np.int64)
+    return (np.sign(s) * (np.abs(s) // 2)).astype(np.int32)  # Rust `/` truncates toward zero
+
+
+def branch(lb: np.ndarray, ub: np.ndarray, active: Optional[np.ndarray]):
+    """BinarySplit children of each (Unknown) row, folded: returns (lb2, ub2, active2) with 2 rows per input row,
+    ordered left child then right child."""
+    n = lb.shape[0]
+    var = first_smallest_var(lb, ub)
+    if (var < 0).any():
+        raise RuntimeError("Cannot select a variable in a space where all variables are assigned.")
+    rows = np.arange(n)
+    v = middle_val(lb[rows, var], ub[rows, var])
+    L = np.repeat(lb, 2, axis=0)
+    U = np.repeat(ub, 2, axis=0)
+    U[2 * rows, var] = np.minimum(U[2 * rows, var], v)          # x <= v
+    L[2 * rows + 1, var] = np.maximum(L[2 * rows + 1, var], v + 1)  # x > v
+    A = None if active is None else np.repeat(active, 2, axis=0)
+    return L, U, A
+
+
+@dataclass
+class SearchStats:
+    num_nodes: int = 0
+    num_solution: int = 0
+    num_failed_node: int = 0
+    launches: int = 0
+    filter_steps: int = 0
+    solutions: List[np.ndarray] = field(default_factory=list)
+
+
+def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds: int = 64) -> Tuple[np.ndarray, np.ndarray, np.ndarray, SearchStats]:
+    """Expand the search tree breadth-first until at least ``n_open`` open (branched, not yet propagated) nodes
+    exist; returns their folded (lb, ub, active) rows, at most ``n_open`` of them, in tree order."""
+    from .engine import full_active
+    st = SearchStats()
+    L = np.ascontiguousarray(lb0, np.int32).reshape(1, -1)
+    U = np.ascontiguousarray(ub0, np.int32).reshape(1, -1)
+    A = full_active(1, ctx.n_units)
+    for _ in range(max_rounds):
+        if L.shape[0] >= n_open or L.shape[0] == 0:
+            break
+        ok = (L <= U).all(axis=1)  # a folded branch can be empty: that child is failed without a launch
+        st.num_failed_node += int((~ok).sum())
+        L, U, A = L[ok], U[ok], A[ok]
+        if L.shape[0] == 0:
+            break
+        lb, ub, act, status, s = ctx.propagate(L, U, A)
+        st.launches += 1
+        st.num_nodes += L.shape[0]
+        st.filter_steps += s["steps"] + s["steps3"]
+        st.num_failed_node += int((status == FALSE).sum())
+        for r in np.nonzero(status == TRUE)[0]:
+            st.num_solution += 1
+            st.solutions.append(lb[r].copy())
+        unk = status == UNKNOWN
+        L, U, A = branch(lb[unk], ub[unk], act[unk])
+    ok = (L <= U).all(axis=1)
+    return L[ok][:n_open], U[ok][:n_open], A[ok][:n_open], st
+
+
+def dfs(ctx, lb0: np.ndarray, ub0: np.ndarray, all_solutions: bool = False, node_limit: int = 0, batch: int = 1) -> SearchStats:
+    """Depth-first search with a LIFO stack of open nodes (gcollections::VectorStack in the reference).  With
+    ``batch=1`` the node order is exactly the reference's left-first DFS (one_solution.rs:46-51, 92-105); with
+    ``batch>1`` the top ``batch`` open nodes are propagated in one launch (batched subtree propagation)."""
+    from .engine import full_active
+    st = SearchStats()
+    stack: List[Tuple[np.ndarray, np.ndarray, np.ndarray]] = [
+        (np.ascontiguousarray(lb0, np.int32), np.ascontiguousarray(ub0, np.int32), full_active(1, ctx.n_units)[0])
+    ]
+    while stack:
+        take = stack[-batch:][::-1]  # top of the stack first
+        del stack[-batch:]
+        if node_limit:
+            take = take[: max(0, node_limit - st.num_nodes)]
+            if not take:
+                break
+        L = np.stack([t[0] for t in take])
+        U = np.stack([t[1] for t in take])
+        A = np.stack([t[2] for t in take])
+        ok = (L <= U).all(axis=1)
+        lb, ub, act, status = L.copy(), U.copy(), A.copy(), np.zeros(L.shape[0], np.uint8)
+        if ok.any():
+            plb, pub, pact, pst, s = ctx.propagate(L[ok], U[ok], A[ok])
+            lb[ok], ub[ok], act[ok], status[ok] = plb, pub, pact, pst
+            st.launches += 1
+            st.filter_steps += s["steps"] + s["steps3"]
+        st.num_nodes += L.shape[0]
+        st.num_failed_node += int((status == FALSE).sum())
+        done = False
+        for r in np.nonzero(status == TRUE)[0]:
+            st.num_solution += 1
+            st.solutions.append(lb[r].copy())
+            if not all_solutions:
+                done = True
+        if done or (node_limit and st.num_nodes >= node_limit):
+            break
+        unk = np.nonzero(status == UNKNOWN)[0]
+        if len(unk):
+            cl, cu, ca = branch(lb[unk], ub[unk], act[unk])
+            # push so that the first taken node's left child ends on top: iterate parents in reverse, right then left
+            for k in range(len(unk) - 1, -1, -1):
+                stack.append((cl[2 * k + 1], cu[2 * k + 1], ca[2 * k + 1]))
+                stack.append((cl[2 * k], cu[2 * k], ca[2 * k]))
+    return st

@@ -79,6 +79,22 @@ def test_random_csp_batch(ctx, seed, planted):
     both(ctx, V, props, L, U, act, f"csp seed={seed} planted={planted}")
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_csp_mixed_statuses(ctx, seed):
+    """Nodes that fail, stay Unknown and become True in the same launch."""
+    V, P, N = 40 + 13 * seed, 100 + 40 * seed, 128
+    props, lb, ub, sol = random_csp(1000 + seed, V, P, planted=True, dom=(0, 12))
+    L, U = random_nodes(2000 + seed, lb, ub, N, None, p_narrow=0.05)
+    act = random_active(3000 + seed, N, P, p_off=0.15)
+    ref, _ = both(ctx, V, props, L, U, act, f"mixed seed={seed}")
+    assert (ref[3] == 0).any() and (ref[3] == 2).any()
+    props, lb, ub, sol = random_csp(5 + seed, 12, 10, planted=True, dom=(0, 3))
+    L, U = random_nodes(6 + seed, lb, ub, 200, sol, p_narrow=0.9)
+    ref, got = both(ctx, 12, props, L, U, None, f"tiny seed={seed}")
+    assert (ref[3] == 1).any() and (ref[3] == 2).any()
+    assert got[4]["nodes"] == 200 and got[4]["steps"] + got[4]["steps3"] >= 200 * 10
+
+
 @pytest.mark.parametrize("opts", [
     {"nodes_per_block": 1}, {"nodes_per_block": 3}, {"nodes_per_block": 32}, {"block_threads": 256}, {"block_threads": 512},
     {"list_cap": 64}, {"force_path": 2, "team": 2}, {"force_path": 2, "team": 7}, {"force_path": 2, "team": 64},
