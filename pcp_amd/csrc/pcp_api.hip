@@ -329,10 +329,14 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const uint32_t list_cap = (uint32_t)c->opt_list_cap;
 
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
-  uint32_t Bmax = 0;
-  for (uint32_t b = 32; b >= 1; --b)
-    if (size_t need = lds_bytes_for(S, b, list_cap, block); need && need <= c->lds_max) { Bmax = b; break; }
-  if (Bmax == 0) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large for the LDS-resident kernel");
+  // tile sizes the kernel is instantiated for (pcp_kernels.hip launch_fixpoint)
+  static const uint32_t kTiles[] = {16, 12, 8, 4, 2, 1};
+  auto fits = [&](uint32_t b) { size_t need = lds_bytes_for(S, b, list_cap, block); return need && need <= c->lds_max; };
+  auto tile_le = [&](uint32_t want) {  // largest instantiated tile <= want that fits in LDS (0 if none)
+    for (uint32_t t : kTiles) if (t <= want && fits(t)) return t;
+    return 0u;
+  };
+  if (!fits(1)) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large for the LDS-resident kernel");
   const uint32_t slots = (uint32_t)c->num_cu;  // one resident workgroup per CU is what large tiles allow
   uint32_t B = 1, team = 1;
   bool use_team = false;
@@ -343,8 +347,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     const uint32_t max_by_work = std::max<uint32_t>(1, words / 16);  // >= 16 words (1024 records) per slice
     team = std::max<uint32_t>(1, std::min(g, max_by_work));
   } else {
-    if (c->opt_nodes_per_block) B = std::min<uint32_t>((uint32_t)c->opt_nodes_per_block, Bmax);
-    else B = std::max<uint32_t>(1, std::min<uint32_t>(Bmax, (n_nodes + slots - 1) / slots));
+    const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
+    B = std::max<uint32_t>(1, tile_le(want));
   }
   LaunchPlan plan;
   plan.block = block;

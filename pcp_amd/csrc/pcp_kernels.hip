@@ -30,38 +30,41 @@ namespace {
 constexpr int kWave = 64;
 
 struct Ctr {  // per-thread counters, reduced once per block
-  uint32_t steps2 = 0, steps3 = 0, narrow = 0;
+  uint32_t narrow = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
 // Domain access policy: node-local (lb,ub) pairs in LDS.
 // ------------------------------------------------------------------------------------------------
 struct LdsDom {
-  int2* dom;       // [n_slots]
-  uint32_t* chg;   // next-wave changed bitmask [ceil(n_slots/32)]
-  uint32_t* fail;  // block fail mask
-  uint32_t fbit;   // this node's bit in *fail
+  int2* dom;        // &dom[0*BP + b]: this node's column of the [slot][BP] array
+  uint32_t bp;      // row stride in int2 (nodes per block + padding)
+  uint32_t* chg;    // next-wave changed bitmask of this node [ceil(n_slots/32)]
+  uint32_t* fail;   // block fail mask
+  uint32_t fbit;    // this node's bit in *fail
   Ctr* c;
 
-  __device__ __forceinline__ int2 load(uint32_t v) const { return dom[v]; }
+  __device__ __forceinline__ int2 load(uint32_t v) const { return dom[(size_t)v * bp]; }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
   // lb := max(lb, nlb).  Called only when nlb exceeds the lb this thread read.
   __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
-    int old = atomicMax(&dom[v].x, nlb);
+    int2* p = dom + (size_t)v * bp;
+    int old = atomicMax(&p->x, nlb);
     if (old < nlb) {
       ++c->narrow;
       mark(v);
-      int ub = __hip_atomic_load(&dom[v].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int ub = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (nlb > ub) set_fail();
     }
   }
   __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
-    int old = atomicMin(&dom[v].y, nub);
+    int2* p = dom + (size_t)v * bp;
+    int old = atomicMin(&p->y, nub);
     if (old > nub) {
       ++c->narrow;
       mark(v);
-      int lb = __hip_atomic_load(&dom[v].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int lb = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (lb > nub) set_fail();
     }
   }
@@ -103,7 +106,6 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
   const uint32_t x = rec.xk & kSlotMask, y = rec.y;
   const int d = rec.d;
   if (kind <= PCP_LT) {
-    ++dm.c->steps2;
     int2 X = dm.load(x), Y = dm.load(y);
     int Yl = Y.x + d, Yu = Y.y + d;  // Y as seen through Addition(y, d)  (term/addition.rs:98)
     if (kind == PCP_NEQ) {
@@ -139,7 +141,6 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
       return nxu < nYl;  // x_less_y.rs:90-91: x.upper() < y.lower()
     }
   }
-  ++dm.c->steps3;
   const uint32_t z = rec.z;
   int2 X = dm.load(x), Y = dm.load(y), Z = dm.load(z);
   if (kind == PCP_LT3) {
@@ -203,18 +204,27 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// lane l of the result takes the wave-uniform value v, the other lanes keep `old`
+__device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32_t l) {
+  return ((threadIdx.x & 63u) == l) ? v : old;
+}
+
 }  // namespace
 
-// LDS carve (all offsets multiples of 16 bytes).
+// LDS carve (all offsets multiples of 16 bytes).  Domains are stored NODE-MINOR: dom[slot * BP + b] with
+// BP = B + 1 (B > 1): consecutive slots are (B+1)*8 bytes apart, an odd multiple of 8, so that a wavefront
+// reading 16-32 distinct consecutive slots with ds_read_b64 touches distinct bank pairs, and the B nodes of
+// one slot sit at compile-time immediate offsets of one address register.
 struct Carve {
   size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
+__host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 1u; }
 __host__ __device__ inline Carve carve(uint32_t n_slots, uint32_t B, uint32_t list_cap) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t Wv = (n_slots + 31) / 32;
   Carve c;
   size_t o = 0;
-  c.dom = o; o = up(o + (size_t)B * n_slots * 8);
+  c.dom = o; o = up(o + (size_t)row_stride(B) * n_slots * 8);
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
@@ -232,22 +242,131 @@ size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_c
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-// misc[] indices
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_STEPS2 = 4, M_STEPS3 = 5, M_NARROW = 6, M_WAVES = 7, M_ROUNDMASK = 8 };
+// misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_STEPS2 = 8, M_STEPS3 = 10 };
+
+struct BlockCtx {
+  int2* dom;
+  uint32_t bp;  // row stride of dom
+  uint32_t S, Wv;
+  uint32_t* misc;
+};
+
+__device__ __forceinline__ LdsDom make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
+  return LdsDom{k.dom + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
+}
 
 // ------------------------------------------------------------------------------------------------
-// One pass over 64-record words [w0, w1) for the nb nodes of this block.
-//   FILTER == false : every live record (the reference's init_scheduler, store.rs:144-149)
-//   FILTER == true  : only live records touching a variable in `cur` (dense wake-up round)
-// The wavefront's 64 lanes hold 64 consecutive records == one u64 word of each node's live mask.
+// Wave 0: one pass over 64-record words [w0, w1) for the nb nodes of this block — the reference's
+// init_scheduler (store.rs:144-149): every live propagator runs once.  The 64 lanes of a wavefront hold 64
+// consecutive records == one u64 word of each node's live mask; lane b also carries node b's word.
+//
+// Fast path (all 64 records of one binary kind, no failed node yet): the per-lane predicates
+//   need = "this filter would narrow something or fail"   ent = "entailed under the domains read"
+// are wave masks straight out of v_cmp (ballot), combined with scalar logic; only lanes in `need` run the
+// full filter with LDS atomics.  The fast predicates restate exactly the no-op conditions of
+// XNeqY/XLessY/XEqY::propagate and the True case of their is_subsumed (files cited in eval_record).
 // ------------------------------------------------------------------------------------------------
-template <bool FILTER>
-__device__ __forceinline__ void sweep_words(const LaunchArgs& a, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb, int2* dom,
-                                            uint32_t* cur, uint32_t* nxt, uint32_t* misc, const uint64_t* live_src, uint32_t& rem_acc,
-                                            Ctr& ctr) {
+// Fast predicate of one binary kind on the domains read for one node: a wave mask straight out of v_cmp.
+// A clear bit proves that running the filter on that lane would change NOTHING: no domain narrows, the
+// propagator is not entailed, nothing fails — so its live bit and the domains stay as they are.
+//  NEQ (x_neq_y.rs:82-93, x_eq_y.rs:87-93): nothing happens iff X.x < Yu && Yl < X.y.  With neither side a
+//      singleton this is "overlapping in more than a point" (no singleton => no narrowing; overlap => not
+//      entailed); with X = {v} it reads Yl < v < Yu, i.e. v strictly inside Y (Interval::difference leaves Y
+//      alone and the two are not disjoint); symmetrically for Y = {u}; two singletons never satisfy it.
+//  LT  (x_less_y.rs:87-109): x.ub drops iff X.y >= Yu, y.lb rises iff Yl <= X.x, entailed iff X.y < Yl.
+//  EQ  (x_eq_y.rs:87-107): x ∩ y differs from x or y iff a bound differs; entailed iff both are one singleton.
+template <int KIND>
+__device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const int Yu) {
+  if (KIND == PCP_NEQ) return __ballot(X.x >= Yu) | __ballot(Yl >= X.y);
+  if (KIND == PCP_LT) return __ballot(X.y >= Yu) | __ballot(Yl <= X.x) | __ballot(X.y < Yl);
+  return __ballot(X.x != Yl) | __ballot(X.y != Yu) | __ballot(X.x == X.y);
+}
+
+// The unrolled per-node loop of the fast path: two ds_read_b64 at immediate offsets, two or three compares and
+// scalar mask logic.  (word,node) pairs with a flagged live lane are returned in the bitmask for the full filter.
+template <int KIND, int B>
+__device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, const int d, const uint64_t my_word) {
+  uint32_t todo = 0;
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const uint64_t word = readlane64(my_word, b);
+    if (word == 0) continue;
+    const int2 X = px[b], Y = py[b];
+    const uint64_t flag = fast_flag<KIND>(X, Y.x + d, Y.y + d) & word;
+    todo |= flag ? (1u << b) : 0u;
+  }
+  return __builtin_amdgcn_readfirstlane(todo);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave 0: one pass over 64-record words [w0, w1) for the nb nodes of this block — the reference's
+// init_scheduler (store.rs:144-149): every live propagator runs once.  The 64 lanes of a wavefront hold 64
+// consecutive records == one u64 word of each node's live mask; lane b also carries node b's word.
+//
+// Fast path (all 64 records of one binary kind, no failed node yet): the per-lane predicates
+//   need = "this filter would narrow something or fail"   ent = "entailed under the domains read"
+// are wave masks straight out of v_cmp (ballot), combined with scalar logic; only lanes in `need` run the
+// full filter with LDS atomics.  The fast predicates restate exactly the no-op conditions of
+// XNeqY/XLessY/XEqY::propagate and the True case of their is_subsumed (files cited in eval_record).
+// ------------------------------------------------------------------------------------------------
+// Fast predicates of one binary kind on the domains read for one node: wave masks straight out of v_cmp.
+//   need = "this filter would narrow something or fail"      ent = "entailed under the domains read"
+template <int KIND>
+__device__ __forceinline__ void fast_masks(const int2 X, const int Yl, const int Yu, uint64_t& need, uint64_t& ent) {
+  if (KIND == PCP_NEQ) {
+    // narrows only if one side is a singleton sitting on a bound of the other (x_neq_y.rs:82-93)
+    const uint64_t sing = __ballot(X.x == X.y) | __ballot(Yl == Yu);
+    const uint64_t touch = __ballot(X.x == Yl) | __ballot(X.x == Yu) | __ballot(X.y == Yl) | __ballot(X.y == Yu);
+    need = sing & touch;
+    ent = __ballot(X.x > Yu) | __ballot(Yl > X.y);  // disjoint (x_eq_y.rs:89-90 negated)
+  } else if (KIND == PCP_LT) {
+    // x.ub drops iff X.y >= Yu; y.lb rises iff Yl <= X.x (x_less_y.rs:104-109)
+    need = __ballot(X.y >= Yu) | __ballot(Yl <= X.x);
+    ent = __ballot(X.y < Yl);  // x_less_y.rs:90-91
+  } else {
+    need = __ballot(X.x != Yl) | __ballot(X.y != Yu);  // x ∩ y differs from x or y (x_eq_y.rs:102-107)
+    ent = __ballot(X.x == X.y);                        // and then both are the same singleton
+  }
+}
+
+// The unrolled per-node loop of the fast path: two ds_read_b64 at immediate offsets, compares, scalar mask logic.
+// Nodes whose word has a lane in `need` are only flagged here (need_b) and re-run by the caller with the full filter.
+template <int KIND, int B>
+__device__ __forceinline__ void fast_nodes(const int2* px, const int2* py, const int d, const uint64_t my_word, uint64_t& my_new,
+                                           uint32_t& need_b, uint64_t& steps2) {
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const uint64_t word = readlane64(my_word, b);
+    if (word == 0) continue;
+    const int2 X = px[b], Y = py[b];
+    uint64_t need, ent;
+    fast_masks<KIND>(X, Y.x + d, Y.y + d, need, ent);
+    if (need & word) need_b |= 1u << b;
+    my_new = writelane64(my_new, word & ~ent, b);
+    steps2 += __popcll(word);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave 0: one pass over 64-record words [w0, w1) for the nb nodes of this block — the reference's
+// init_scheduler (store.rs:144-149): every live propagator runs once.  The 64 lanes of a wavefront hold 64
+// consecutive records == one u64 word of each node's live mask; lane b also carries node b's word.
+//
+// Fast path (all 64 records of one binary kind, no failed node yet): per-lane predicates become wave masks
+// and only (word,node) pairs in which some live lane would narrow are re-run with the full filter and its
+// LDS atomics.  The fast predicates restate exactly the no-op conditions of XNeqY/XLessY/XEqY::propagate and
+// the True case of their is_subsumed (files cited in eval_record).
+// ------------------------------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
+                                           uint32_t* chg_next, uint32_t& rem_acc, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 1u;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const uint32_t P = a.m.n_recs, words = (P + 63) >> 6, S = a.m.n_slots, Wv = (S + 31) >> 5;
+  const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
+  const uint64_t* live_src = a.live_in;
+  uint32_t steps_lane = 0;
   for (uint32_t w = w0 + wave; w < w1; w += nw) {
     const uint32_t r = (w << 6) + lane;
     Rec rec;
@@ -258,35 +377,89 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, uint32_t w0, ui
       my_word = live_src ? live_src[(size_t)(node0 + lane) * words + w] : ~0ull;
       if (w == words - 1) my_word &= tail_mask;
     }
-    const uint32_t failm = __hip_atomic_load(&misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint64_t my_new = my_word;
+    const uint32_t kind = rec.xk >> 28;
+    const uint32_t x = rec.xk & kSlotMask, y = rec.y;
+    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+    uint32_t todo;  // nodes to run with the full filter
+    if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+      const int2* px = k.dom + (size_t)x * BP;
+      const int2* py = k.dom + (size_t)y * BP;
+      if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
+      else if (kind0 == PCP_LT) todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
+      else todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, my_word);
+      steps_lane += __popcll(my_word);  // lane b holds node b's word: every live record of every node runs once
+    } else {
+      // mixed kinds / ternary / a failed node in the tile: everything through the full filter
+      const bool tern = kind > PCP_LT;
+      todo = 0;
+      for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t word = readlane64(my_word, b);
+        if (word == 0 || ((failm >> b) & 1u)) continue;
+        todo |= 1u << b;
+        const uint64_t t3 = __ballot(((word >> lane) & 1ull) && tern);
+        steps3 += __popcll(t3);
+        steps2 += __popcll(word) - __popcll(t3);
+      }
+    }
+    while (todo) {
+      const uint32_t b = __builtin_ctz(todo);
+      todo &= todo - 1;
+      const uint64_t word = readlane64(my_word, b);
+      bool e = false;
+      if ((word >> lane) & 1ull) {
+        const LdsDom dm = make_dom(k, b, chg_next, &ctr);
+        e = eval_record(rec, dm);
+      }
+      my_new = writelane64(my_new, word & ~__ballot(e), b);
+    }
+    if (lane < nb) {
+      rem_acc += __popcll(my_new);
+      if (live_src != a.live || my_new != my_word) a.live[(size_t)(node0 + lane) * words + w] = my_new;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
+  steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
+}
+
+// Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
+// the live records that touch a variable in `cur`.  Rare path, generic code.
+__device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, const uint32_t* cur,
+                                               uint32_t* chg_next, uint32_t& rem_sub, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
+  for (uint32_t w = wave; w < words; w += nw) {
+    const uint32_t r = (w << 6) + lane;
+    Rec rec;
+    if (r < P) rec = a.m.recs[r];
+    else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
+    uint64_t my_word = 0;
+    if (lane < nb) my_word = a.live[(size_t)(node0 + lane) * words + w];
+    uint64_t my_new = my_word;
+    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t x = rec.xk & kSlotMask;
     const bool tern = (rec.xk >> 28) > PCP_LT;
     for (uint32_t b = 0; b < nb; ++b) {
       const uint64_t word = readlane64(my_word, b);
-      if ((failm >> b) & 1u) continue;
-      uint64_t nword = word;
-      if (word != 0) {
-        bool mine = (word >> lane) & 1ull;
-        if (FILTER) {
-          const uint32_t* cb = cur + (size_t)b * Wv;
-          bool touched = ((cb[x >> 5] >> (x & 31)) & 1u) | ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u);
-          if (tern) touched |= (cb[rec.z >> 5] >> (rec.z & 31)) & 1u;
-          mine = mine && touched;
-        }
-        bool ent = false;
-        if (mine) {
-          LdsDom dm{dom + (size_t)b * S, nxt + (size_t)b * Wv, &misc[M_FAIL], 1u << b, &ctr};
-          ent = eval_record(rec, dm);
-        }
-        nword = word & ~__ballot(ent);
+      if (word == 0 || ((failm >> b) & 1u)) continue;
+      const uint32_t* cb = cur + (size_t)b * k.Wv;
+      bool touched = ((cb[x >> 5] >> (x & 31)) & 1u) | ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u);
+      if (tern) touched |= (cb[rec.z >> 5] >> (rec.z & 31)) & 1u;
+      const bool mine = ((word >> lane) & 1ull) && touched;
+      bool e = false;
+      if (mine) {
+        const LdsDom dm = make_dom(k, b, chg_next, &ctr);
+        e = eval_record(rec, dm);
       }
-      if (!FILTER) {
-        if (lane == b) rem_acc += __popcll(nword);
-        if (lane == 0 && (live_src != a.live || nword != word)) a.live[(size_t)(node0 + b) * words + w] = nword;
-      } else {
-        if (lane == b) rem_acc += __popcll(word) - __popcll(nword);  // newly entailed
-        if (lane == 0 && nword != word) a.live[(size_t)(node0 + b) * words + w] = nword;
-      }
+      const uint64_t run = __ballot(mine), t3 = __ballot(mine && tern);
+      steps3 += __popcll(t3);
+      steps2 += __popcll(run) - __popcll(t3);
+      my_new = writelane64(my_new, word & ~__ballot(e), b);
+    }
+    if (lane < nb && my_new != my_word) {
+      rem_sub += __popcll(my_word) - __popcll(my_new);  // newly entailed
+      a.live[(size_t)(node0 + lane) * words + w] = my_new;
     }
   }
 }
@@ -294,11 +467,13 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, uint32_t w0, ui
 // ------------------------------------------------------------------------------------------------
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
+template <int B>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
-  const uint32_t B = a.nodes_per_block, team = a.team, C = a.list_cap;
+  const uint32_t team = a.team, C = a.list_cap;
+  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 1u;
   const Carve cv = carve(S, B, C);
   int2* dom = reinterpret_cast<int2*>(smem + cv.dom);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
@@ -308,41 +483,42 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + cv.tmp);
   uint32_t* remaining = reinterpret_cast<uint32_t*>(smem + cv.remaining);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+  const BlockCtx k{dom, BP, S, Wv, misc};
 
   uint32_t node0, nb, g;
   if (team > 1) { node0 = blockIdx.x / team; g = blockIdx.x % team; nb = 1; }
-  else { node0 = blockIdx.x * B; g = 0; nb = min(B, a.n_nodes - node0); }
+  else { node0 = blockIdx.x * B; g = 0; nb = min((uint32_t)B, a.n_nodes - node0); }
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   if (tid < 16) misc[tid] = 0;
-  if (tid < B) remaining[tid] = 0;
-  for (uint32_t i = tid; i < B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
+  if (tid < (uint32_t)B) remaining[tid] = 0;
+  for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   __syncthreads();
-  for (uint32_t b = 0; b < nb; ++b) {
-    const int32_t* lbp = a.lb_in + (size_t)(node0 + b) * V;
-    const int32_t* ubp = a.ub_in + (size_t)(node0 + b) * V;
-    // team > 1: the merged arrays (lb_out) are the ones every slice narrows with atomics; they were
-    // initialised from lb_in by the host before the launch, so read the inputs here.
+  for (uint32_t b = 0; b < (uint32_t)B; ++b) {
+    const bool real = b < nb;
+    const int32_t* lbp = a.lb_in + (size_t)(node0 + (real ? b : 0)) * V;
+    const int32_t* ubp = a.ub_in + (size_t)(node0 + (real ? b : 0)) * V;
     bool bad = false;
     for (uint32_t v = tid; v < S; v += nth) {
       int2 d;
       if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
       else { d.x = d.y = a.m.const_val[v - V]; }
-      dom[(size_t)b * S + v] = d;
+      dom[(size_t)v * BP + b] = d;  // missing nodes of a tail tile mirror node 0: readable, never used
     }
-    if (bad) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
+    if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
   }
   __syncthreads();
 
   Ctr ctr;
   uint32_t rem_acc = 0;
+  uint64_t steps2 = 0, steps3 = 0;
 
-  // ---- phase 1: wave 0 = every live propagator once (slice of the table when team > 1) -------------------
+  // ---- phase 1: wave 0 = every live propagator once (a slice of the table when team > 1) -----------------
   {
     uint32_t w0 = 0, w1 = words;
     if (team > 1) { const uint32_t ws = (words + team - 1) / team; w0 = min(words, g * ws); w1 = min(words, w0 + ws); }
-    // sweep writes "next" bits into `cur` so that the first round reads them as its current set
-    sweep_words<false>(a, w0, w1, node0, nb, dom, nxt, cur, misc, a.live_in, rem_acc, ctr);
+    // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
+    sweep_fast<B>(a, k, w0, w1, node0, nb, cur, rem_acc, steps2, steps3, ctr);
     if (lane < nb && rem_acc) atomicAdd(&remaining[lane], rem_acc);
     rem_acc = 0;
   }
@@ -362,21 +538,17 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       while (bits) {
         const uint32_t v = (w << 5) + __builtin_ctz(bits);
         bits &= bits - 1;
-        if (v < V) { atomicMax(&glb[v], dom[v].x); atomicMin(&gub[v], dom[v].y); }
+        if (v < V) { atomicMax(&glb[v], dom[(size_t)v * BP].x); atomicMin(&gub[v], dom[(size_t)v * BP].y); }
       }
     }
-    // block-reduce counters into the node's team counters (the tail block adds its own later)
-    for (int o = 32; o > 0; o >>= 1) {
-      ctr.steps2 += __shfl_down(ctr.steps2, o);
-      ctr.steps3 += __shfl_down(ctr.steps3, o);
-      ctr.narrow += __shfl_down(ctr.narrow, o);
-    }
+    for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
     if (lane == 0) {
-      if (ctr.steps2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], (unsigned long long)ctr.steps2);
-      if (ctr.steps3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], (unsigned long long)ctr.steps3);
+      // steps2/steps3 are wave-uniform accumulators: one add per wave
+      if (steps2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], (unsigned long long)steps2);
+      if (steps3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], (unsigned long long)steps3);
       if (ctr.narrow) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 2], (unsigned long long)ctr.narrow);
     }
-    ctr = Ctr();
+    ctr = Ctr(); steps2 = 0; steps3 = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its merge atomics have been performed
     __syncthreads();
     if (tid == 0) {
@@ -397,7 +569,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       int2 d;
       d.x = __hip_atomic_load(&glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       d.y = __hip_atomic_load(&gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      dom[v] = d;
+      dom[(size_t)v * BP] = d;
     }
     for (uint32_t w = tid; w < Wv; w += nth) {
       cur[w] = __hip_atomic_load(&gchg[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -411,7 +583,6 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   }
 
   // ---- phase 3: wake-up rounds until no variable changes (IndexedDeps::react + RelaxedFifo, as waves) ------
-  uint32_t rounds = 0;
   const uint32_t TW = nb * Wv;
   for (;;) {
     // (a) count changed (node,var) pairs of live nodes
@@ -428,7 +599,6 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     uint32_t off = block_exclusive_scan(cnt, tmp, &misc[M_TOTAL]);
     const uint32_t total = misc[M_TOTAL];
     if (total == 0) break;
-    ++rounds;
     if (total <= C) {
       // (b) compact them into a list with each variable's degree, prefix-sum the degrees
       for (uint32_t w = tid; w < TW; w += nth) {
@@ -445,7 +615,6 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         }
       }
       __syncthreads();
-      // exclusive scan of list_pre[0..total) in place, chunked per thread
       {
         const uint32_t per = (total + nth - 1) / nth;
         const uint32_t s = min(total, tid * per), e = min(total, s + per);
@@ -458,6 +627,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       __syncthreads();
       const uint32_t T = misc[M_ITEMS];
       // (c) one item = one (changed var, incident record): flat, load-balanced over the whole block
+      uint32_t my2 = 0, my3 = 0;
       for (uint32_t i = tid; i < T; i += nth) {
         uint32_t lo = 0, hi = total;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
@@ -471,23 +641,27 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         // from the lowest-numbered one.
         const uint32_t* cb = cur + (size_t)b * Wv;
         const uint32_t x = rec.xk & kSlotMask;
+        const bool tern = (rec.xk >> 28) > PCP_LT;
         bool skip = false;
         if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) skip = true;
         if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) skip = true;
-        if ((rec.xk >> 28) > PCP_LT && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) skip = true;
+        if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) skip = true;
         if (skip) continue;
-        LdsDom dm{dom + (size_t)b * S, nxt + (size_t)b * Wv, &misc[M_FAIL], 1u << b, &ctr};
+        const LdsDom dm = make_dom(k, b, nxt, &ctr);
+        if (tern) ++my3; else ++my2;
         if (eval_record(rec, dm)) {
           const uint32_t old = atomicAnd(lw, ~bit);
           if (old & bit) atomicSub(&remaining[b], 1u);
         }
       }
+      for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); }
+      my2 = __builtin_amdgcn_readfirstlane(my2); my3 = __builtin_amdgcn_readfirstlane(my3);
+      steps2 += my2; steps3 += my3;
     } else {
-      // dense round: more changed variables than the list holds — stream the table again, filtered.
       __syncthreads();
-      sweep_words<true>(a, 0, words, node0, nb, dom, cur, nxt, misc, a.live, rem_acc, ctr);
-      if (lane < nb && rem_acc) atomicSub(&remaining[lane], rem_acc);
-      rem_acc = 0;
+      uint32_t rem_sub = 0;
+      sweep_filtered(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
+      if (lane < nb && rem_sub) atomicSub(&remaining[lane], rem_sub);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -504,21 +678,17 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
     bool bad = false;
     for (uint32_t v = tid; v < S; v += nth) {
-      const int2 d = dom[(size_t)b * S + v];
+      const int2 d = dom[(size_t)v * BP + b];
       bad |= d.x > d.y;
       if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
     }
     if (bad) atomicOr(&misc[M_FAIL], 1u << b);
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    ctr.steps2 += __shfl_down(ctr.steps2, o);
-    ctr.steps3 += __shfl_down(ctr.steps3, o);
-    ctr.narrow += __shfl_down(ctr.narrow, o);
-  }
+  for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
   if (lane == 0) {
-    if (ctr.steps2) atomicAdd(&misc[M_STEPS2], ctr.steps2);
-    if (ctr.steps3) atomicAdd(&misc[M_STEPS3], ctr.steps3);
     if (ctr.narrow) atomicAdd(&misc[M_NARROW], ctr.narrow);
+    if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]), (unsigned long long)steps2);
+    if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]), (unsigned long long)steps3);
   }
   __syncthreads();
   if (tid < nb) {
@@ -528,13 +698,15 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     a.status[node0 + tid] = failed ? (uint8_t)PCP_FALSE : (remaining[tid] == 0 ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
   }
   if (tid == 0) {
-    unsigned long long s2 = misc[M_STEPS2], s3 = misc[M_STEPS3], nr = misc[M_NARROW];
+    unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);
+    unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]);
+    unsigned long long nr = misc[M_NARROW];
     if (team > 1) {
       s2 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s3 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       nr += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    atomicAdd((unsigned long long*)&a.stats->steps, s2);
+    if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
     if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
     if (nr) atomicAdd((unsigned long long*)&a.stats->narrowings, nr);
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[M_WAVES]));
@@ -542,16 +714,29 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));
     if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
   }
-  (void)rounds;
 }
 
-hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+template <int B>
+static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fixpoint_kernel, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL(fixpoint_kernel<B>, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
+}
+
+// nodes_per_block must be one of the instantiated tile sizes.
+hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  switch (a.nodes_per_block) {
+    case 1: return launch_b<1>(a, p, stream);
+    case 2: return launch_b<2>(a, p, stream);
+    case 4: return launch_b<4>(a, p, stream);
+    case 8: return launch_b<8>(a, p, stream);
+    case 12: return launch_b<12>(a, p, stream);
+    case 16: return launch_b<16>(a, p, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 }  // namespace pcp
