@@ -32,7 +32,7 @@ extern "C" {
 
 /* Interval bounds and offsets must stay inside [-PCP_BOUND_MAX, PCP_BOUND_MAX] so that no filter can
  * overflow i32 (the reference wraps in release and panics in debug; SURVEY.md §7 "i32 overflow"). */
-#define PCP_BOUND_MAX 0x3FFFFFFF
+#define PCP_BOUND_MAX 0x1FFFFFFF
 
 typedef enum {
   PCP_OK = 0,

@@ -331,9 +331,20 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
   // tile sizes the kernel is instantiated for (pcp_kernels.hip launch_fixpoint)
   static const uint32_t kTiles[] = {16, 12, 8, 4, 2, 1};
-  auto fits = [&](uint32_t b) { size_t need = lds_bytes_for(S, b, list_cap, block); return need && need <= c->lds_max; };
+  // The changed-(node,var) list shares LDS with the domains: shrink it (down to 256 entries) before giving up
+  // a tile size; a round with more changed pairs than the list holds falls back to a filtered sweep.
+  uint32_t list_cap_used = list_cap;
+  auto fits_cap = [&](uint32_t b, uint32_t cap) { size_t need = lds_bytes_for(S, b, cap, block); return need && need <= c->lds_max; };
+  auto fits = [&](uint32_t b) {
+    for (uint32_t cap = list_cap;; cap /= 2) {
+      if (fits_cap(b, cap)) return cap;
+      if (cap <= 256) return 0u;
+    }
+  };
   auto tile_le = [&](uint32_t want) {  // largest instantiated tile <= want that fits in LDS (0 if none)
-    for (uint32_t t : kTiles) if (t <= want && fits(t)) return t;
+    for (uint32_t t : kTiles)
+      if (t <= want)
+        if (uint32_t cap = fits(t)) { list_cap_used = cap; return t; }
     return 0u;
   };
   if (!fits(1)) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large for the LDS-resident kernel");
@@ -352,14 +363,15 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   LaunchPlan plan;
   plan.block = block;
-  plan.lds_bytes = lds_bytes_for(S, B, list_cap, block);
+  if (use_team) list_cap_used = fits(1);
+  plan.lds_bytes = lds_bytes_for(S, B, list_cap_used, block);
   plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
-  a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap;
+  a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;

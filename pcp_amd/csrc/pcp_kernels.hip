@@ -212,13 +212,13 @@ __device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32
 }  // namespace
 
 // LDS carve (all offsets multiples of 16 bytes).  Domains are stored NODE-MINOR: dom[slot * BP + b] with
-// BP = B + 1 (B > 1): consecutive slots are (B+1)*8 bytes apart, an odd multiple of 8, so that a wavefront
-// reading 16-32 distinct consecutive slots with ds_read_b64 touches distinct bank pairs, and the B nodes of
-// one slot sit at compile-time immediate offsets of one address register.
+// BP = B + 2 (B > 1): the B nodes of one slot sit at compile-time immediate offsets of one address register,
+// node pairs are 16-byte aligned (one ds_read_b128 reads two nodes), and consecutive slots are (B+2)*8 bytes
+// = 12/20/28/36 banks apart for B = 4/8/12/16, so 16 consecutive slots start on 16 distinct 4-bank groups.
 struct Carve {
   size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
-__host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 1u; }
+__host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 2u; }
 __host__ __device__ inline Carve carve(uint32_t n_slots, uint32_t B, uint32_t list_cap) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t Wv = (n_slots + 31) / 32;
@@ -256,17 +256,6 @@ __device__ __forceinline__ LdsDom make_dom(const BlockCtx& k, uint32_t b, uint32
   return LdsDom{k.dom + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave 0: one pass over 64-record words [w0, w1) for the nb nodes of this block — the reference's
-// init_scheduler (store.rs:144-149): every live propagator runs once.  The 64 lanes of a wavefront hold 64
-// consecutive records == one u64 word of each node's live mask; lane b also carries node b's word.
-//
-// Fast path (all 64 records of one binary kind, no failed node yet): the per-lane predicates
-//   need = "this filter would narrow something or fail"   ent = "entailed under the domains read"
-// are wave masks straight out of v_cmp (ballot), combined with scalar logic; only lanes in `need` run the
-// full filter with LDS atomics.  The fast predicates restate exactly the no-op conditions of
-// XNeqY/XLessY/XEqY::propagate and the True case of their is_subsumed (files cited in eval_record).
-// ------------------------------------------------------------------------------------------------
 // Fast predicate of one binary kind on the domains read for one node: a wave mask straight out of v_cmp.
 // A clear bit proves that running the filter on that lane would change NOTHING: no domain narrows, the
 // propagator is not entailed, nothing fails — so its live bit and the domains stay as they are.
@@ -283,69 +272,85 @@ __device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const 
   return __ballot(X.x != Yl) | __ballot(X.y != Yu) | __ballot(X.x == X.y);
 }
 
-// The unrolled per-node loop of the fast path: two ds_read_b64 at immediate offsets, two or three compares and
-// scalar mask logic.  (word,node) pairs with a flagged live lane are returned in the bitmask for the full filter.
+// The unrolled per-node loop of the fast path.  Nodes are taken four at a time: their x- and y-domains are two
+// ds_read_b128 each (nodes b, b+1 of one slot are 16 adjacent, 16-byte-aligned bytes) at immediate offsets of
+// one address register, all issued before the first compare so that the LDS latency is paid once per group;
+// then two or three compares per node and scalar mask logic.  (word,node) pairs with a flagged live lane are
+// returned in the bitmask for the full filter.
 template <int KIND, int B>
 __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, const int d, const uint64_t my_word) {
   uint32_t todo = 0;
+  if (B == 1) {
+    const uint64_t word = readlane64(my_word, 0);
+    if (word) {
+      const int2 X = px[0], Y = py[0];
+      if (fast_flag<KIND>(X, Y.x + d, Y.y + d) & word) todo = 1;
+    }
+    return todo;
+  }
+  constexpr int G = (B % 4 == 0) ? 4 : 2;
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const uint64_t word = readlane64(my_word, b);
-    if (word == 0) continue;
-    const int2 X = px[b], Y = py[b];
-    const uint64_t flag = fast_flag<KIND>(X, Y.x + d, Y.y + d) & word;
-    todo |= flag ? (1u << b) : 0u;
+  for (int g = 0; g < B; g += G) {
+    uint64_t wd[G];
+    uint64_t any = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) { wd[j] = readlane64(my_word, g + j); any |= wd[j]; }
+    if (any == 0) continue;
+    int4 Xp[G / 2], Yp[G / 2];
+#pragma unroll
+    for (int j = 0; j < G / 2; ++j) {
+      Xp[j] = *reinterpret_cast<const int4*>(px + g + 2 * j);
+      Yp[j] = *reinterpret_cast<const int4*>(py + g + 2 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < G / 2; ++j) {
+      const uint64_t f0 = fast_flag<KIND>(make_int2(Xp[j].x, Xp[j].y), Yp[j].x + d, Yp[j].y + d) & wd[2 * j];
+      const uint64_t f1 = fast_flag<KIND>(make_int2(Xp[j].z, Xp[j].w), Yp[j].z + d, Yp[j].w + d) & wd[2 * j + 1];
+      todo |= f0 ? (1u << (g + 2 * j)) : 0u;
+      todo |= f1 ? (1u << (g + 2 * j + 1)) : 0u;
+    }
   }
   return __builtin_amdgcn_readfirstlane(todo);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Wave 0: one pass over 64-record words [w0, w1) for the nb nodes of this block — the reference's
-// init_scheduler (store.rs:144-149): every live propagator runs once.  The 64 lanes of a wavefront hold 64
-// consecutive records == one u64 word of each node's live mask; lane b also carries node b's word.
-//
-// Fast path (all 64 records of one binary kind, no failed node yet): the per-lane predicates
-//   need = "this filter would narrow something or fail"   ent = "entailed under the domains read"
-// are wave masks straight out of v_cmp (ballot), combined with scalar logic; only lanes in `need` run the
-// full filter with LDS atomics.  The fast predicates restate exactly the no-op conditions of
-// XNeqY/XLessY/XEqY::propagate and the True case of their is_subsumed (files cited in eval_record).
-// ------------------------------------------------------------------------------------------------
-// Fast predicates of one binary kind on the domains read for one node: wave masks straight out of v_cmp.
-//   need = "this filter would narrow something or fail"      ent = "entailed under the domains read"
-template <int KIND>
-__device__ __forceinline__ void fast_masks(const int2 X, const int Yl, const int Yu, uint64_t& need, uint64_t& ent) {
-  if (KIND == PCP_NEQ) {
-    // narrows only if one side is a singleton sitting on a bound of the other (x_neq_y.rs:82-93)
-    const uint64_t sing = __ballot(X.x == X.y) | __ballot(Yl == Yu);
-    const uint64_t touch = __ballot(X.x == Yl) | __ballot(X.x == Yu) | __ballot(X.y == Yl) | __ballot(X.y == Yu);
-    need = sing & touch;
-    ent = __ballot(X.x > Yu) | __ballot(Yl > X.y);  // disjoint (x_eq_y.rs:89-90 negated)
-  } else if (KIND == PCP_LT) {
-    // x.ub drops iff X.y >= Yu; y.lb rises iff Yl <= X.x (x_less_y.rs:104-109)
-    need = __ballot(X.y >= Yu) | __ballot(Yl <= X.x);
-    ent = __ballot(X.y < Yl);  // x_less_y.rs:90-91
-  } else {
-    need = __ballot(X.x != Yl) | __ballot(X.y != Yu);  // x ∩ y differs from x or y (x_eq_y.rs:102-107)
-    ent = __ballot(X.x == X.y);                        // and then both are the same singleton
+// First-level test of the fast path: ONE sign word per lane for ALL the nodes of the tile, liveness ignored.
+// For each node the "nothing happens" condition of fast_flag is rewritten as a conjunction of non-negative
+// differences (every bound and offset is below 2^29 in magnitude, so three-term sums cannot wrap):
+//   NEQ:  X.x < Yu && Yl < X.y      <=>  (Y.y + (d-1)) - X.x >= 0  &&  (X.y + (-d-1)) - Y.x >= 0
+//   LT :  X.y < Yu && Yl > X.x && X.y >= Yl
+//                                    <=>  (Y.y + (d-1)) - X.y >= 0  &&  (Y.x + (d-1)) - X.x >= 0  &&  (X.y - d) - Y.x >= 0
+// and the differences of all nodes are OR-ed together: the sign bit of the result is clear iff nothing happens on
+// this lane's record in ANY node.  No scalar work, no cross-lane work: 4-6 VALU and half a ds_read_b128 per node.
+template <int KIND, int B>
+__device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const int d) {
+  const int c1 = d - 1, c2 = -d - 1;
+  int o = 0;
+  auto one = [&](int xl, int xu, int yl, int yu) {
+    if (KIND == PCP_NEQ) o |= ((yu + c1) - xl) | ((xu + c2) - yl);
+    else o |= ((yu + c1) - xu) | ((yl + c1) - xl) | ((xu - d) - yl);
+  };
+  if (B == 1) {
+    const int2 X = px[0], Y = py[0];
+    one(X.x, X.y, Y.x, Y.y);
+    return o;
   }
+#pragma unroll
+  for (int g = 0; g < B; g += 2) {
+    const int4 Xp = *reinterpret_cast<const int4*>(px + g);
+    const int4 Yp = *reinterpret_cast<const int4*>(py + g);
+    one(Xp.x, Xp.y, Yp.x, Yp.y);
+    one(Xp.z, Xp.w, Yp.z, Yp.w);
+  }
+  return o;
 }
 
-// The unrolled per-node loop of the fast path: two ds_read_b64 at immediate offsets, compares, scalar mask logic.
-// Nodes whose word has a lane in `need` are only flagged here (need_b) and re-run by the caller with the full filter.
-template <int KIND, int B>
-__device__ __forceinline__ void fast_nodes(const int2* px, const int2* py, const int d, const uint64_t my_word, uint64_t& my_new,
-                                           uint32_t& need_b, uint64_t& steps2) {
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const uint64_t word = readlane64(my_word, b);
-    if (word == 0) continue;
-    const int2 X = px[b], Y = py[b];
-    uint64_t need, ent;
-    fast_masks<KIND>(X, Y.x + d, Y.y + d, need, ent);
-    if (need & word) need_b |= 1u << b;
-    my_new = writelane64(my_new, word & ~ent, b);
-    steps2 += __popcll(word);
-  }
+// OR of a 32-bit value over the 16 lanes of each DPP row (quad swaps, then half-mirror, then mirror).
+__device__ __forceinline__ uint32_t row_or16(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+  return v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -361,22 +366,31 @@ __device__ __forceinline__ void fast_nodes(const int2* px, const int2* py, const
 template <int B>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t& rem_acc, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
-  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 1u;
+  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 2u;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
   const uint64_t* live_src = a.live_in;
   uint32_t steps_lane = 0;
-  for (uint32_t w = w0 + wave; w < w1; w += nw) {
+  // Software prefetch: the records and live words of the NEXT 64-record word are requested before the current
+  // one is processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
+  auto fetch = [&](uint32_t w, Rec& rec, uint64_t& word) {
     const uint32_t r = (w << 6) + lane;
-    Rec rec;
-    if (r < P) rec = a.m.recs[r];
+    if (w < w1 && r < P) rec = a.m.recs[r];
     else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
-    uint64_t my_word = 0;
-    if (lane < nb) {
-      my_word = live_src ? live_src[(size_t)(node0 + lane) * words + w] : ~0ull;
-      if (w == words - 1) my_word &= tail_mask;
+    word = 0;
+    if (w < w1 && lane < nb) {
+      word = live_src ? live_src[(size_t)(node0 + lane) * words + w] : ~0ull;
+      if (w == words - 1) word &= tail_mask;
     }
+  };
+  Rec rec_n;
+  uint64_t word_n;
+  fetch(w0 + wave, rec_n, word_n);
+  for (uint32_t w = w0 + wave; w < w1; w += nw) {
+    const Rec rec = rec_n;
+    const uint64_t my_word = word_n;
+    fetch(w + nw, rec_n, word_n);
     uint64_t my_new = my_word;
     const uint32_t kind = rec.xk >> 28;
     const uint32_t x = rec.xk & kSlotMask, y = rec.y;
@@ -386,9 +400,23 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
       const int2* px = k.dom + (size_t)x * BP;
       const int2* py = k.dom + (size_t)y * BP;
-      if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
-      else if (kind0 == PCP_LT) todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
-      else todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, my_word);
+      todo = 0;
+      if (__ballot(my_word != 0)) {  // some record of this word is live in some node
+        if (kind0 == PCP_EQ) {
+          todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, my_word);
+        } else {
+          // level 1: one sign word per lane for the whole tile; level 2 (per node, with liveness) only if a record
+          // that is live somewhere in the tile is flagged.
+          const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+          static_assert(B <= 16, "the tile's live words must sit in one 16-lane DPP row");
+          const uint64_t alive = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(my_word >> 32))) << 32) |
+                                 __builtin_amdgcn_readfirstlane(row_or16((uint32_t)my_word));
+          if (__ballot(o < 0) & alive) {
+            if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
+            else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
+          }
+        }
+      }
       steps_lane += __popcll(my_word);  // lane b holds node b's word: every live record of every node runs once
     } else {
       // mixed kinds / ternary / a failed node in the tile: everything through the full filter
@@ -473,7 +501,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
   const uint32_t team = a.team, C = a.list_cap;
-  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 1u;
+  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 2u;
   const Carve cv = carve(S, B, C);
   int2* dom = reinterpret_cast<int2*>(smem + cv.dom);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);

@@ -25,7 +25,7 @@ import numpy as np
 
 PCP_CONST = 0xFFFFFFFF
 PCP_NOVAR = 0xFFFFFFFE
-PCP_BOUND_MAX = 0x3FFFFFFF
+PCP_BOUND_MAX = 0x1FFFFFFF
 
 NEQ, EQ, LT, LT3, GT3, EQ3, MUL3 = range(7)
 KIND_NAMES = ["NEQ", "EQ", "LT", "LT3", "GT3", "EQ3", "MUL3"]
