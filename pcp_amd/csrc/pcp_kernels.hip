@@ -313,6 +313,18 @@ __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, c
   return __builtin_amdgcn_readfirstlane(todo);
 }
 
+// slot * BP (BP = B + 2) as shifts and adds: a 32-bit integer multiply is a quarter-rate VALU op on gfx950.
+template <int B>
+__device__ __forceinline__ uint32_t slot_row(uint32_t v) {
+  if (B == 1) return v;
+  if (B == 2) return v << 2;
+  if (B == 4) return (v << 2) + (v << 1);
+  if (B == 8) return (v << 3) + (v << 1);
+  if (B == 12) return (v << 4) - (v << 1);
+  if (B == 16) return (v << 4) + (v << 1);
+  return v * (uint32_t)(B + 2);
+}
+
 // First-level test of the fast path: ONE sign word per lane for ALL the nodes of the tile, liveness ignored.
 // For each node the "nothing happens" condition of fast_flag is rewritten as a conjunction of non-negative
 // differences (every bound and offset is below 2^29 in magnitude, so three-term sums cannot wrap):
@@ -366,7 +378,6 @@ __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
 template <int B>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t& rem_acc, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
-  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 2u;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
@@ -374,13 +385,16 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   uint32_t steps_lane = 0;
   // Software prefetch: the records and live words of the NEXT 64-record word are requested before the current
   // one is processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
+  const uint32_t my_node = node0 + (lane < nb ? lane : 0);
+  const uint64_t* my_in = live_src ? live_src + (size_t)my_node * words : nullptr;
+  uint64_t* my_out = a.live + (size_t)my_node * words;
+  const Rec* my_rec = a.m.recs + lane;
   auto fetch = [&](uint32_t w, Rec& rec, uint64_t& word) {
-    const uint32_t r = (w << 6) + lane;
-    if (w < w1 && r < P) rec = a.m.recs[r];
+    if (w < w1 && (w << 6) + lane < P) rec = my_rec[(size_t)w << 6];
     else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
     word = 0;
     if (w < w1 && lane < nb) {
-      word = live_src ? live_src[(size_t)(node0 + lane) * words + w] : ~0ull;
+      word = my_in ? my_in[w] : ~0ull;
       if (w == words - 1) word &= tail_mask;
     }
   };
@@ -398,8 +412,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
     uint32_t todo;  // nodes to run with the full filter
     if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
-      const int2* px = k.dom + (size_t)x * BP;
-      const int2* py = k.dom + (size_t)y * BP;
+      const int2* px = k.dom + slot_row<B>(x);
+      const int2* py = k.dom + slot_row<B>(y);
       todo = 0;
       if (__ballot(my_word != 0)) {  // some record of this word is live in some node
         if (kind0 == PCP_EQ) {
@@ -409,11 +423,15 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           // that is live somewhere in the tile is flagged.
           const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
           static_assert(B <= 16, "the tile's live words must sit in one 16-lane DPP row");
-          const uint64_t alive = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(my_word >> 32))) << 32) |
-                                 __builtin_amdgcn_readfirstlane(row_or16((uint32_t)my_word));
-          if (__ballot(o < 0) & alive) {
-            if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
-            else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
+          const uint64_t flagged = __ballot(o < 0);
+          if (flagged) {
+            // records live in at least one node of the tile (OR of the tile's live words over the DPP row)
+            const uint64_t alive = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(my_word >> 32))) << 32) |
+                                   __builtin_amdgcn_readfirstlane(row_or16((uint32_t)my_word));
+            if (flagged & alive) {
+              if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
+              else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
+            }
           }
         }
       }
@@ -444,7 +462,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     }
     if (lane < nb) {
       rem_acc += __popcll(my_new);
-      if (live_src != a.live || my_new != my_word) a.live[(size_t)(node0 + lane) * words + w] = my_new;
+      if (live_src != a.live || my_new != my_word) my_out[w] = my_new;
     }
   }
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
