@@ -354,8 +354,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (c->opt_force_path == 2) use_team = true;
   else if (c->opt_force_path == 0) use_team = (n_nodes * 2 <= slots) && words >= 64;
   if (use_team) {
-    uint32_t g = c->opt_team ? (uint32_t)c->opt_team : std::max<uint32_t>(1, (2 * slots) / n_nodes);
-    const uint32_t max_by_work = std::max<uint32_t>(1, words / 16);  // >= 16 words (1024 records) per slice
+    // measured on N-queens-1000 (23 415 words): 128-256 blocks per node is the sweet spot; more blocks pay
+    // their fixed cost (domain staging, merge, ticket) without shortening the slice stream further.
+    uint32_t g = c->opt_team ? (uint32_t)c->opt_team : std::max<uint32_t>(1, slots / n_nodes);
+    const uint32_t max_by_work = std::max<uint32_t>(1, words / (c->opt_team ? 1 : 128));
     team = std::max<uint32_t>(1, std::min(g, max_by_work));
   } else {
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);

@@ -587,17 +587,26 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         if (v < V) { atomicMax(&glb[v], dom[(size_t)v * BP].x); atomicMin(&gub[v], dom[(size_t)v * BP].y); }
       }
     }
+    // counters: wave -> LDS -> ONE global atomic per block and counter (same-address device atomics serialise
+    // at ~12 ns each: per-wave adds from a 512-block team would cost more than the sweep itself)
     for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
     if (lane == 0) {
-      // steps2/steps3 are wave-uniform accumulators: one add per wave
-      if (steps2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], (unsigned long long)steps2);
-      if (steps3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], (unsigned long long)steps3);
-      if (ctr.narrow) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 2], (unsigned long long)ctr.narrow);
+      if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]), (unsigned long long)steps2);
+      if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]), (unsigned long long)steps3);
+      if (ctr.narrow) atomicAdd(&misc[M_NARROW], ctr.narrow);
     }
     ctr = Ctr(); steps2 = 0; steps3 = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its merge atomics have been performed
     __syncthreads();
     if (tid == 0) {
+      const unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);
+      const unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]);
+      if (s2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], s2);
+      if (s3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], s3);
+      if (misc[M_NARROW]) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 2], (unsigned long long)misc[M_NARROW]);
+      *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]) = 0;
+      *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]) = 0;
+      misc[M_NARROW] = 0;
       if (remaining[0]) atomicAdd(&a.team_remaining[node0], remaining[0]);
       if (misc[M_FAIL]) atomicOr(&a.team_fail[node0], 1u);
       // publish: agent-scope release, drain, then take a ticket (MI355X_MICROARCH "valid forms")
