@@ -1,0 +1,195 @@
+"""Multi-GPU subtree search: the open-node worklist sharded over the ranks of one node.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` is RCCL over xGMI on MI355X, ``gloo`` in the CPU
+tests).  The propagation data path has NO collective: open search nodes are independent spaces over one
+immutable model, every rank holds the whole model and propagates its own nodes.  The only exchange step is
+work balancing:
+
+  X1  all_gather of the worklist lengths                      (world x 8 bytes)
+  X2  pairwise send/recv of whole node records, richest -> poorest, one batch_isend_irecv — on xGMI every
+      pair of GPUs has its own link, so direct pairwise transfers use all links at once where a ring would
+      be bound by one
+  X3  all_reduce(SUM) of counters, all_reduce(MAX) of the stop flag
+
+A node record is what the reference's branch label holds (search/branching/branch.rs:29-49): the vstore label
+= the domains (copy memory, variable/memory/copy_memory.rs:141-151) and the cstore label = the ``active``
+BitSet (propagation/store.rs:315-317); the model itself (``propagators``) is shared and never moves.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from .model import FALSE, TRUE, UNKNOWN
+from .search import branch
+
+
+@dataclass
+class Worklist:
+    """LIFO stack of open nodes (gcollections::VectorStack in the reference), stored as row blocks."""
+    n_vars: int
+    words: int
+    lb: np.ndarray = None
+    ub: np.ndarray = None
+    act: np.ndarray = None
+
+    def __post_init__(self):
+        if self.lb is None:
+            self.lb = np.zeros((0, self.n_vars), np.int32)
+            self.ub = np.zeros((0, self.n_vars), np.int32)
+            self.act = np.zeros((0, self.words), np.uint64)
+
+    def __len__(self):
+        return self.lb.shape[0]
+
+    def push(self, lb, ub, act):
+        self.lb = np.concatenate([self.lb, lb.reshape(-1, self.n_vars)])
+        self.ub = np.concatenate([self.ub, ub.reshape(-1, self.n_vars)])
+        self.act = np.concatenate([self.act, act.reshape(-1, self.words)])
+
+    def pop(self, k: int):
+        """Take the top k nodes (top of the stack first)."""
+        k = min(k, len(self))
+        n = len(self)
+        out = (self.lb[n - k:][::-1].copy(), self.ub[n - k:][::-1].copy(), self.act[n - k:][::-1].copy())
+        self.lb, self.ub, self.act = self.lb[: n - k], self.ub[: n - k], self.act[: n - k]
+        return out
+
+    def take_bottom(self, k: int):
+        """Give away the k OLDEST nodes (closest to the root: the largest subtrees, the classic work-stealing end)."""
+        k = min(k, len(self))
+        out = (self.lb[:k].copy(), self.ub[:k].copy(), self.act[:k].copy())
+        self.lb, self.ub, self.act = self.lb[k:], self.ub[k:], self.act[k:]
+        return out
+
+
+def plan_moves(lengths: List[int]) -> List[Tuple[int, int, int]]:
+    """Deterministic balancing plan from the gathered worklist lengths: repeatedly move nodes from the richest
+    to the poorest rank until every rank is within one node of the mean.  Returns (src, dst, count) triples;
+    every rank computes the same plan from the same all_gather result."""
+    n = len(lengths)
+    cur = list(lengths)
+    total = sum(cur)
+    target = [total // n + (1 if r < total % n else 0) for r in range(n)]
+    surplus = [[r, cur[r] - target[r]] for r in range(n) if cur[r] > target[r]]
+    deficit = [[r, target[r] - cur[r]] for r in range(n) if cur[r] < target[r]]
+    surplus.sort(key=lambda t: (-t[1], t[0]))
+    deficit.sort(key=lambda t: (-t[1], t[0]))
+    moves = []
+    i = j = 0
+    while i < len(surplus) and j < len(deficit):
+        k = min(surplus[i][1], deficit[j][1])
+        if k > 0:
+            moves.append((surplus[i][0], deficit[j][0], k))
+        surplus[i][1] -= k
+        deficit[j][1] -= k
+        if surplus[i][1] == 0:
+            i += 1
+        if deficit[j][1] == 0:
+            j += 1
+    return moves
+
+
+def balance(wl: Worklist, dist, device=None) -> int:
+    """X1 + X2.  Returns the number of nodes this rank sent (+) or received (-)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    mine = torch.tensor([len(wl)], dtype=torch.int64, device=dev)
+    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    lengths = [int(t.item()) for t in gathered]
+    moves = plan_moves(lengths)
+    ops, recv_bufs, delta = [], [], 0
+    rec_words = 2 * wl.n_vars * 4 + wl.words * 8  # bytes per node record
+    for src, dst, k in moves:
+        if rank == src:
+            lb, ub, act = wl.take_bottom(k)
+            payload = np.concatenate([lb.view(np.uint8).reshape(k, -1), ub.view(np.uint8).reshape(k, -1), act.view(np.uint8).reshape(k, -1)], axis=1)
+            t = torch.from_numpy(np.ascontiguousarray(payload)).to(dev)
+            ops.append(dist.P2POp(dist.isend, t, dst))
+            delta += k
+        elif rank == dst:
+            t = torch.empty((k, rec_words), dtype=torch.uint8, device=dev)
+            ops.append(dist.P2POp(dist.irecv, t, src))
+            recv_bufs.append(t)
+            delta -= k
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for t in recv_bufs:
+        raw = t.cpu().numpy()
+        nv4 = wl.n_vars * 4
+        lb = np.ascontiguousarray(raw[:, :nv4]).view(np.int32)
+        ub = np.ascontiguousarray(raw[:, nv4:2 * nv4]).view(np.int32)
+        act = np.ascontiguousarray(raw[:, 2 * nv4:]).view(np.uint64)
+        # received nodes go to the BOTTOM: they are old, large subtrees; the local dive continues on top
+        wl.lb = np.concatenate([lb, wl.lb])
+        wl.ub = np.concatenate([ub, wl.ub])
+        wl.act = np.concatenate([act, wl.act])
+    return delta
+
+
+@dataclass
+class ParallelStats:
+    num_nodes: int = 0
+    num_solution: int = 0
+    num_failed_node: int = 0
+    filter_steps: int = 0
+    rounds: int = 0
+    moved: int = 0
+    solutions: List[np.ndarray] = field(default_factory=list)
+
+
+def parallel_search(ctx, lb0, ub0, dist, batch: int = 64, all_solutions: bool = True, node_limit: int = 0,
+                    balance_every: int = 1, device=None, full_active: Optional[Callable] = None) -> ParallelStats:
+    """Batched subtree search with the worklist sharded over ranks.  Rank 0 starts with the root; every round
+    each rank propagates the top ``batch`` nodes of its stack in one launch, branches the Unknown ones
+    (FirstSmallestVar/MiddleVal/BinarySplit, folded) and pushes the children; every ``balance_every`` rounds
+    the stacks are balanced (X1+X2) and termination / counters are agreed on (X3).  The set of solutions and
+    every node's fixpoint are schedule-independent; the exploration order is not."""
+    import torch
+    from .engine import full_active as _fa
+    fa = full_active or _fa
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    n_vars = int(np.asarray(lb0).shape[-1])
+    wl = Worklist(n_vars, ctx.words)
+    if rank == 0:
+        wl.push(np.ascontiguousarray(lb0, np.int32), np.ascontiguousarray(ub0, np.int32), fa(1, ctx.n_units))
+    st = ParallelStats()
+    while True:
+        if len(wl):
+            L, U, A = wl.pop(batch)
+            ok = (L <= U).all(axis=1)
+            st.num_nodes += L.shape[0]
+            st.num_failed_node += int((~ok).sum())
+            if ok.any():
+                lb, ub, act, status, s = ctx.propagate(L[ok], U[ok], A[ok])
+                st.filter_steps += s["steps"] + s.get("steps3", 0)
+                st.num_failed_node += int((status == FALSE).sum())
+                for r in np.nonzero(status == TRUE)[0]:
+                    st.num_solution += 1
+                    st.solutions.append(lb[r].copy())
+                unk = np.nonzero(status == UNKNOWN)[0]
+                if len(unk):
+                    cl, cu, ca = branch(lb[unk], ub[unk], act[unk])
+                    # children in reverse so that the first node's left child ends on top of the stack
+                    wl.push(cl[::-1], cu[::-1], ca[::-1])
+        st.rounds += 1
+        if st.rounds % balance_every == 0:
+            sent = balance(wl, dist, dev)
+            st.moved += max(sent, 0)
+            # X3: agree on termination (global open count, solutions, node budget)
+            flags = torch.tensor([len(wl), st.num_solution, st.num_nodes], dtype=torch.int64, device=dev)
+            dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+            open_total, sol_total, nodes_total = (int(x) for x in flags.tolist())
+            if open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit):
+                break
+    tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, st.moved], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    g = ParallelStats(*[int(x) for x in tot.tolist()[:4]], rounds=st.rounds, moved=int(tot[4]))
+    g.solutions = st.solutions  # local solutions only
+    return g

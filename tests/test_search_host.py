@@ -1,0 +1,145 @@
+"""Host-side search driver (pcp_amd.search) and multi-rank worklist (pcp_amd.distributed) on CPU.  The engine
+is replaced by the oracle-backed stand-in of tests/oracle_ctx.py; the N>1 path runs as 2 gloo ranks."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from pcp_amd import model as M
+from pcp_amd import search as S
+from pcp_amd import distributed as D
+
+from oracle_ctx import OracleCtx
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ALL_SOLUTIONS = [1, 0, 0, 2, 10, 4, 40, 92, 352]  # search/engine/all_solution.rs:70
+
+
+def test_branching_against_reference_tables():
+    g = json.load(open(os.path.join(GOLDEN, "engine_kats.json")))["search"]
+    for c in g["first_smallest_var"]["cases"]:
+        lb = np.array([[d[0] for d in c["vars"]]], np.int32)
+        ub = np.array([[d[1] for d in c["vars"]]], np.int32)
+        assert S.first_smallest_var(lb, ub)[0] == c["expect"]
+    pv = g["first_smallest_var"]["panic"]["vars"]
+    assert S.first_smallest_var(np.array([[d[0] for d in pv]], np.int32), np.array([[d[1] for d in pv]], np.int32))[0] == -1
+    root = g["binary_split"]["root"]
+    # FirstSmallestVar picks var 2 ([1,2]) on the reference's root; check each var's split by masking the others
+    for c in g["binary_split"]["cases"]:
+        lb = np.array([[5, 5, 5]], np.int32)
+        ub = np.array([[5, 5, 5]], np.int32)
+        lb[0, c["var"]], ub[0, c["var"]] = root[c["var"]]
+        L, U, _ = S.branch(lb, ub, None)
+        assert [[int(L[0, c["var"]]), int(U[0, c["var"]])], [int(L[1, c["var"]]), int(U[1, c["var"]])]] == c["children"]
+    # MiddleVal truncates toward zero like Rust's `/`
+    assert S.middle_val(np.array([-3]), np.array([-2]))[0] == -2 and orc.middle_val(-3, -2) == -2
+    assert S.middle_val(np.array([-7]), np.array([2]))[0] == -2 and orc.middle_val(-7, 2) == -2
+
+
+@pytest.mark.parametrize("n", range(1, 9))
+def test_dfs_matches_reference_order(n):
+    """batch=1 DFS == the reference's left-first DFS: same solutions, same node and failure counts."""
+    props = M.nqueens_props(n) if n > 1 else M.lower_units([], 1)
+    ctx = OracleCtx(n, props)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    st = S.dfs(ctx, lb0, ub0, all_solutions=True)
+    ss, _, _, _ = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
+    assert st.num_solution == ALL_SOLUTIONS[n - 1] == ss["num_solution"]
+    assert st.num_nodes == ss["num_nodes"] and st.num_failed_node == ss["num_failed_node"]
+    one = S.dfs(ctx, lb0, ub0, all_solutions=False)
+    ss1, _, _, sol = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=False)
+    assert one.num_nodes == ss1["num_nodes"]
+    if ss1["num_solution"]:
+        assert np.array_equal(one.solutions[0], sol)
+
+
+@pytest.mark.parametrize("batch", [2, 7, 64])
+def test_batched_dfs_finds_the_same_solutions(batch):
+    n = 8
+    props = M.nqueens_props(n)
+    ctx = OracleCtx(n, props)
+    st = S.dfs(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True, batch=batch)
+    assert st.num_solution == 92 and st.num_nodes == 779 and st.num_failed_node == 298
+    assert len({tuple(s) for s in st.solutions}) == 92
+    assert st.launches <= 779 // min(batch, 4) + 1
+
+
+def test_node_limit_is_stopnode():
+    n = 6
+    ctx = OracleCtx(n, M.nqueens_props(n))
+    st = S.dfs(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True, node_limit=10)
+    assert st.num_nodes == 10  # search/stop_node.rs:82-104
+
+
+def test_bfs_frontier():
+    n = 8
+    ctx = OracleCtx(n, M.nqueens_props(n))
+    L, U, A, st = S.bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), 32)
+    assert L.shape[0] == 32 and (L <= U).all()
+    assert len({(tuple(l), tuple(u)) for l, u in zip(L, U)}) == 32  # distinct open nodes
+    # finishing the search from the frontier finds what is left of the 92 solutions
+    rest = 0
+    full = S.bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), 10 ** 6, max_rounds=40)
+    assert full[3].num_solution == 92 and full[0].shape[0] == 0
+
+
+def test_plan_moves_balances():
+    for lengths in ([10, 0], [0, 0, 9, 1], [5, 5, 5, 5], [100, 3, 0, 0, 0, 0, 0, 1], [1, 0, 0]):
+        moves = D.plan_moves(lengths)
+        cur = list(lengths)
+        for s, d, k in moves:
+            assert k > 0 and s != d
+            cur[s] -= k
+            cur[d] += k
+        assert sum(cur) == sum(lengths) and max(cur) - min(cur) <= 1 and min(cur) >= 0
+    assert D.plan_moves([4, 4]) == []
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, batch, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = OracleCtx(n, M.nqueens_props(n))
+        st = D.parallel_search(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), dist, batch=batch, all_solutions=True,
+                               full_active=orc.full_active)
+        local = sorted(tuple(int(v) for v in s) for s in st.solutions)
+        q.put((rank, st.num_nodes, st.num_solution, st.num_failed_node, st.moved, local))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [1, 16])
+def test_two_rank_worklist_gloo(batch):
+    """world_size 2 over gloo: the sharded search explores exactly the reference's tree (779 nodes, 298 failures,
+    92 distinct solutions for n=8), work really moves between the ranks, and both ranks agree on the totals."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_worker, args=(r, 2, port, 8, batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    assert res[0][1:5] == res[1][1:5]          # identical global totals on both ranks
+    assert res[0][1] == 779 and res[0][2] == 92 and res[0][3] == 298
+    assert res[0][4] > 0                        # nodes were exchanged
+    sols = res[0][5] + res[1][5]
+    assert len(sols) == 92 and len(set(sols)) == 92
+    assert len(res[0][5]) > 0 and len(res[1][5]) > 0  # both ranks did real work
