@@ -30,6 +30,9 @@ struct pcp_ctx {
   uint32_t* d_adj_off = nullptr;
   uint32_t* d_adj = nullptr;
   int32_t* d_const = nullptr;
+  uint32_t* d_rec_unit = nullptr;    // grouped models only: unit of each record
+  uint32_t* d_unit_first = nullptr;  // grouped models only: first record of each unit (+ sentinel)
+  size_t cap_rec_unit = 0, cap_unit_first = 0;
   uint32_t n_slots = 0;
   bool has_ternary = false;
   size_t cap_recs = 0, cap_adj = 0, cap_adj_off = 0, cap_const = 0;
@@ -106,7 +109,6 @@ int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
 int32_t finalize_model(pcp_ctx* c) {
   if (!c->dirty) return PCP_OK;
   const size_t P = c->props.size();
-  if (c->has_groups) return fail(c, PCP_ERR_UNSUPPORTED, "Conjunction/Distinct groups are not lowered yet");
   std::map<int32_t, uint32_t> const_slot;
   std::vector<int32_t> consts;
   auto slot_of = [&](uint32_t var, int32_t value) -> uint32_t {
@@ -167,6 +169,14 @@ int32_t finalize_model(pcp_ctx* c) {
   HIP_TRY(c, hipMemcpy(c->d_adj_off, adj_off.data(), adj_off.size() * 4, hipMemcpyHostToDevice));
   if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  if (c->has_groups) {
+    std::vector<uint32_t> first(c->n_units + 1, (uint32_t)P);
+    for (size_t r = P; r-- > 0;) first[c->unit_of_prop[r]] = (uint32_t)r;
+    if ((rc = ensure(c, c->d_rec_unit, c->cap_rec_unit, P))) return rc;
+    if ((rc = ensure(c, c->d_unit_first, c->cap_unit_first, first.size()))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_rec_unit, c->unit_of_prop.data(), P * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_unit_first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
+  }
   c->n_slots = n_slots;
   c->has_ternary = tern;
   c->dirty = false;
@@ -223,7 +233,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -378,8 +388,16 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.live_in = bt->active_in;
   a.status = bt->status;
   a.stats = c->d_stats;
-  if (bt->active_out) a.live = bt->active_out;
-  else {
+  const uint32_t unit_words = (c->n_units + 63) / 64;
+  if (c->has_groups) {
+    // record-level live rows in scratch, seeded from the unit-level `active` rows (in place for the kernel)
+    if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+    HIP_TRY(c, launch_expand_units(c->d_rec_unit, P, unit_words, bt->active_in, c->d_live, n_nodes, stream));
+    a.live_in = c->d_live;
+    a.live = c->d_live;
+  } else if (bt->active_out) {
+    a.live = bt->active_out;
+  } else {
     if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
     a.live = c->d_live;
   }
@@ -403,6 +421,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (c->has_groups && bt->active_out)
+    HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
   c->ev_valid = true;
   return PCP_OK;
 }

@@ -70,4 +70,10 @@ size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_c
 
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);
 
+// Grouped models (Conjunction / Distinct units): unit-level `active` rows <-> record-level live rows.
+hipError_t launch_expand_units(const uint32_t* rec_unit, uint32_t n_recs, uint32_t unit_words, const uint64_t* active_in, uint64_t* live,
+                               uint32_t n_nodes, hipStream_t stream);
+hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, uint32_t n_recs, const uint64_t* live, uint64_t* active_out,
+                                 uint32_t n_nodes, hipStream_t stream);
+
 }  // namespace pcp

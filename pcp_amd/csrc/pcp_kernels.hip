@@ -21,6 +21,8 @@
 //    the fixpoint alone — no grid barrier, no co-residency requirement.
 // Integer bound work only: no MFMA.  All filters are monotone and contracting, so the wave schedule reaches
 // the same greatest fixpoint as the reference's FIFO (SURVEY.md §7 "chaotic-iteration equivalence").
+#include <algorithm>
+
 #include "pcp_internal.h"
 
 namespace pcp {
@@ -769,6 +771,74 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));
     if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conjunction / Distinct units (logic/conjunction.rs:77-119, propagators/distinct.rs:63-126).  The reference keeps
+// ONE active bit for the whole conjunction: it is entailed iff every member is (conjunction.rs:78-94), and a pop
+// runs every member (conjunction.rs:97-104).  The fixpoint kernel works on elementary records, so a grouped model
+// carries a record-level live mask: expand_units seeds it (member live <=> its unit active) and contract_units
+// folds it back (unit active <=> some member still live, i.e. not all members entailed under the final domains).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) expand_units_kernel(const uint32_t* __restrict__ rec_unit, uint32_t n_recs, uint32_t unit_words,
+                                                           const uint64_t* __restrict__ active_in, uint64_t* __restrict__ live, uint32_t n_nodes) {
+  const uint32_t rec_words = (n_recs + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint64_t i = wave; i < (uint64_t)n_nodes * rec_words; i += nwaves) {
+    const uint32_t node = (uint32_t)(i / rec_words), w = (uint32_t)(i % rec_words);
+    const uint32_t r = (w << 6) + lane;
+    bool on = false;
+    if (r < n_recs) {
+      const uint32_t u = rec_unit[r];
+      on = active_in ? ((active_in[(size_t)node * unit_words + (u >> 6)] >> (u & 63)) & 1ull) : true;
+    }
+    const uint64_t word = __ballot(on);
+    if (lane == 0) live[(size_t)node * rec_words + w] = word;
+  }
+}
+
+__global__ void __launch_bounds__(256) contract_units_kernel(const uint32_t* __restrict__ unit_first, uint32_t n_units, uint32_t n_recs,
+                                                             const uint64_t* __restrict__ live, uint64_t* __restrict__ active_out, uint32_t n_nodes) {
+  const uint32_t rec_words = (n_recs + 63) >> 6, unit_words = (n_units + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint64_t i = wave; i < (uint64_t)n_nodes * unit_words; i += nwaves) {
+    const uint32_t node = (uint32_t)(i / unit_words), uw = (uint32_t)(i % unit_words);
+    const uint32_t u = (uw << 6) + lane;
+    const uint64_t* row = live + (size_t)node * rec_words;
+    bool on = false;
+    if (u < n_units) {
+      const uint32_t r0 = unit_first[u], r1 = unit_first[u + 1];
+      if (r1 - r0 == 1) {
+        on = (row[r0 >> 6] >> (r0 & 63)) & 1ull;
+      } else {
+        for (uint32_t w = r0 >> 6; w <= ((r1 - 1) >> 6) && !on; ++w) {
+          uint64_t m = row[w];
+          if (w == (r0 >> 6)) m &= ~0ull << (r0 & 63);
+          if (w == ((r1 - 1) >> 6) && (r1 & 63)) m &= (1ull << (r1 & 63)) - 1;
+          on = m != 0;
+        }
+      }
+    }
+    const uint64_t word = __ballot(on);
+    if (lane == 0) active_out[(size_t)node * unit_words + uw] = word;
+  }
+}
+
+hipError_t launch_expand_units(const uint32_t* rec_unit, uint32_t n_recs, uint32_t unit_words, const uint64_t* active_in, uint64_t* live,
+                               uint32_t n_nodes, hipStream_t stream) {
+  const uint64_t items = (uint64_t)n_nodes * ((n_recs + 63) >> 6);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + 3) / 4), 8192);
+  hipLaunchKernelGGL(expand_units_kernel, dim3(grid), dim3(256), 0, stream, rec_unit, n_recs, unit_words, active_in, live, n_nodes);
+  return hipGetLastError();
+}
+hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, uint32_t n_recs, const uint64_t* live, uint64_t* active_out,
+                                 uint32_t n_nodes, hipStream_t stream) {
+  const uint64_t items = (uint64_t)n_nodes * ((n_units + 63) >> 6);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + 3) / 4), 8192);
+  hipLaunchKernelGGL(contract_units_kernel, dim3(grid), dim3(256), 0, stream, unit_first, n_units, n_recs, live, active_out, n_nodes);
+  return hipGetLastError();
 }
 
 template <int B>

@@ -294,3 +294,23 @@ def chained_lt(n: int) -> Tuple[VStore, CStore]:
     for i in range(n - 1):
         cs.alloc(XLessY(xs[i], xs[i + 1]))
     return vs, cs
+
+
+def golomb(m: int = 10, length: int = 80):
+    """BASELINE config 4: bound-consistent distinct + sum network, Golomb-ruler style.
+    marks m_0..m_{m-1} in [0,length], m_0 = 0, m_i < m_{i+1}; differences d_ij in [1,length] with
+    m_j = m_i + d_ij (XEqYPlusZ); ONE Distinct over all differences; symmetry d_01 < d_{m-2,m-1}."""
+    vs, cs = VStore(), CStore()
+    marks = [vs.alloc((0, length)) for _ in range(m)]
+    cs.alloc(XEqY(marks[0], Constant(0)))
+    for i in range(m - 1):
+        cs.alloc(XLessY(marks[i], marks[i + 1]))
+    diffs = {}
+    for i in range(m - 1):
+        for j in range(i + 1, m):
+            d = vs.alloc((1, length))
+            diffs[(i, j)] = d
+            cs.alloc(XEqYPlusZ(marks[j], marks[i], d))
+    cs.alloc(Distinct(list(diffs.values())))
+    cs.alloc(XLessY(diffs[(0, 1)], diffs[(m - 2, m - 1)]))
+    return vs, cs

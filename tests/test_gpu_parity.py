@@ -42,8 +42,6 @@ def test_kat_inputs_as_one_node_fixpoints(ctx):
     data = json.load(open(os.path.join(GOLDEN, "propagator_kats.json")))
     n_cases = 0
     for s in data["suites"]:
-        if s["ctor"] == "Distinct":
-            continue  # Conjunction groups: covered once groups are lowered
         for c in s["cases"]:
             unit = build_unit(s, c)
             n = len(c["doms"])
@@ -161,6 +159,46 @@ def test_nqueens_1000_root_and_dive(ctx):
         got = ctx.propagate(L, U, E.full_active(N, om.n_units))
         assert_parity(ref[:4], got[:4], f"nqueens1000 {opts}")
         assert got[4]["steps"] >= N * om.n_units
+
+
+def test_golomb_distinct_sum_network(ctx):
+    """BASELINE config 4: EQ3 sum network + ONE Distinct unit (a Conjunction group of 990 XNeqY) + LT chain, V=55;
+    the search frontier after 12 BinarySplit levels, propagated in one launch (batch and team paths)."""
+    vs, cs = M.golomb(10, 80)
+    V = len(vs)
+    props = cs.lower(V)
+    om = orc.OracleModel(V, props)
+    assert om.n_units == len(cs) and len(props) == 1 + 9 + 45 + 990 + 1
+    lb0, ub0 = vs.bounds()
+    from oracle_ctx import OracleCtx
+    from pcp_amd import search as S
+    L, U, A, _ = S.bfs_frontier(OracleCtx(V, props), lb0, ub0, 512, max_rounds=14)
+    assert L.shape[0] >= 256
+    ref = om.consistency(L, U, A)
+    assert (ref[3] == 0).any() and (ref[3] == 2).any()
+    ctx.set_model(V, props)
+    for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 2}, {"force_path": 2, "team": 3}):
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(L, U, A)
+        assert_parity(ref[:4], got[:4], f"golomb {opts}")
+        assert got[4]["steps3"] > 0
+
+
+@pytest.mark.parametrize("n", [6, 9])
+def test_nqueens_global_distinct_search(ctx, n):
+    """The doc-comment N-queens (lib.rs:56) with ONE Distinct unit: whole search on the GPU engine through the host
+    driver == the oracle's search (node, failure and solution counts; the tree is schedule-independent)."""
+    from pcp_amd import search as S
+    vs, cs = M.nqueens(n, "global")
+    props = cs.lower(n)
+    lb0, ub0 = vs.bounds()
+    ss, _, _, _ = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048}.items():
+        ctx.set_option(k, v)
+    st = S.dfs(ctx, lb0, ub0, all_solutions=True, batch=32)
+    assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
 
 
 def test_contract_errors(ctx):
