@@ -102,13 +102,19 @@ def main():
     ctx.set_option("nodes_per_block", args.nodes_per_block)
 
     # ---- synthetic input: the breadth-first frontier of the search tree, sharded by rank --------------------
-    total_nodes = args.nodes * world
+    # Every rank expands the root to a small common frontier (>= 8 subtrees per rank), keeps the subtrees
+    # rank, rank+world, ... and expands THOSE breadth-first to its own args.nodes open nodes: per-GPU work is fixed
+    # (weak scaling) and no rank ever materialises another rank's nodes.
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
-    L, U, A, fst = S.bfs_frontier(ctx, lb0, ub0, total_nodes)
-    if L.shape[0] < total_nodes:
+    if world > 1:
+        L0, U0, A0, _ = S.bfs_frontier(ctx, lb0, ub0, 8 * world)
+        if L0.shape[0] < world:
+            raise SystemExit(f"common frontier has only {L0.shape[0]} open nodes for {world} ranks")
+        L, U, A, fst = S.bfs_frontier(ctx, L0[rank::world], U0[rank::world], args.nodes, active0=A0[rank::world])
+    else:
+        L, U, A, fst = S.bfs_frontier(ctx, lb0, ub0, args.nodes)
+    if L.shape[0] < args.nodes:
         raise SystemExit(f"frontier has only {L.shape[0]} open nodes")
-    sl = slice(rank * args.nodes, (rank + 1) * args.nodes)
-    L, U, A = L[sl], U[sl], A[sl]
     t_lb_in = torch.from_numpy(L).to(dev)
     t_ub_in = torch.from_numpy(U).to(dev)
     t_act_in = torch.from_numpy(A.view(np.int64)).to(dev)

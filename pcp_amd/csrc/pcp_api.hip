@@ -54,6 +54,7 @@ struct pcp_ctx {
   int64_t opt_force_path = 0;       // 0 auto, 1 batch, 2 team
   int64_t opt_team = 0;             // 0 = auto
   int64_t opt_list_cap = 2048;
+  int64_t opt_global_dom = 0;       // 1 = force the HBM-resident-domain variant (tests)
 };
 
 namespace {
@@ -312,6 +313,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "team") {
     if (value < 0 || value > 4096) return fail(c, PCP_ERR_ARG, "team must be in [0,4096]");
     c->opt_team = value;
+  } else if (k == "global_dom") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "global_dom must be 0 or 1");
+    c->opt_global_dom = value;
   } else if (k == "list_cap") {
     if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
     c->opt_list_cap = value;
@@ -357,7 +361,14 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
         if (uint32_t cap = fits(t)) { list_cap_used = cap; return t; }
     return 0u;
   };
-  if (!fits(1)) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large for the LDS-resident kernel");
+  // Variable stores too large for LDS (8 bytes per variable and node) run with the domains left in HBM/L2.
+  const bool global_dom = c->opt_global_dom || !fits(1);
+  if (global_dom) {
+    uint32_t cap = list_cap;
+    while (cap > 256 && !lds_bytes_global(c->n_vars, S, cap)) cap /= 2;
+    if (!lds_bytes_global(c->n_vars, S, cap)) return fail(c, PCP_ERR_UNSUPPORTED, "variable store too large even for the bitmasks in LDS");
+    list_cap_used = cap;
+  }
   const uint32_t slots = (uint32_t)c->num_cu;  // one resident workgroup per CU is what large tiles allow
   uint32_t B = 1, team = 1;
   bool use_team = false;
@@ -371,19 +382,19 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     team = std::max<uint32_t>(1, std::min(g, max_by_work));
   } else {
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
-    B = std::max<uint32_t>(1, tile_le(want));
+    B = global_dom ? 1u : std::max<uint32_t>(1, tile_le(want));
   }
   LaunchPlan plan;
   plan.block = block;
-  if (use_team) list_cap_used = fits(1);
-  plan.lds_bytes = lds_bytes_for(S, B, list_cap_used, block);
+  if (use_team && !global_dom) list_cap_used = fits(1);
+  plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block);
   plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
-  a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used;
+  a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -413,10 +424,11 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     a.team_remaining = a.team_ticket + n_nodes;
     a.team_fail = a.team_remaining + n_nodes;
     a.team_chg = a.team_fail + n_nodes + (n_nodes & 1);                  // keep alignment tidy
-    if (bt->lb_out != bt->lb_in && c->n_vars) {
-      HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
-      HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
-    }
+  }
+  if ((team > 1 || global_dom) && bt->lb_out != bt->lb_in && c->n_vars) {
+    // team: every slice narrows the node's rows in lb_out/ub_out with atomics; global_dom: they are the working set
+    HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));

@@ -43,6 +43,7 @@ struct LaunchArgs {
   uint32_t nodes_per_block;  // B: nodes whose domains one workgroup keeps in LDS (team == 1)
   uint32_t team;             // G: workgroups cooperating on ONE node (nodes_per_block == 1 when team > 1)
   uint32_t list_cap;         // capacity of the per-round changed-(node,var) list in LDS
+  uint32_t global_dom;       // 1 = domains stay in lb_out/ub_out (HBM/L2), for variable stores larger than LDS
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -67,6 +68,7 @@ struct LaunchPlan {
 
 // Computes the dynamic-LDS footprint for (n_slots, B, list_cap); returns 0 if it cannot fit.
 size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block);
+size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap);
 
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);
 

@@ -72,6 +72,54 @@ struct LdsDom {
   }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Domain access policy for variable stores that do not fit in LDS (BASELINE config 3: 50 000 variables =
+// 400 KB per node): the node's (lb,ub) rows stay in HBM/L2 — the lb_out/ub_out arrays themselves — and are
+// narrowed with device-scope atomicMax/atomicMin.  Reads are relaxed agent-scope atomic loads (global_load … sc1):
+// they bypass the per-CU L1, which is never refreshed by atomics performed at L2, so a workgroup always sees
+// its own and its team-mates' narrowings.  Constants (pseudo-variable slots >= n_vars) sit in a small LDS array.
+// A failure can be missed at the moment it happens (two narrowings of one variable racing on different CUs);
+// the final scan of the node's domains (phase 4) catches it.
+// ------------------------------------------------------------------------------------------------
+struct GlobalDom {
+  int32_t* lb;      // [n_vars] this node's rows
+  int32_t* ub;
+  int2* cdom;       // LDS: constants, indexed by slot - n_vars
+  uint32_t n_vars;
+  uint32_t* chg;
+  uint32_t* fail;
+  uint32_t fbit;
+  Ctr* c;
+
+  __device__ __forceinline__ int2 load(uint32_t v) const {
+    if (v >= n_vars) return cdom[v - n_vars];
+    int2 d;
+    d.x = __hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.y = __hip_atomic_load(&ub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return d;
+  }
+  __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
+  __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    if (v >= n_vars) { if (nlb > cdom[v - n_vars].y) set_fail(); return; }  // Constant::update (term/constant.rs:49-52)
+    const int old = atomicMax(&lb[v], nlb);
+    if (old < nlb) {
+      ++c->narrow;
+      mark(v);
+      if (nlb > __hip_atomic_load(&ub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) set_fail();
+    }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    if (v >= n_vars) { if (nub < cdom[v - n_vars].x) set_fail(); return; }
+    const int old = atomicMin(&ub[v], nub);
+    if (old > nub) {
+      ++c->narrow;
+      mark(v);
+      if (__hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > nub) set_fail();
+    }
+  }
+};
+
 __device__ __forceinline__ int clamp_i32(long long v) {
   const long long lo = -2147483647LL, hi = 2147483647LL;
   return (int)(v < lo ? lo : (v > hi ? hi : v));
@@ -221,12 +269,14 @@ struct Carve {
   size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
 __host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 2u; }
-__host__ __device__ inline Carve carve(uint32_t n_slots, uint32_t B, uint32_t list_cap) {
+// dom_slots: slots whose domains live in LDS (all of them, or only the constants in the global variant);
+// mask_slots: slots covered by the changed-variable bitmasks (always all).
+__host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t list_cap, uint32_t mask_slots) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  const size_t Wv = (n_slots + 31) / 32;
+  const size_t Wv = (mask_slots + 31) / 32;
   Carve c;
   size_t o = 0;
-  c.dom = o; o = up(o + (size_t)row_stride(B) * n_slots * 8);
+  c.dom = o; o = up(o + (size_t)row_stride(B) * dom_slots * 8);
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
@@ -240,7 +290,11 @@ __host__ __device__ inline Carve carve(uint32_t n_slots, uint32_t B, uint32_t li
 
 size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block) {
   (void)block;
-  Carve c = carve(n_slots, nodes_per_block, list_cap);
+  Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots);
+  return c.total <= 160 * 1024 ? c.total : 0;
+}
+size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
+  Carve c = carve(n_slots - n_vars, 1, list_cap, n_slots);
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
@@ -248,14 +302,29 @@ size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_c
 enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_STEPS2 = 8, M_STEPS3 = 10 };
 
 struct BlockCtx {
-  int2* dom;
+  int2* dom;    // LDS domains [slot][bp] (LDS variant) or the constants' singleton domains [slot - n_vars] (global variant)
   uint32_t bp;  // row stride of dom
   uint32_t S, Wv;
   uint32_t* misc;
+  int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
+  int32_t* gub;
+  uint32_t V;
 };
 
-__device__ __forceinline__ LdsDom make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
+template <bool GLOBAL>
+struct DomOf { using type = LdsDom; };
+template <>
+struct DomOf<true> { using type = GlobalDom; };
+
+template <bool GLOBAL>
+__device__ __forceinline__ typename DomOf<GLOBAL>::type make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr);
+template <>
+__device__ __forceinline__ LdsDom make_dom<false>(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
   return LdsDom{k.dom + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
+}
+template <>
+__device__ __forceinline__ GlobalDom make_dom<true>(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
+  return GlobalDom{k.glb, k.gub, k.dom, k.V, chg_next, &k.misc[M_FAIL], 1u, ctr};  // one node per block
 }
 
 // Fast predicate of one binary kind on the domains read for one node: a wave mask straight out of v_cmp.
@@ -377,7 +446,7 @@ __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
 // LDS atomics.  The fast predicates restate exactly the no-op conditions of XNeqY/XLessY/XEqY::propagate and
 // the True case of their is_subsumed (files cited in eval_record).
 // ------------------------------------------------------------------------------------------------
-template <int B>
+template <int B, bool GLOBAL>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t& rem_acc, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -413,7 +482,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
     uint32_t todo;  // nodes to run with the full filter
-    if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+    if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
       const int2* px = k.dom + slot_row<B>(x);
       const int2* py = k.dom + slot_row<B>(y);
       todo = 0;
@@ -457,7 +526,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       const uint64_t word = readlane64(my_word, b);
       bool e = false;
       if ((word >> lane) & 1ull) {
-        const LdsDom dm = make_dom(k, b, chg_next, &ctr);
+        const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
         e = eval_record(rec, dm);
       }
       my_new = writelane64(my_new, word & ~__ballot(e), b);
@@ -473,6 +542,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
 // the live records that touch a variable in `cur`.  Rare path, generic code.
+template <bool GLOBAL>
 __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, const uint32_t* cur,
                                                uint32_t* chg_next, uint32_t& rem_sub, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -497,7 +567,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
       const bool mine = ((word >> lane) & 1ull) && touched;
       bool e = false;
       if (mine) {
-        const LdsDom dm = make_dom(k, b, chg_next, &ctr);
+        const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
         e = eval_record(rec, dm);
       }
       const uint64_t run = __ballot(mine), t3 = __ballot(mine && tern);
@@ -515,14 +585,16 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 // ------------------------------------------------------------------------------------------------
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
-template <int B>
+template <int B, bool GLOBAL>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
+  static_assert(!GLOBAL || B == 1, "the global-domain variant runs one node per block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
   const uint32_t team = a.team, C = a.list_cap;
   constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 2u;
-  const Carve cv = carve(S, B, C);
+  // global variant: only the constants' singleton domains are kept in LDS (slots n_vars..S-1)
+  const Carve cv = carve(GLOBAL ? S - V : S, B, C, S);
   int2* dom = reinterpret_cast<int2*>(smem + cv.dom);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
   uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
@@ -531,29 +603,38 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + cv.tmp);
   uint32_t* remaining = reinterpret_cast<uint32_t*>(smem + cv.remaining);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
-  const BlockCtx k{dom, BP, S, Wv, misc};
 
   uint32_t node0, nb, g;
   if (team > 1) { node0 = blockIdx.x / team; g = blockIdx.x % team; nb = 1; }
   else { node0 = blockIdx.x * B; g = 0; nb = min((uint32_t)B, a.n_nodes - node0); }
+  const BlockCtx k{dom, BP, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   if (tid < 16) misc[tid] = 0;
   if (tid < (uint32_t)B) remaining[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   __syncthreads();
-  for (uint32_t b = 0; b < (uint32_t)B; ++b) {
-    const bool real = b < nb;
-    const int32_t* lbp = a.lb_in + (size_t)(node0 + (real ? b : 0)) * V;
-    const int32_t* ubp = a.ub_in + (size_t)(node0 + (real ? b : 0)) * V;
+  if (GLOBAL) {
+    // the node's rows in lb_out/ub_out ARE the working domains (the host copied the inputs there); only check them
     bool bad = false;
-    for (uint32_t v = tid; v < S; v += nth) {
-      int2 d;
-      if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
-      else { d.x = d.y = a.m.const_val[v - V]; }
-      dom[(size_t)v * BP + b] = d;  // missing nodes of a tail tile mirror node 0: readable, never used
+    if (g == 0)
+      for (uint32_t v = tid; v < V; v += nth) bad |= a.lb_in[(size_t)node0 * V + v] > a.ub_in[(size_t)node0 * V + v];
+    for (uint32_t v = V + tid; v < S; v += nth) { int2 d; d.x = d.y = a.m.const_val[v - V]; dom[v - V] = d; }
+    if (bad) atomicOr(&misc[M_FAIL], 1u);
+  } else {
+    for (uint32_t b = 0; b < (uint32_t)B; ++b) {
+      const bool real = b < nb;
+      const int32_t* lbp = a.lb_in + (size_t)(node0 + (real ? b : 0)) * V;
+      const int32_t* ubp = a.ub_in + (size_t)(node0 + (real ? b : 0)) * V;
+      bool bad = false;
+      for (uint32_t v = tid; v < S; v += nth) {
+        int2 d;
+        if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
+        else { d.x = d.y = a.m.const_val[v - V]; }
+        dom[(size_t)v * BP + b] = d;  // missing nodes of a tail tile mirror node 0: readable, never used
+      }
+      if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
     }
-    if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
   }
   __syncthreads();
 
@@ -566,7 +647,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     uint32_t w0 = 0, w1 = words;
     if (team > 1) { const uint32_t ws = (words + team - 1) / team; w0 = min(words, g * ws); w1 = min(words, w0 + ws); }
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
-    sweep_fast<B>(a, k, w0, w1, node0, nb, cur, rem_acc, steps2, steps3, ctr);
+    sweep_fast<B, GLOBAL>(a, k, w0, w1, node0, nb, cur, rem_acc, steps2, steps3, ctr);
     if (lane < nb && rem_acc) atomicAdd(&remaining[lane], rem_acc);
     rem_acc = 0;
   }
@@ -583,7 +664,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     for (uint32_t w = tid; w < Wv; w += nth) {
       uint32_t bits = cur[w];
       if (bits) atomicOr(&gchg[w], bits);
-      while (bits) {
+      while (!GLOBAL && bits) {
         const uint32_t v = (w << 5) + __builtin_ctz(bits);
         bits &= bits - 1;
         if (v < V) { atomicMax(&glb[v], dom[(size_t)v * BP].x); atomicMin(&gub[v], dom[(size_t)v * BP].y); }
@@ -622,7 +703,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     __syncthreads();
     if (!misc[M_ISLAST]) return;
     // tail block: reload the merged state
-    for (uint32_t v = tid; v < V; v += nth) {
+    for (uint32_t v = tid; !GLOBAL && v < V; v += nth) {
       int2 d;
       d.x = __hip_atomic_load(&glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       d.y = __hip_atomic_load(&gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -704,7 +785,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) skip = true;
         if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) skip = true;
         if (skip) continue;
-        const LdsDom dm = make_dom(k, b, nxt, &ctr);
+        const auto dm = make_dom<GLOBAL>(k, b, nxt, &ctr);
         if (tern) ++my3; else ++my2;
         if (eval_record(rec, dm)) {
           const uint32_t old = atomicAnd(lw, ~bit);
@@ -717,7 +798,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     } else {
       __syncthreads();
       uint32_t rem_sub = 0;
-      sweep_filtered(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
+      sweep_filtered<GLOBAL>(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
       if (lane < nb && rem_sub) atomicSub(&remaining[lane], rem_sub);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -730,16 +811,23 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
 
   // ---- phase 4: write back domains, status, counters ---------------------------------------------------
   __syncthreads();
-  for (uint32_t b = 0; b < nb; ++b) {
-    int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
-    int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
-    bool bad = false;
-    for (uint32_t v = tid; v < S; v += nth) {
-      const int2 d = dom[(size_t)v * BP + b];
-      bad |= d.x > d.y;
-      if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
+  if (GLOBAL) {
+    bool bad = false;  // the domains are already in place; a missed failure shows as an empty domain here
+    for (uint32_t v = tid; v < V; v += nth)
+      bad |= __hip_atomic_load(&k.glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > __hip_atomic_load(&k.gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (bad) atomicOr(&misc[M_FAIL], 1u);
+  } else {
+    for (uint32_t b = 0; b < nb; ++b) {
+      int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
+      int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
+      bool bad = false;
+      for (uint32_t v = tid; v < S; v += nth) {
+        const int2 d = dom[(size_t)v * BP + b];
+        bad |= d.x > d.y;
+        if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
+      }
+      if (bad) atomicOr(&misc[M_FAIL], 1u << b);
     }
-    if (bad) atomicOr(&misc[M_FAIL], 1u << b);
   }
   for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
   if (lane == 0) {
@@ -841,25 +929,26 @@ hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, u
   return hipGetLastError();
 }
 
-template <int B>
+template <int B, bool GLOBAL>
 static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(fixpoint_kernel<B>, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 
-// nodes_per_block must be one of the instantiated tile sizes.
+// nodes_per_block must be one of the instantiated tile sizes; global_dom selects the HBM-resident-domain variant.
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (a.global_dom) return a.nodes_per_block == 1 ? launch_b<1, true>(a, p, stream) : hipErrorInvalidValue;
   switch (a.nodes_per_block) {
-    case 1: return launch_b<1>(a, p, stream);
-    case 2: return launch_b<2>(a, p, stream);
-    case 4: return launch_b<4>(a, p, stream);
-    case 8: return launch_b<8>(a, p, stream);
-    case 12: return launch_b<12>(a, p, stream);
-    case 16: return launch_b<16>(a, p, stream);
+    case 1: return launch_b<1, false>(a, p, stream);
+    case 2: return launch_b<2, false>(a, p, stream);
+    case 4: return launch_b<4, false>(a, p, stream);
+    case 8: return launch_b<8, false>(a, p, stream);
+    case 12: return launch_b<12, false>(a, p, stream);
+    case 16: return launch_b<16, false>(a, p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -66,14 +66,17 @@ class SearchStats:
     solutions: List[np.ndarray] = field(default_factory=list)
 
 
-def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds: int = 64) -> Tuple[np.ndarray, np.ndarray, np.ndarray, SearchStats]:
+def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds: int = 64, active0: Optional[np.ndarray] = None
+                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, SearchStats]:
     """Expand the search tree breadth-first until at least ``n_open`` open (branched, not yet propagated) nodes
-    exist; returns their folded (lb, ub, active) rows, at most ``n_open`` of them, in tree order."""
+    exist; returns their folded (lb, ub, active) rows, at most ``n_open`` of them, in tree order.  ``lb0/ub0`` may be
+    one root or a block of open nodes (with their ``active0`` rows) to continue from."""
     from .engine import full_active
     st = SearchStats()
-    L = np.ascontiguousarray(lb0, np.int32).reshape(1, -1)
-    U = np.ascontiguousarray(ub0, np.int32).reshape(1, -1)
-    A = full_active(1, ctx.n_units)
+    L = np.ascontiguousarray(lb0, np.int32)
+    L = L.reshape(1, -1) if L.ndim == 1 else L
+    U = np.ascontiguousarray(ub0, np.int32).reshape(L.shape)
+    A = full_active(L.shape[0], ctx.n_units) if active0 is None else np.ascontiguousarray(active0, np.uint64).reshape(L.shape[0], -1)
     for _ in range(max_rounds):
         if L.shape[0] >= n_open or L.shape[0] == 0:
             break

@@ -11,7 +11,7 @@ from oracle import oracle as orc
 from pcp_amd import model as M
 import pcp_amd.engine as E
 
-from util import assert_parity, random_active, random_csp, random_nodes
+from util import assert_parity, planted_binary_csp, random_active, random_csp, random_nodes, unit_narrowing_prefix
 from test_oracle_golden import build_unit
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +30,7 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     om = orc.OracleModel(n_vars, props)
     ref = om.consistency(lb, ub, active)
     ctx.set_model(n_vars, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
         ctx.set_option(k, v)
     got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
     assert_parity(ref[:4], got[:4], what)
@@ -96,6 +96,7 @@ def test_random_csp_mixed_statuses(ctx, seed):
 @pytest.mark.parametrize("opts", [
     {"nodes_per_block": 1}, {"nodes_per_block": 3}, {"nodes_per_block": 32}, {"block_threads": 256}, {"block_threads": 512},
     {"list_cap": 64}, {"force_path": 2, "team": 2}, {"force_path": 2, "team": 7}, {"force_path": 2, "team": 64},
+    {"global_dom": 1}, {"global_dom": 1, "list_cap": 64}, {"global_dom": 1, "force_path": 2, "team": 5},
 ])
 def test_random_csp_launch_shapes(ctx, opts):
     """Same answers whatever the launch geometry: tile size, block size, dense-round fallback, team size."""
@@ -131,7 +132,7 @@ def test_nqueens_dfs_nodes(ctx, n):
     ref = (rec["lb_out"][keep], rec["ub_out"][keep], rec["active_out"][keep], rec["status"][keep])
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 5}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(rec["lb_in"][keep], rec["ub_in"][keep], rec["active_in"][keep])
         assert_parity(ref, got[:4], f"nqueens({n}) {opts}")
@@ -154,7 +155,7 @@ def test_nqueens_1000_root_and_dive(ctx):
     ref = om.consistency(L, U, None, check_dup=False)
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 2}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(N, om.n_units))
         assert_parity(ref[:4], got[:4], f"nqueens1000 {opts}")
@@ -178,7 +179,7 @@ def test_golomb_distinct_sum_network(ctx):
     assert (ref[3] == 0).any() and (ref[3] == 2).any()
     ctx.set_model(V, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 2}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, A)
         assert_parity(ref[:4], got[:4], f"golomb {opts}")
@@ -195,10 +196,27 @@ def test_nqueens_global_distinct_search(ctx, n):
     lb0, ub0 = vs.bounds()
     ss, _, _, _ = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0}.items():
         ctx.set_option(k, v)
     st = S.dfs(ctx, lb0, ub0, all_solutions=True, batch=32)
     assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
+
+
+def test_config3_random_binary_csp_full_size(ctx):
+    """BASELINE config 3 at full size: 50 000 Interval<i32> variables (400 KB of bounds per node: more than LDS, so
+    the HBM-resident-domain variant runs), 500 000 `x ◇ y + c` constraints, planted solution, long cascades."""
+    V, P = 50_000, 500_000
+    props, lb, ub, sol = planted_binary_csp(0xC3, V, P)
+    L, U = unit_narrowing_prefix(0xC3 + 1, lb, ub, sol, 4)
+    om = orc.OracleModel(V, props)
+    ref = om.consistency(L, U, None)
+    assert (ref[3] == 2).all() and ((ref[0] != L) | (ref[1] != U)).sum() > V
+    ctx.set_model(V, props)
+    for opts in ({}, {"force_path": 2, "team": 16}):
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(L, U, E.full_active(4, P))
+        assert_parity(ref[:4], got[:4], f"config3 {opts}")
 
 
 def test_contract_errors(ctx):
