@@ -50,6 +50,21 @@ def cpu_baseline(n, props, lb, ub, act, budget_s):
     }
 
 
+def profiled_traffic(n, nodes):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes (profiles/*traffic.json,
+    written by tools/profile_bench.sh + tools/traffic_json.py for exactly this workload), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("n") == n and d.get("nodes_per_launch") == nodes:
+            best = d
+    return best
+
+
 def _cpu_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -89,7 +104,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as g
-    g.build()
+    if rank == 0:
+        g.build()  # a no-op when the prebuilt libraries match the sources (content hash)
+    if world > 1:
+        dist.barrier()
     import pcp_amd.engine as E
     from pcp_amd import model as M
     from pcp_amd import search as S
@@ -163,6 +181,7 @@ def main():
     status = t_status.cpu().numpy()
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
+        tr = profiled_traffic(n, args.nodes)
         alg_bytes = BYTES_BINARY * per_step["steps"] + BYTES_TERNARY * per_step["steps3"] + BYTES_NARROWING * per_step["narrowings"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
@@ -190,7 +209,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": (tr or {}).get("traffic_bytes"),
+                "traffic_source": (tr or {}).get("source"),
                 "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "algorithmic bytes = 28 B per binary filter step + 8 B per narrowing (SURVEY.md §8d); domains live in LDS and the "

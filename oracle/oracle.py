@@ -40,14 +40,26 @@ class OraclePanic(Exception):
     """The reference would have panicked (assert!) on this input."""
 
 
+def _src_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pcp_oracle.hpp", "pcp_oracle_capi.cpp", "../include/pcp_hip.h"):
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(fh.read() + b"\0")
+    return h.hexdigest()
+
+
 def build(force: bool = False) -> str:
-    """Compile the oracle with g++ (oracle/Makefile)."""
-    src_newer = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("pcp_oracle.hpp", "pcp_oracle_capi.cpp")
-    )
-    if force or src_newer:
-        subprocess.run(["make", "-C", _HERE, "libpcp_oracle.so"], check=True, capture_output=True)
+    """Compile the oracle with g++ (oracle/Makefile) when it is missing or its sources changed (content hash)."""
+    tag = _LIB_PATH + ".srchash"
+    try:
+        fresh = os.path.exists(_LIB_PATH) and open(tag).read().strip() == _src_hash()
+    except OSError:
+        fresh = False
+    if force or not fresh:
+        subprocess.run(["make", "-B", "-C", _HERE, "libpcp_oracle.so"], check=True, capture_output=True)
+        with open(tag, "w") as f:
+            f.write(_src_hash())
     return _LIB_PATH
 
 
