@@ -349,10 +349,11 @@ __device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const 
 // then two or three compares per node and scalar mask logic.  (word,node) pairs with a flagged live lane are
 // returned in the bitmask for the full filter.
 template <int KIND, int B>
-__device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, const int d, const uint64_t my_word) {
+__device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, const int d, const uint64_t live4, const uint32_t j) {
+  // live4: lane b*kChunk + j holds word j of node b (see sweep_fast)
   uint32_t todo = 0;
   if (B == 1) {
-    const uint64_t word = readlane64(my_word, 0);
+    const uint64_t word = readlane64(live4, j);
     if (word) {
       const int2 X = px[0], Y = py[0];
       if (fast_flag<KIND>(X, Y.x + d, Y.y + d) & word) todo = 1;
@@ -365,20 +366,20 @@ __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, c
     uint64_t wd[G];
     uint64_t any = 0;
 #pragma unroll
-    for (int j = 0; j < G; ++j) { wd[j] = readlane64(my_word, g + j); any |= wd[j]; }
+    for (int jj = 0; jj < G; ++jj) { wd[jj] = readlane64(live4, (uint32_t)(g + jj) * 4u + j); any |= wd[jj]; }
     if (any == 0) continue;
     int4 Xp[G / 2], Yp[G / 2];
 #pragma unroll
-    for (int j = 0; j < G / 2; ++j) {
-      Xp[j] = *reinterpret_cast<const int4*>(px + g + 2 * j);
-      Yp[j] = *reinterpret_cast<const int4*>(py + g + 2 * j);
+    for (int jj = 0; jj < G / 2; ++jj) {
+      Xp[jj] = *reinterpret_cast<const int4*>(px + g + 2 * jj);
+      Yp[jj] = *reinterpret_cast<const int4*>(py + g + 2 * jj);
     }
 #pragma unroll
-    for (int j = 0; j < G / 2; ++j) {
-      const uint64_t f0 = fast_flag<KIND>(make_int2(Xp[j].x, Xp[j].y), Yp[j].x + d, Yp[j].y + d) & wd[2 * j];
-      const uint64_t f1 = fast_flag<KIND>(make_int2(Xp[j].z, Xp[j].w), Yp[j].z + d, Yp[j].w + d) & wd[2 * j + 1];
-      todo |= f0 ? (1u << (g + 2 * j)) : 0u;
-      todo |= f1 ? (1u << (g + 2 * j + 1)) : 0u;
+    for (int jj = 0; jj < G / 2; ++jj) {
+      const uint64_t f0 = fast_flag<KIND>(make_int2(Xp[jj].x, Xp[jj].y), Yp[jj].x + d, Yp[jj].y + d) & wd[2 * jj];
+      const uint64_t f1 = fast_flag<KIND>(make_int2(Xp[jj].z, Xp[jj].w), Yp[jj].z + d, Yp[jj].w + d) & wd[2 * jj + 1];
+      todo |= f0 ? (1u << (g + 2 * jj)) : 0u;
+      todo |= f1 ? (1u << (g + 2 * jj + 1)) : 0u;
     }
   }
   return __builtin_amdgcn_readfirstlane(todo);
@@ -446,96 +447,123 @@ __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
 // LDS atomics.  The fast predicates restate exactly the no-op conditions of XNeqY/XLessY/XEqY::propagate and
 // the True case of their is_subsumed (files cited in eval_record).
 // ------------------------------------------------------------------------------------------------
+// Each wavefront owns CHUNK consecutive 64-record words at a time.  For the live-mask I/O the lanes are laid out as
+// lane = node*CHUNK + j: one 8-byte load (and one store) per lane moves the CHUNK words of every node of the tile —
+// 32 contiguous bytes per node instead of a lone 8-byte access per (word,node), which the memory side turns into a
+// 32-byte transaction each (measured: WRITE_SIZE 3.4x the bytes stored).  Word j of node b is then lane b*CHUNK+j.
+constexpr int kChunk = 4;
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+  return ((uint64_t)hi << 32) | lo;
+}
+
 template <int B, bool GLOBAL>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
-                                           uint32_t* chg_next, uint32_t& rem_acc, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+                                           uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+  static_assert(B * kChunk <= 64, "node*CHUNK+j must fit in the 64 lanes");
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
   const uint64_t* live_src = a.live_in;
-  uint32_t steps_lane = 0;
-  // Software prefetch: the records and live words of the NEXT 64-record word are requested before the current
-  // one is processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
-  const uint32_t my_node = node0 + (lane < nb ? lane : 0);
+  const uint32_t bq = lane / kChunk, jq = lane % kChunk;  // this lane's (node, word-in-chunk) for the live-mask I/O
+  const bool io = bq < nb;
+  const uint32_t my_node = node0 + (io ? bq : 0);
   const uint64_t* my_in = live_src ? live_src + (size_t)my_node * words : nullptr;
   uint64_t* my_out = a.live + (size_t)my_node * words;
   const Rec* my_rec = a.m.recs + lane;
-  auto fetch = [&](uint32_t w, Rec& rec, uint64_t& word) {
+  const uint32_t c0 = w0 / kChunk, c1 = (w1 + kChunk - 1) / kChunk;  // w0 is a multiple of kChunk
+  // Software prefetch: the live words of the NEXT chunk and the records of the NEXT word are requested before the
+  // current ones are processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
+  auto fetch_live = [&](uint32_t c) -> uint64_t {
+    const uint32_t w = c * kChunk + jq;
+    uint64_t v = 0;
+    if (c < c1 && io && w < w1) {
+      v = my_in ? my_in[w] : ~0ull;
+      if (w == words - 1) v &= tail_mask;
+    }
+    return v;
+  };
+  auto fetch_rec = [&](uint32_t w, Rec& rec) {
     if (w < w1 && (w << 6) + lane < P) rec = my_rec[(size_t)w << 6];
     else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
-    word = 0;
-    if (w < w1 && lane < nb) {
-      word = my_in ? my_in[w] : ~0ull;
-      if (w == words - 1) word &= tail_mask;
-    }
   };
+  uint32_t steps_lane = 0, rem_acc = 0;
+  uint64_t live_n = fetch_live(c0 + wave);
   Rec rec_n;
-  uint64_t word_n;
-  fetch(w0 + wave, rec_n, word_n);
-  for (uint32_t w = w0 + wave; w < w1; w += nw) {
-    const Rec rec = rec_n;
-    const uint64_t my_word = word_n;
-    fetch(w + nw, rec_n, word_n);
-    uint64_t my_new = my_word;
-    const uint32_t kind = rec.xk >> 28;
-    const uint32_t x = rec.xk & kSlotMask, y = rec.y;
-    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
-    uint32_t todo;  // nodes to run with the full filter
-    if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
-      const int2* px = k.dom + slot_row<B>(x);
-      const int2* py = k.dom + slot_row<B>(y);
-      todo = 0;
-      if (__ballot(my_word != 0)) {  // some record of this word is live in some node
-        if (kind0 == PCP_EQ) {
-          todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, my_word);
-        } else {
-          // level 1: one sign word per lane for the whole tile; level 2 (per node, with liveness) only if a record
-          // that is live somewhere in the tile is flagged.
-          const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
-          static_assert(B <= 16, "the tile's live words must sit in one 16-lane DPP row");
-          const uint64_t flagged = __ballot(o < 0);
-          if (flagged) {
-            // records live in at least one node of the tile (OR of the tile's live words over the DPP row)
-            const uint64_t alive = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(my_word >> 32))) << 32) |
-                                   __builtin_amdgcn_readfirstlane(row_or16((uint32_t)my_word));
-            if (flagged & alive) {
-              if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, my_word);
-              else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, my_word);
+  fetch_rec((c0 + wave) * kChunk, rec_n);
+  for (uint32_t c = c0 + wave; c < c1; c += nw) {
+    const uint64_t loaded = live_n;
+    live_n = fetch_live(c + nw);
+    uint64_t my_new = loaded;
+#pragma unroll 1
+    for (uint32_t j = 0; j < (uint32_t)kChunk; ++j) {
+      const uint32_t w = c * kChunk + j;
+      if (w >= w1) break;
+      const Rec rec = rec_n;
+      fetch_rec((j + 1 < (uint32_t)kChunk && w + 1 < w1) ? w + 1 : (c + nw) * kChunk, rec_n);
+      const uint64_t jmask = 0x1111111111111111ull << j;  // the lanes holding word j of each node
+      const uint32_t kind = rec.xk >> 28;
+      const uint32_t x = rec.xk & kSlotMask, y = rec.y;
+      const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+      uint32_t todo;  // nodes to run with the full filter
+      if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+        const int2* px = k.dom + slot_row<B>(x);
+        const int2* py = k.dom + slot_row<B>(y);
+        todo = 0;
+        if (__ballot(loaded != 0) & jmask) {  // some record of this word is live in some node
+          if (kind0 == PCP_EQ) {
+            todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, loaded, j);
+          } else {
+            // level 1: one sign word per lane for the whole tile; level 2 (per node, with liveness) only if a record
+            // that is live somewhere in the tile is flagged.
+            const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+            const uint64_t flagged = __ballot(o < 0);
+            if (flagged) {
+              const uint64_t alive = wave_or64(jq == j ? loaded : 0ull);  // records live in at least one node of the tile
+              if (flagged & alive) {
+                if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
+                else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
+              }
             }
           }
         }
+        if (jq == j) steps_lane += __popcll(loaded);  // every live record of every node runs once
+      } else {
+        // mixed kinds / ternary / a failed node in the tile / HBM-resident domains: everything through the full filter
+        const bool tern = kind > PCP_LT;
+        todo = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+          const uint64_t word = readlane64(loaded, b * kChunk + j);
+          if (word == 0 || ((failm >> b) & 1u)) continue;
+          todo |= 1u << b;
+          const uint64_t t3 = __ballot(((word >> lane) & 1ull) && tern);
+          steps3 += __popcll(t3);
+          steps2 += __popcll(word) - __popcll(t3);
+        }
       }
-      steps_lane += __popcll(my_word);  // lane b holds node b's word: every live record of every node runs once
-    } else {
-      // mixed kinds / ternary / a failed node in the tile: everything through the full filter
-      const bool tern = kind > PCP_LT;
-      todo = 0;
-      for (uint32_t b = 0; b < nb; ++b) {
-        const uint64_t word = readlane64(my_word, b);
-        if (word == 0 || ((failm >> b) & 1u)) continue;
-        todo |= 1u << b;
-        const uint64_t t3 = __ballot(((word >> lane) & 1ull) && tern);
-        steps3 += __popcll(t3);
-        steps2 += __popcll(word) - __popcll(t3);
+      while (todo) {
+        const uint32_t b = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const uint64_t word = readlane64(loaded, b * kChunk + j);
+        bool e = false;
+        if ((word >> lane) & 1ull) {
+          const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
+          e = eval_record(rec, dm);
+        }
+        my_new = writelane64(my_new, word & ~__ballot(e), b * kChunk + j);
       }
     }
-    while (todo) {
-      const uint32_t b = __builtin_ctz(todo);
-      todo &= todo - 1;
-      const uint64_t word = readlane64(my_word, b);
-      bool e = false;
-      if ((word >> lane) & 1ull) {
-        const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
-        e = eval_record(rec, dm);
-      }
-      my_new = writelane64(my_new, word & ~__ballot(e), b);
-    }
-    if (lane < nb) {
+    const uint32_t wl = c * kChunk + jq;
+    if (io && wl < w1) {
       rem_acc += __popcll(my_new);
-      if (live_src != a.live || my_new != my_word) my_out[w] = my_new;
+      if (live_src != a.live || my_new != loaded) my_out[wl] = my_new;
     }
   }
+  if (io && rem_acc) atomicAdd(&remaining[bq], rem_acc);
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
 }
@@ -639,17 +667,17 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   __syncthreads();
 
   Ctr ctr;
-  uint32_t rem_acc = 0;
   uint64_t steps2 = 0, steps3 = 0;
 
   // ---- phase 1: wave 0 = every live propagator once (a slice of the table when team > 1) -----------------
   {
     uint32_t w0 = 0, w1 = words;
-    if (team > 1) { const uint32_t ws = (words + team - 1) / team; w0 = min(words, g * ws); w1 = min(words, w0 + ws); }
+    if (team > 1) {  // slices are whole chunks
+      const uint32_t ws = (((words + team - 1) / team) + kChunk - 1) / kChunk * kChunk;
+      w0 = min(words, g * ws); w1 = min(words, w0 + ws);
+    }
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
-    sweep_fast<B, GLOBAL>(a, k, w0, w1, node0, nb, cur, rem_acc, steps2, steps3, ctr);
-    if (lane < nb && rem_acc) atomicAdd(&remaining[lane], rem_acc);
-    rem_acc = 0;
+    if (w0 < w1) sweep_fast<B, GLOBAL>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
