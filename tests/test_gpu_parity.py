@@ -219,6 +219,32 @@ def test_config3_random_binary_csp_full_size(ctx):
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
 
 
+def test_cpp_host_mirror_nqueens():
+    """The C++ host side (pcp_amd/host/pcp_host.hpp) running the reference's n-queens example code
+    (example/src/nqueens.rs:28-74) with every node's fixpoint on the GPU: same first solution, same node and failure
+    counts as the oracle's DFS, same all-solution counts as the reference's test table (all_solution.rs:70)."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(g.ROOT, "pcp_amd", "host", "examples", "nqueens")
+    for n in (1, 2, 3, 4, 6, 8, 10):
+        props = M.nqueens_props(n) if n > 1 else M.lower_units([], 1)
+        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+        out = json.loads(subprocess.run([exe, str(n)], check=True, capture_output=True, text=True).stdout)
+        ss, _, _, sol = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=False)
+        assert out["nodes"] == ss["num_nodes"] and out["failed"] == ss["num_failed_node"] and out["solutions"] == ss["num_solution"], (n, out, ss)
+        assert out["status"] == ("Satisfiable" if ss["num_solution"] else "Unsatisfiable")
+        if ss["num_solution"]:
+            assert out["first"] == [int(v) for v in sol]
+    counts = [1, 0, 0, 2, 10, 4, 40, 92]
+    for n in (4, 6, 8):
+        out = json.loads(subprocess.run([exe, str(n), "all"], check=True, capture_output=True, text=True).stdout)
+        ss, _, _, _ = orc.OracleModel(n, M.nqueens_props(n)).search(np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True)
+        assert out["solutions"] == counts[n - 1] and out["nodes"] == ss["num_nodes"] and out["failed"] == ss["num_failed_node"]
+    out = json.loads(subprocess.run([exe, "6", "all", "10"], check=True, capture_output=True, text=True).stdout)
+    assert out["nodes"] == 10 and out["status"] == "EndOfSearch"  # search/stop_node.rs:82-104
+
+
 def test_contract_errors(ctx):
     ctx.set_model(2, M.lower_units([M.XLessY(M.Identity(0), M.Identity(1))], 2))
     with pytest.raises(E.PcpError) as e:
