@@ -385,16 +385,11 @@ __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, c
   return __builtin_amdgcn_readfirstlane(todo);
 }
 
-// slot * BP (BP = B + 2) as shifts and adds: a 32-bit integer multiply is a quarter-rate VALU op on gfx950.
+// slot * BP (BP = B + 2) with the full-rate 24-bit multiply (slots < 2^26 / B fit): a 32-bit v_mul_lo_u32 is a
+// quarter-rate VALU op on gfx950, and hipcc folds shift-add sequences back into it.
 template <int B>
 __device__ __forceinline__ uint32_t slot_row(uint32_t v) {
-  if (B == 1) return v;
-  if (B == 2) return v << 2;
-  if (B == 4) return (v << 2) + (v << 1);
-  if (B == 8) return (v << 3) + (v << 1);
-  if (B == 12) return (v << 4) - (v << 1);
-  if (B == 16) return (v << 4) + (v << 1);
-  return v * (uint32_t)(B + 2);
+  return B == 1 ? v : __umul24(v, (uint32_t)(B + 2));
 }
 
 // First-level test of the fast path: ONE sign word per lane for ALL the nodes of the tile, liveness ignored.
@@ -473,41 +468,40 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   const uint32_t my_node = node0 + (io ? bq : 0);
   const uint64_t* my_in = live_src ? live_src + (size_t)my_node * words : nullptr;
   uint64_t* my_out = a.live + (size_t)my_node * words;
-  const Rec* my_rec = a.m.recs + lane;
   const uint32_t c0 = w0 / kChunk, c1 = (w1 + kChunk - 1) / kChunk;  // w0 is a multiple of kChunk
   // Software prefetch: the live words of the NEXT chunk and the records of the NEXT word are requested before the
   // current ones are processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
+  // All stream loads are UNCONDITIONAL (indices clamped into the buffers, validity applied afterwards): hipcc can then
+  // count them and wait with vmcnt(N>0) for the older load while the prefetch stays in flight; a load under a
+  // divergent guard makes it fall back to vmcnt(0), i.e. wait for the prefetch it has just issued.
+  const uint32_t last_word = words - 1;
   auto fetch_live = [&](uint32_t c) -> uint64_t {
     const uint32_t w = c * kChunk + jq;
-    uint64_t v = 0;
-    if (c < c1 && io && w < w1) {
-      v = my_in ? my_in[w] : ~0ull;
-      if (w == words - 1) v &= tail_mask;
-    }
-    return v;
+    const uint64_t v = my_in ? my_in[min(w, last_word)] : ~0ull;
+    const bool ok = c < c1 && io && w < w1;
+    return ok ? (w == last_word ? v & tail_mask : v) : 0ull;
   };
-  auto fetch_rec = [&](uint32_t w, Rec& rec) {
-    if (w < w1 && (w << 6) + lane < P) rec = my_rec[(size_t)w << 6];
-    else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
+  auto fetch_rec = [&](uint32_t w) -> Rec {  // lanes past the last record read the last record; their live bit is 0
+    const uint32_t r = min((min(w, last_word) << 6) + lane, P - 1);
+    return a.m.recs[r];
   };
   uint32_t steps_lane = 0, rem_acc = 0;
   uint64_t live_n = fetch_live(c0 + wave);
-  Rec rec_n;
-  fetch_rec((c0 + wave) * kChunk, rec_n);
+  Rec rec_n = fetch_rec((c0 + wave) * kChunk);
   for (uint32_t c = c0 + wave; c < c1; c += nw) {
     const uint64_t loaded = live_n;
     live_n = fetch_live(c + nw);
     uint64_t my_new = loaded;
+    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll 1
     for (uint32_t j = 0; j < (uint32_t)kChunk; ++j) {
       const uint32_t w = c * kChunk + j;
-      if (w >= w1) break;
       const Rec rec = rec_n;
-      fetch_rec((j + 1 < (uint32_t)kChunk && w + 1 < w1) ? w + 1 : (c + nw) * kChunk, rec_n);
+      rec_n = fetch_rec((j + 1 < (uint32_t)kChunk) ? w + 1 : (c + nw) * kChunk);
+      if (w >= w1) continue;
       const uint64_t jmask = 0x1111111111111111ull << j;  // the lanes holding word j of each node
       const uint32_t kind = rec.xk >> 28;
       const uint32_t x = rec.xk & kSlotMask, y = rec.y;
-      const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
       uint32_t todo;  // nodes to run with the full filter
       if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
