@@ -39,35 +39,37 @@ struct Ctr {  // per-thread counters, reduced once per block
 // Domain access policy: node-local (lb,ub) pairs in LDS.
 // ------------------------------------------------------------------------------------------------
 struct LdsDom {
-  int2* dom;        // &dom[0*BP + b]: this node's column of the [slot][BP] array
+  int2* dom;        // &dom[0*BP + b]: this node's column of the [slot][BP] array; element = (-lb, ub)
   uint32_t bp;      // row stride in int2 (nodes per block + padding)
   uint32_t* chg;    // next-wave changed bitmask of this node [ceil(n_slots/32)]
   uint32_t* fail;   // block fail mask
   uint32_t fbit;    // this node's bit in *fail
   Ctr* c;
 
-  __device__ __forceinline__ int2 load(uint32_t v) const { return dom[(size_t)v * bp]; }
+  // LDS holds (-lb, ub): both narrowings are ds_min, and the sweep's no-op test becomes one v_add3_u32 per bound
+  // (see fast_signs).  Bounds are below 2^29 in magnitude, so the negation cannot overflow.
+  __device__ __forceinline__ int2 load(uint32_t v) const { const int2 d = dom[(size_t)v * bp]; return make_int2(-d.x, d.y); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
   // lb := max(lb, nlb).  Called only when nlb exceeds the lb this thread read.
   __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
     int2* p = dom + (size_t)v * bp;
-    int old = atomicMax(&p->x, nlb);
-    if (old < nlb) {
+    const int old = atomicMin(&p->x, -nlb);
+    if (old > -nlb) {
       ++c->narrow;
       mark(v);
-      int ub = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int ub = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (nlb > ub) set_fail();
     }
   }
   __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
     int2* p = dom + (size_t)v * bp;
-    int old = atomicMin(&p->y, nub);
+    const int old = atomicMin(&p->y, nub);
     if (old > nub) {
       ++c->narrow;
       mark(v);
-      int lb = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (lb > nub) set_fail();
+      const int nlb = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (-nlb > nub) set_fail();
     }
   }
 };
@@ -355,8 +357,8 @@ __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, c
   if (B == 1) {
     const uint64_t word = readlane64(live4, j);
     if (word) {
-      const int2 X = px[0], Y = py[0];
-      if (fast_flag<KIND>(X, Y.x + d, Y.y + d) & word) todo = 1;
+      const int2 X = px[0], Y = py[0];  // stored as (-lb, ub)
+      if (fast_flag<KIND>(make_int2(-X.x, X.y), d - Y.x, Y.y + d) & word) todo = 1;
     }
     return todo;
   }
@@ -376,8 +378,9 @@ __device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, c
     }
 #pragma unroll
     for (int jj = 0; jj < G / 2; ++jj) {
-      const uint64_t f0 = fast_flag<KIND>(make_int2(Xp[jj].x, Xp[jj].y), Yp[jj].x + d, Yp[jj].y + d) & wd[2 * jj];
-      const uint64_t f1 = fast_flag<KIND>(make_int2(Xp[jj].z, Xp[jj].w), Yp[jj].z + d, Yp[jj].w + d) & wd[2 * jj + 1];
+      // LDS holds (-lb, ub)
+      const uint64_t f0 = fast_flag<KIND>(make_int2(-Xp[jj].x, Xp[jj].y), d - Yp[jj].x, Yp[jj].y + d) & wd[2 * jj];
+      const uint64_t f1 = fast_flag<KIND>(make_int2(-Xp[jj].z, Xp[jj].w), d - Yp[jj].z, Yp[jj].w + d) & wd[2 * jj + 1];
       todo |= f0 ? (1u << (g + 2 * jj)) : 0u;
       todo |= f1 ? (1u << (g + 2 * jj + 1)) : 0u;
     }
@@ -394,19 +397,21 @@ __device__ __forceinline__ uint32_t slot_row(uint32_t v) {
 
 // First-level test of the fast path: ONE sign word per lane for ALL the nodes of the tile, liveness ignored.
 // For each node the "nothing happens" condition of fast_flag is rewritten as a conjunction of non-negative
-// differences (every bound and offset is below 2^29 in magnitude, so three-term sums cannot wrap):
-//   NEQ:  X.x < Yu && Yl < X.y      <=>  (Y.y + (d-1)) - X.x >= 0  &&  (X.y + (-d-1)) - Y.x >= 0
-//   LT :  X.y < Yu && Yl > X.x && X.y >= Yl
-//                                    <=>  (Y.y + (d-1)) - X.y >= 0  &&  (Y.x + (d-1)) - X.x >= 0  &&  (X.y - d) - Y.x >= 0
-// and the differences of all nodes are OR-ed together: the sign bit of the result is clear iff nothing happens on
-// this lane's record in ANY node.  No scalar work, no cross-lane work: 4-6 VALU and half a ds_read_b128 per node.
+// differences (every bound and offset is below 2^29 in magnitude, so three-term sums cannot wrap).  LDS holds
+// (-lb, ub) per (slot,node) — write Xn = -X.lb, Xu = X.ub, Yn = -Y.lb, Yu = Y.ub:
+//   NEQ:  X.lb < Y.ub+d && Y.lb+d < X.ub   <=>  Yu + (d-1) + Xn >= 0   &&  Xu + (-d-1) + Yn >= 0      (two v_add3_u32)
+//   LT :  X.ub < Y.ub+d && Y.lb+d > X.lb && X.ub >= Y.lb+d
+//                                           <=>  (Yu - Xu) + (d-1) >= 0  &&  (Xn - Yn) + (d-1) >= 0  &&  Xu + (-d) + Yn >= 0
+// and the terms of all nodes are OR-ed together (v_or3_b32): the sign bit of the result is clear iff nothing happens
+// on this lane's record in ANY node.  No scalar work, no cross-lane work: 3 VALU (NEQ) and half a ds_read_b128 per
+// (record,node).
 template <int KIND, int B>
 __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const int d) {
-  const int c1 = d - 1, c2 = -d - 1;
+  const int c1 = d - 1, c2 = -d - 1, c3 = -d;
   int o = 0;
-  auto one = [&](int xl, int xu, int yl, int yu) {
-    if (KIND == PCP_NEQ) o |= ((yu + c1) - xl) | ((xu + c2) - yl);
-    else o |= ((yu + c1) - xu) | ((yl + c1) - xl) | ((xu - d) - yl);
+  auto one = [&](int xn, int xu, int yn, int yu) {
+    if (KIND == PCP_NEQ) o |= (yu + c1 + xn) | (xu + c2 + yn);
+    else o |= ((yu - xu) + c1) | ((xn - yn) + c1) | (xu + c3 + yn);
   };
   if (B == 1) {
     const int2 X = px[0], Y = py[0];
@@ -653,6 +658,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         int2 d;
         if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
         else { d.x = d.y = a.m.const_val[v - V]; }
+        d.x = -d.x;                   // LDS holds (-lb, ub)
         dom[(size_t)v * BP + b] = d;  // missing nodes of a tail tile mirror node 0: readable, never used
       }
       if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
@@ -689,7 +695,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       while (!GLOBAL && bits) {
         const uint32_t v = (w << 5) + __builtin_ctz(bits);
         bits &= bits - 1;
-        if (v < V) { atomicMax(&glb[v], dom[(size_t)v * BP].x); atomicMin(&gub[v], dom[(size_t)v * BP].y); }
+        if (v < V) { atomicMax(&glb[v], -dom[(size_t)v * BP].x); atomicMin(&gub[v], dom[(size_t)v * BP].y); }
       }
     }
     // counters: wave -> LDS -> ONE global atomic per block and counter (same-address device atomics serialise
@@ -727,7 +733,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     // tail block: reload the merged state
     for (uint32_t v = tid; !GLOBAL && v < V; v += nth) {
       int2 d;
-      d.x = __hip_atomic_load(&glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      d.x = -__hip_atomic_load(&glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       d.y = __hip_atomic_load(&gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       dom[(size_t)v * BP] = d;
     }
@@ -844,9 +850,9 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
       bool bad = false;
       for (uint32_t v = tid; v < S; v += nth) {
-        const int2 d = dom[(size_t)v * BP + b];
-        bad |= d.x > d.y;
-        if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
+        const int2 d = dom[(size_t)v * BP + b];  // (-lb, ub)
+        bad |= -d.x > d.y;
+        if (v < V) { lbp[v] = -d.x; ubp[v] = d.y; }
       }
       if (bad) atomicOr(&misc[M_FAIL], 1u << b);
     }
