@@ -226,7 +226,8 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
 // `tmp` has >= 33 words.  Returns the exclusive prefix; *total_out (LDS) holds the grand total after return.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* tmp, uint32_t* total_out) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   uint32_t inc = v;
 #pragma unroll
   for (int o = 1; o < kWave; o <<= 1) {
@@ -464,7 +465,9 @@ template <int B, bool GLOBAL>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   static_assert(B * kChunk <= 64, "node*CHUNK+j must fit in the 64 lanes");
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  static_assert(kChunk == 4, "the hot loop is written for four record buffers");
+  const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
   const uint64_t* live_src = a.live_in;
@@ -474,11 +477,12 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   const uint64_t* my_in = live_src ? live_src + (size_t)my_node * words : nullptr;
   uint64_t* my_out = a.live + (size_t)my_node * words;
   const uint32_t c0 = w0 / kChunk, c1 = (w1 + kChunk - 1) / kChunk;  // w0 is a multiple of kChunk
-  // Software prefetch: the live words of the NEXT chunk and the records of the NEXT word are requested before the
-  // current ones are processed, so the HBM/L2 latency of the stream overlaps the LDS work instead of preceding it.
-  // All stream loads are UNCONDITIONAL (indices clamped into the buffers, validity applied afterwards): hipcc can then
-  // count them and wait with vmcnt(N>0) for the older load while the prefetch stays in flight; a load under a
-  // divergent guard makes it fall back to vmcnt(0), i.e. wait for the prefetch it has just issued.
+  // The stream is latency-bound, not bandwidth-bound: with one 1-KiB record load in flight per wavefront a CU moves
+  // 16 KiB per memory round trip (measured: the loop skeleton alone took 73 % of the kernel).  So every wavefront
+  // keeps FOUR record loads (one whole chunk ahead) plus the next chunk's live words in flight.  All stream loads
+  // are UNCONDITIONAL (indices clamped into the buffers, validity applied afterwards) and sit in straight-line code:
+  // hipcc can then count them and wait with vmcnt(N>0) for the oldest load while the younger ones stay in flight; a
+  // load under a divergent guard makes it fall back to vmcnt(0).
   const uint32_t last_word = words - 1;
   auto fetch_live = [&](uint32_t c) -> uint64_t {
     const uint32_t w = c * kChunk + jq;
@@ -492,49 +496,68 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   };
   uint32_t steps_lane = 0, rem_acc = 0;
   uint64_t live_n = fetch_live(c0 + wave);
-  Rec rec_n = fetch_rec((c0 + wave) * kChunk);
+  Rec buf[kChunk];
+#pragma unroll
+  for (int j = 0; j < kChunk; ++j) buf[j] = fetch_rec((c0 + wave) * kChunk + j);
   for (uint32_t c = c0 + wave; c < c1; c += nw) {
     const uint64_t loaded = live_n;
     live_n = fetch_live(c + nw);
     uint64_t my_new = loaded;
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll 1
-    for (uint32_t j = 0; j < (uint32_t)kChunk; ++j) {
+    const uint64_t nz = __ballot(loaded != 0);
+    // ---- hot part, unrolled: level-1 test of the four words; anything else is only noted in `slow` --------------
+    uint32_t slow = 0;
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) {
+      const Rec rec = buf[j];
+      buf[j] = fetch_rec((c + nw) * kChunk + j);
       const uint32_t w = c * kChunk + j;
-      const Rec rec = rec_n;
-      rec_n = fetch_rec((j + 1 < (uint32_t)kChunk) ? w + 1 : (c + nw) * kChunk);
-      if (w >= w1) continue;
-      const uint64_t jmask = 0x1111111111111111ull << j;  // the lanes holding word j of each node
-      const uint32_t kind = rec.xk >> 28;
-      const uint32_t x = rec.xk & kSlotMask, y = rec.y;
-      const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
-      uint32_t todo;  // nodes to run with the full filter
-      if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
-        const int2* px = k.dom + slot_row<B>(x);
-        const int2* py = k.dom + slot_row<B>(y);
-        todo = 0;
-        if (__ballot(loaded != 0) & jmask) {  // some record of this word is live in some node
-          if (kind0 == PCP_EQ) {
-            todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, loaded, j);
-          } else {
-            // level 1: one sign word per lane for the whole tile; level 2 (per node, with liveness) only if a record
-            // that is live somewhere in the tile is flagged.
-            const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
-            const uint64_t flagged = __ballot(o < 0);
-            if (flagged) {
-              const uint64_t alive = wave_or64(jq == j ? loaded : 0ull);  // records live in at least one node of the tile
-              if (flagged & alive) {
-                if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
-                else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
-              }
+      if (w < w1) {
+        const uint32_t kind = rec.xk >> 28;
+        const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+        if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+          if (nz & (0x1111111111111111ull << j)) {  // some record of this word is live in some node
+            if (kind0 == PCP_EQ) {
+              slow |= 1u << j;
+            } else {
+              const int2* px = k.dom + slot_row<B>(rec.xk & kSlotMask);
+              const int2* py = k.dom + slot_row<B>(rec.y);
+              const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+              if (__ballot(o < 0)) slow |= 1u << j;
             }
           }
+          if (jq == (uint32_t)j) steps_lane += __popcll(loaded);  // every live record of every node runs once
+        } else {
+          slow |= 16u << j;  // mixed kinds / ternary / a failed node in the tile / HBM-resident domains
         }
-        if (jq == j) steps_lane += __popcll(loaded);  // every live record of every node runs once
+      }
+    }
+    // ---- cold part, one rolled copy: flagged words (level 2 + full filter) and words outside the fast path ---------
+    while (slow) {
+      const uint32_t jb = __builtin_ctz(slow);
+      slow &= slow - 1;
+      const uint32_t j = jb & 3u;
+      const bool generic = jb >= 4;
+      const uint32_t w = c * kChunk + j;
+      const Rec rec = fetch_rec(w);  // re-read (L1/L2 hit) instead of keeping four more records alive
+      const uint32_t kind = rec.xk >> 28;
+      uint32_t todo = 0;  // nodes to run with the full filter
+      if (!generic) {
+        const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+        const int2* px = k.dom + slot_row<B>(rec.xk & kSlotMask);
+        const int2* py = k.dom + slot_row<B>(rec.y);
+        if (kind0 == PCP_EQ) {
+          todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, loaded, j);
+        } else {
+          const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+          const uint64_t alive = wave_or64(jq == j ? loaded : 0ull);  // records live in at least one node of the tile
+          if (__ballot(o < 0) & alive) {
+            if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
+            else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
+          }
+        }
       } else {
-        // mixed kinds / ternary / a failed node in the tile / HBM-resident domains: everything through the full filter
         const bool tern = kind > PCP_LT;
-        todo = 0;
         for (uint32_t b = 0; b < nb; ++b) {
           const uint64_t word = readlane64(loaded, b * kChunk + j);
           if (word == 0 || ((failm >> b) & 1u)) continue;
@@ -572,7 +595,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 template <bool GLOBAL>
 __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, const uint32_t* cur,
                                                uint32_t* chg_next, uint32_t& rem_sub, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   for (uint32_t w = wave; w < words; w += nw) {
     const uint32_t r = (w << 6) + lane;
