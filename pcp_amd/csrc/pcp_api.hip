@@ -27,6 +27,7 @@ struct pcp_ctx {
 
   // device model
   Rec* d_recs = nullptr;
+  Rec8* d_recs8 = nullptr; size_t cap_recs8 = 0; bool compact = false;
   uint32_t* d_adj_off = nullptr;
   uint32_t* d_adj = nullptr;
   int32_t* d_const = nullptr;
@@ -170,6 +171,16 @@ int32_t finalize_model(pcp_ctx* c) {
   HIP_TRY(c, hipMemcpy(c->d_adj_off, adj_off.data(), adj_off.size() * 4, hipMemcpyHostToDevice));
   if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  c->compact = !tern && n_slots <= kCompactSlots && P > 0;
+  if (c->compact) {
+    std::vector<Rec8> r8(P);
+    for (size_t r = 0; r < P; ++r) {
+      r8[r].xyk = (recs[r].xk & kSlotMask) | (recs[r].y << 15) | ((recs[r].xk >> 28) << 30);
+      r8[r].d = recs[r].d;
+    }
+    if ((rc = ensure(c, c->d_recs8, c->cap_recs8, P))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_recs8, r8.data(), P * sizeof(Rec8), hipMemcpyHostToDevice));
+  }
   if (c->has_groups) {
     std::vector<uint32_t> first(c->n_units + 1, (uint32_t)P);
     for (size_t r = P; r-- > 0;) first[c->unit_of_prop[r]] = (uint32_t)r;
@@ -234,7 +245,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -392,7 +403,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
-  a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
+  a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;

@@ -25,8 +25,19 @@ static_assert(sizeof(Rec) == 16, "Rec must be 16 bytes");
 constexpr uint32_t kSlotMask = 0x0FFFFFFFu;
 constexpr uint32_t kMaxSlots = 1u << 26;  // (node, slot) pairs are packed into 32 bits in the kernels
 
+// Compact 8-byte form of a binary record, used for the sweep's stream when every record of the model is binary and
+// every slot index fits 15 bits (always true when the domains are LDS-resident with B > 1): the stream, which every
+// workgroup reads in full, is half as long.   x = slot_x | slot_y << 15 | kind << 30,   y = d.
+struct __attribute__((aligned(8))) Rec8 {
+  uint32_t xyk;
+  int32_t d;
+};
+static_assert(sizeof(Rec8) == 8, "Rec8 must be 8 bytes");
+constexpr uint32_t kCompactSlots = 1u << 15;
+
 struct ModelDev {
   const Rec* recs;          // [n_recs]
+  const Rec8* recs8;        // [n_recs] or null when the model is not compactable
   const uint32_t* adj_off;  // [n_vars + 1]  CSR var -> incident record ids (constants have no adjacency)
   const uint32_t* adj;      // [adj_off[n_vars]]
   const int32_t* const_val; // [n_slots - n_vars]

@@ -22,8 +22,15 @@
 // Integer bound work only: no MFMA.  All filters are monotone and contracting, so the wave schedule reaches
 // the same greatest fixpoint as the reference's FIFO (SURVEY.md §7 "chaotic-iteration equivalence").
 #include <algorithm>
+#include <type_traits>
 
 #include "pcp_internal.h"
+
+// PCP_ABLATE (profiling builds only, tools/ablate.sh; results are WRONG when non-zero): bit 0 = no LDS reads in the
+// level-1 test, bit 1 = no arithmetic in it, bit 2 = no record stream (one record reused), bit 3 = no live-word I/O.
+#ifndef PCP_ABLATE
+#define PCP_ABLATE 0
+#endif
 
 namespace pcp {
 
@@ -410,7 +417,17 @@ template <int KIND, int B>
 __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const int d) {
   const int c1 = d - 1, c2 = -d - 1, c3 = -d;
   int o = 0;
+  if (PCP_ABLATE & 1) {
+    const int f = (int)(size_t)px ^ (int)(size_t)py;
+#pragma unroll
+    for (int g = 0; g < B; ++g) {
+      if (PCP_ABLATE & 2) o |= f + g;
+      else o |= ((f + g) + c1 + (f - g)) | ((f ^ g) + c2 + (f + 2 * g));
+    }
+    return o & 0x7fffffff;
+  }
   auto one = [&](int xn, int xu, int yn, int yu) {
+    if (PCP_ABLATE & 2) { o |= (xn ^ yu) & (xu ^ yn) & 0x7fffffff; return; }
     if (KIND == PCP_NEQ) o |= (yu + c1 + xn) | (xu + c2 + yn);
     else o |= ((yu - xu) + c1) | ((xn - yn) + c1) | (xu + c3 + yn);
   };
@@ -461,7 +478,17 @@ __device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-template <int B, bool GLOBAL>
+__device__ __forceinline__ Rec expand(const Rec8 q) {
+  Rec r;
+  r.xk = (q.xyk & 0x7fffu) | ((q.xyk >> 30) << 28);
+  r.y = (q.xyk >> 15) & 0x7fffu;
+  r.z = 0;
+  r.d = q.d;
+  return r;
+}
+__device__ __forceinline__ Rec expand(const Rec r) { return r; }
+
+template <int B, bool GLOBAL, bool COMPACT>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   static_assert(B * kChunk <= 64, "node*CHUNK+j must fit in the 64 lanes");
@@ -486,17 +513,20 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   const uint32_t last_word = words - 1;
   auto fetch_live = [&](uint32_t c) -> uint64_t {
     const uint32_t w = c * kChunk + jq;
-    const uint64_t v = my_in ? my_in[min(w, last_word)] : ~0ull;
+    const uint64_t v = (my_in && !(PCP_ABLATE & 8)) ? my_in[min(w, last_word)] : ~0ull;
     const bool ok = c < c1 && io && w < w1;
     return ok ? (w == last_word ? v & tail_mask : v) : 0ull;
   };
-  auto fetch_rec = [&](uint32_t w) -> Rec {  // lanes past the last record read the last record; their live bit is 0
+  using RecT = typename std::conditional<COMPACT, Rec8, Rec>::type;
+  const RecT* rec_stream;
+  if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
+  auto fetch_rec = [&](uint32_t w) -> RecT {  // lanes past the last record read the last record; their live bit is 0
     const uint32_t r = min((min(w, last_word) << 6) + lane, P - 1);
-    return a.m.recs[r];
+    return rec_stream[r];
   };
   uint32_t steps_lane = 0, rem_acc = 0;
   uint64_t live_n = fetch_live(c0 + wave);
-  Rec buf[kChunk];
+  RecT buf[kChunk];
 #pragma unroll
   for (int j = 0; j < kChunk; ++j) buf[j] = fetch_rec((c0 + wave) * kChunk + j);
   for (uint32_t c = c0 + wave; c < c1; c += nw) {
@@ -509,7 +539,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     uint32_t slow = 0;
 #pragma unroll
     for (int j = 0; j < kChunk; ++j) {
-      const Rec rec = buf[j];
+      const Rec rec = expand(buf[j]);
       buf[j] = fetch_rec((c + nw) * kChunk + j);
       const uint32_t w = c * kChunk + j;
       if (w < w1) {
@@ -539,7 +569,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       const uint32_t j = jb & 3u;
       const bool generic = jb >= 4;
       const uint32_t w = c * kChunk + j;
-      const Rec rec = fetch_rec(w);  // re-read (L1/L2 hit) instead of keeping four more records alive
+      const Rec rec = expand(fetch_rec(w));  // re-read (L1/L2 hit) instead of keeping four more records alive
       const uint32_t kind = rec.xk >> 28;
       uint32_t todo = 0;  // nodes to run with the full filter
       if (!generic) {
@@ -582,7 +612,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     const uint32_t wl = c * kChunk + jq;
     if (io && wl < w1) {
       rem_acc += __popcll(my_new);
-      if (live_src != a.live || my_new != loaded) my_out[wl] = my_new;
+      if (!(PCP_ABLATE & 8) && (live_src != a.live || my_new != loaded)) my_out[wl] = my_new;
     }
   }
   if (io && rem_acc) atomicAdd(&remaining[bq], rem_acc);
@@ -636,7 +666,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 // ------------------------------------------------------------------------------------------------
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
-template <int B, bool GLOBAL>
+template <int B, bool GLOBAL, bool COMPACT>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   static_assert(!GLOBAL || B == 1, "the global-domain variant runs one node per block");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -701,7 +731,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       w0 = min(words, g * ws); w1 = min(words, w0 + ws);
     }
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
-    if (w0 < w1) sweep_fast<B, GLOBAL>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
+    if (w0 < w1) sweep_fast<B, GLOBAL, COMPACT>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
@@ -981,26 +1011,30 @@ hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, u
   return hipGetLastError();
 }
 
-template <int B, bool GLOBAL>
-static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+template <int B, bool GLOBAL, bool COMPACT>
+static hipError_t launch_k(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL, COMPACT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
+}
+template <int B>
+static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  return a.m.recs8 ? launch_k<B, false, true>(a, p, stream) : launch_k<B, false, false>(a, p, stream);
 }
 
 // nodes_per_block must be one of the instantiated tile sizes; global_dom selects the HBM-resident-domain variant.
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
-  if (a.global_dom) return a.nodes_per_block == 1 ? launch_b<1, true>(a, p, stream) : hipErrorInvalidValue;
+  if (a.global_dom) return a.nodes_per_block == 1 ? launch_k<1, true, false>(a, p, stream) : hipErrorInvalidValue;
   switch (a.nodes_per_block) {
-    case 1: return launch_b<1, false>(a, p, stream);
-    case 2: return launch_b<2, false>(a, p, stream);
-    case 4: return launch_b<4, false>(a, p, stream);
-    case 8: return launch_b<8, false>(a, p, stream);
-    case 12: return launch_b<12, false>(a, p, stream);
-    case 16: return launch_b<16, false>(a, p, stream);
+    case 1: return launch_b<1>(a, p, stream);
+    case 2: return launch_b<2>(a, p, stream);
+    case 4: return launch_b<4>(a, p, stream);
+    case 8: return launch_b<8>(a, p, stream);
+    case 12: return launch_b<12>(a, p, stream);
+    case 16: return launch_b<16>(a, p, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -16,7 +16,7 @@ import numpy as np
 from .model import PROP_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcp_hip.so")
+LIB_PATH = os.environ.get("PCP_HIP_LIB", os.path.join(_HERE, "libpcp_hip.so"))  # PCP_HIP_LIB: profiling builds (tools/ablate.sh)
 
 PCP_OK = 0
 ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP_ERR_NOMEM", -5: "PCP_ERR_UNSUPPORTED", -6: "PCP_ERR_NODEVICE"}
