@@ -142,6 +142,22 @@ typedef struct {
 } pcp_device_batch;
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 
+/* ---- branching on the device (the caller side of the path) -------------------------------------
+ * ≡ Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (search/branching/brancher.rs:52-71) applied to every
+ * PCP_UNKNOWN node of a propagated batch:
+ *   variable = first index among the variables of minimal size > 1   (first_smallest_var.rs:30-39)
+ *   value    = (lb + ub) / 2 truncated toward zero                   (middle_val.rs:25-27)
+ *   children = `x <= value` then `x > value`                          (binary_split.rs:46-57), folded into the bounds
+ * (a var-vs-constant XLessY narrows its variable on its first run and is then entailed and unlinked, x_less_y.rs:87-109).
+ * Children are written in tree order, two per Unknown node, each with a copy of its parent's `active` row — the
+ * cstore label (len, active.clone()) of propagation/store.rs:315-317.  All pointers are device pointers.
+ *   child_lb/child_ub : [2*n_nodes][n_vars] (capacity);  child_active : [2*n_nodes][ceil(n_units/64)]
+ *   counts            : device uint32[4] out = { n_children, n_true, n_false, n_unknown }
+ * Nothing is synchronised; read `counts` after synchronising hip_stream. */
+int32_t pcp_branch_device(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
+                          uint32_t* counts, void* hip_stream);
+
 /* Counters accumulate on the device across pcp_propagate_device calls. */
 int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
 int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */

@@ -41,6 +41,7 @@ struct pcp_ctx {
   // scratch
   pcp_stats* d_stats = nullptr;
   uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
+  uint32_t* d_child_base = nullptr; size_t cap_child_base = 0;  // branching scratch
   uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
   // host-buffer path staging
   void* d_stage = nullptr; size_t cap_stage = 0;
@@ -245,7 +246,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -447,6 +448,22 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (c->has_groups && bt->active_out)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
   c->ev_valid = true;
+  return PCP_OK;
+}
+
+int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
+                          uint32_t* counts, void* hip_stream) {
+  if (!c || !counts) return PCP_ERR_ARG;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t words = (c->n_units + 63) / 64;
+  if (n_nodes && (!status || (c->n_vars && (!lb || !ub || !child_lb || !child_ub)) || (words && (!active || !child_active))))
+    return fail(c, PCP_ERR_ARG, "null buffer");
+  int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
+  if (rc) return rc;
+  if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 16, stream)); return PCP_OK; }
+  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, words, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, stream));
   return PCP_OK;
 }
 

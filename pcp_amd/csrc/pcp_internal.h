@@ -89,4 +89,9 @@ hipError_t launch_expand_units(const uint32_t* rec_unit, uint32_t n_recs, uint32
 hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, uint32_t n_recs, const uint64_t* live, uint64_t* active_out,
                                  uint32_t n_nodes, hipStream_t stream);
 
+// On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
+hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
+                         uint32_t* counts, hipStream_t stream);
+
 }  // namespace pcp

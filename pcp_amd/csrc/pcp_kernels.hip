@@ -1012,6 +1012,89 @@ hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, u
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-device branching — Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (search/branching/brancher.rs:52-71)
+// for every Unknown node of a propagated batch.  branch_scan_kernel (one block) turns the statuses into child slots
+// in tree order; branch_kernel (one block per node) selects the variable with a block-wide (size, index) minimum,
+// splits it, and streams the parent's bounds and `active` row into its two children.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) branch_scan_kernel(const uint8_t* __restrict__ status, uint32_t n_nodes, uint32_t* __restrict__ child_base,
+                                                           uint32_t* __restrict__ counts) {
+  __shared__ uint32_t tmp[40];
+  __shared__ uint32_t total;
+  uint32_t run = 0, n_true = 0, n_false = 0;
+  for (uint32_t base = 0; base < n_nodes; base += blockDim.x) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t st = i < n_nodes ? status[i] : 255u;
+    const uint32_t unk = st == PCP_UNKNOWN ? 1u : 0u;
+    n_true += st == PCP_TRUE;
+    n_false += st == PCP_FALSE;
+    const uint32_t ex = block_exclusive_scan(unk, tmp, &total);
+    if (i < n_nodes) child_base[i] = unk ? 2u * (run + ex) : 0xFFFFFFFFu;
+    run += total;
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) { n_true += __shfl_down(n_true, o); n_false += __shfl_down(n_false, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[1], n_true); atomicAdd(&counts[2], n_false); }
+  if (threadIdx.x == 0) { counts[0] = 2u * run; counts[3] = run; }
+}
+
+__global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t words, const int32_t* __restrict__ lb, const int32_t* __restrict__ ub,
+                                                     const uint64_t* __restrict__ active, const uint32_t* __restrict__ child_base,
+                                                     int32_t* __restrict__ child_lb, int32_t* __restrict__ child_ub, uint64_t* __restrict__ child_active) {
+  const uint32_t node = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t slot = child_base[node];
+  if (slot == 0xFFFFFFFFu) return;  // not Unknown: nothing to branch on
+  __shared__ unsigned long long best[4];
+  const int32_t* plb = lb + (size_t)node * n_vars;
+  const int32_t* pub = ub + (size_t)node * n_vars;
+  // FirstSmallestVar: minimum of (size << 32 | index) over the variables of size > 1 (first index wins ties)
+  unsigned long long key = ~0ull;
+  for (uint32_t v = tid; v < n_vars; v += nth) {
+    const unsigned long long size = (unsigned long long)((long long)pub[v] - (long long)plb[v] + 1);
+    if (size > 1) key = min(key, (size << 32) | v);
+  }
+  for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+  if ((tid & 63) == 0) best[tid >> 6] = key;
+  __syncthreads();
+  key = best[0];
+  for (uint32_t w = 1; w < (nth >> 6); ++w) key = min(key, best[w]);
+  // An Unknown node always has an unassigned variable; if it has none (the reference panics,
+  // first_smallest_var.rs:36) the children are plain copies.
+  const uint32_t var = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)key;
+  int32_t val = 0;
+  if (var != 0xFFFFFFFFu) {
+    const long long s = (long long)plb[var] + (long long)pub[var];
+    val = (int32_t)(s / 2);  // MiddleVal: C++ `/` truncates toward zero like Rust's
+  }
+  int32_t* l0 = child_lb + (size_t)slot * n_vars;
+  int32_t* u0 = child_ub + (size_t)slot * n_vars;
+  int32_t* l1 = l0 + n_vars;
+  int32_t* u1 = u0 + n_vars;
+  for (uint32_t v = tid; v < n_vars; v += nth) {
+    const int32_t a = plb[v], b = pub[v];
+    l0[v] = a;                                   // left:  x <= val
+    u0[v] = (v == var) ? min(b, val) : b;
+    l1[v] = (v == var) ? max(a, val + 1) : a;    // right: x > val
+    u1[v] = b;
+  }
+  const uint64_t* pa = active + (size_t)node * words;
+  uint64_t* a0 = child_active + (size_t)slot * words;
+  uint64_t* a1 = a0 + words;
+  for (uint32_t w = tid; w < words; w += nth) { const uint64_t x = pa[w]; a0[w] = x; a1[w] = x; }
+}
+
+hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
+                         uint32_t* counts, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(1024), 0, stream, status, n_nodes, child_base, counts);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  hipLaunchKernelGGL(branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, words, lb, ub, active, child_base, child_lb, child_ub, child_active);
+  return hipGetLastError();
+}
+
 template <int B, bool GLOBAL, bool COMPACT>
 static hipError_t launch_k(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {

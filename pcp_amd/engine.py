@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
-    "pcp_propagate", "pcp_propagate_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option",
 ]
 
 
@@ -61,6 +61,13 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise EngineUnavailable(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64.  If PyTorch is going to be used in
+    # this process (device buffers, torch.distributed) its runtime has to be the one that gets loaded, otherwise a
+    # later `import torch` finds "No HIP GPUs".  Importing it first makes libpcp_hip.so bind to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = C.CDLL(LIB_PATH)
     except OSError as e:  # missing HIP runtime etc.
@@ -80,12 +87,13 @@ def load_library():
     L.pcp_model_n_units.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.pcp_propagate.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
+    L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
-              "pcp_propagate", "pcp_propagate_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -174,6 +182,13 @@ class Context:
             return None if t is None else C.c_void_p(t.data_ptr())
         bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status))
         self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
+
+    def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0):
+        """pcp_branch_device on torch tensors of this context's device (counts: int32[4]); nothing is synchronised."""
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self._L.pcp_branch_device(self._h, n_nodes, p(lb), p(ub), p(active), p(status), p(child_lb), p(child_ub), p(child_active),
+                                              p(counts), C.c_void_p(stream_ptr)))
 
     def stats_reset(self, stream_ptr: int = 0):
         self._check(self._L.pcp_stats_reset(self._h, C.c_void_p(stream_ptr)))

@@ -219,6 +219,69 @@ def test_config3_random_binary_csp_full_size(ctx):
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
 
 
+def test_device_branching_matches_host_branching(ctx):
+    """pcp_branch_device == the host driver's (numpy) FirstSmallestVar / MiddleVal / BinarySplit on a propagated batch,
+    including the reference's selector tables (first_smallest_var.rs:63-72, binary_split.rs:108-133)."""
+    import torch
+    from pcp_amd import search as S
+    n = 12
+    props = M.nqueens_props(n)
+    om = orc.OracleModel(n, props)
+    _, _, rec, _ = om.search(np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True, node_limit=300, max_records=300)
+    lb, ub, act, status = rec["lb_out"], rec["ub_out"], rec["active_out"], rec["status"]
+    unk = status == 2
+    hl, hu, ha = S.branch(lb[unk], ub[unk], act[unk])
+    ctx.set_model(n, props)
+    dev = torch.device("cuda", 0)
+    N, V, W = lb.shape[0], n, act.shape[1]
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dev)
+    d_lb, d_ub, d_act, d_st = t(lb, np.int32), t(ub, np.int32), t(act, np.int64), t(status, np.uint8)
+    c_lb = torch.empty((2 * N, V), dtype=torch.int32, device=dev)
+    c_ub = torch.empty_like(c_lb)
+    c_act = torch.empty((2 * N, W), dtype=torch.int64, device=dev)
+    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    ctx.branch_device(N, d_lb, d_ub, d_act, d_st, c_lb, c_ub, c_act, counts)
+    torch.cuda.synchronize()
+    nc, nt, nf, nu = counts.cpu().tolist()
+    assert (nc, nt, nf, nu) == (2 * int(unk.sum()), int((status == 1).sum()), int((status == 0).sum()), int(unk.sum()))
+    assert np.array_equal(c_lb[:nc].cpu().numpy(), hl) and np.array_equal(c_ub[:nc].cpu().numpy(), hu)
+    assert np.array_equal(c_act[:nc].cpu().numpy().view(np.uint64), ha)
+    g = json.load(open(os.path.join(GOLDEN, "engine_kats.json")))["search"]
+    root = g["binary_split"]["root"]
+    for c in g["binary_split"]["cases"]:  # make var c the smallest non-assigned one
+        doms = [[5, 5]] * 3
+        doms[c["var"]] = root[c["var"]]
+        ctx.set_model(3, M.lower_units([], 3))
+        dl = torch.tensor([[d[0] for d in doms]], dtype=torch.int32, device=dev)
+        du = torch.tensor([[d[1] for d in doms]], dtype=torch.int32, device=dev)
+        ds = torch.tensor([2], dtype=torch.uint8, device=dev)
+        ol, ou = torch.empty((2, 3), dtype=torch.int32, device=dev), torch.empty((2, 3), dtype=torch.int32, device=dev)
+        ctx.branch_device(1, dl, du, None, ds, ol, ou, None, counts)
+        torch.cuda.synchronize()
+        got = [[int(ol[0, c["var"]]), int(ou[0, c["var"]])], [int(ol[1, c["var"]]), int(ou[1, c["var"]])]]
+        assert got == c["children"]
+
+
+@pytest.mark.parametrize("n,batch", [(6, 1), (8, 1), (8, 64), (9, 256)])
+def test_device_resident_search(ctx, n, batch):
+    """Whole search with stack, propagation and branching on the GPU: the reference's tree exactly
+    (solutions / nodes / failures of the oracle's DFS; all_solution.rs:70 for the counts)."""
+    from pcp_amd.search_device import DeviceSearch
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0}.items():
+        ctx.set_option(k, v)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    ss, _, _, sol = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
+    st = DeviceSearch(ctx, batch=batch, capacity=4096).run(lb0, ub0, all_solutions=True, keep_solutions=400)
+    assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
+    assert len({tuple(s) for s in st.solutions}) == ss["num_solution"]
+    if batch == 1:  # exact reference order: the first solution found is the reference's
+        one = DeviceSearch(ctx, batch=1, capacity=4096).run(lb0, ub0, all_solutions=False, keep_solutions=1)
+        ss1, _, _, sol1 = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=False)
+        assert one.num_nodes == ss1["num_nodes"] and np.array_equal(one.solutions[0], sol1)
+
+
 def test_cpp_host_mirror_nqueens():
     """The C++ host side (pcp_amd/host/pcp_host.hpp) running the reference's n-queens example code
     (example/src/nqueens.rs:28-74) with every node's fixpoint on the GPU: same first solution, same node and failure
