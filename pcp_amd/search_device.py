@@ -61,7 +61,12 @@ class DeviceSearch:
         size = 1
         ctx.stats_reset(stream)
         while size > 0:
-            n = min(self.batch, size)
+            # popping n and pushing at most 2n children must fit: when the stack is nearly full, take fewer nodes
+            # (a deeper, narrower dive) instead of overflowing
+            room = self.cap - size
+            if room <= 0:
+                raise RuntimeError(f"open-node stack full ({size} of {self.cap}); raise `capacity`")
+            n = min(self.batch, size, max(1, room // 2))
             if node_limit:
                 n = min(n, node_limit - st.num_nodes)
                 if n <= 0:
