@@ -27,7 +27,8 @@
 #include "pcp_internal.h"
 
 // PCP_ABLATE (profiling builds only, tools/ablate.sh; results are WRONG when non-zero): bit 0 = no LDS reads in the
-// level-1 test, bit 1 = no arithmetic in it, bit 2 = no record stream (one record reused), bit 3 = no live-word I/O.
+// level-1 test, bit 1 = no arithmetic in it, bit 3 = no live-word I/O, bit 4 = skip the sweep's cold part, bit 5 = skip the
+// wake-up rounds.
 #ifndef PCP_ABLATE
 #define PCP_ABLATE 0
 #endif
@@ -472,12 +473,17 @@ __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
 // 32-byte transaction each (measured: WRITE_SIZE 3.4x the bytes stored).  Word j of node b is then lane b*CHUNK+j.
 constexpr int kChunk = 4;
 
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
-  return ((uint64_t)hi << 32) | lo;
+// OR of a 32-bit value over all lanes congruent to this lane modulo 4 (the kChunk lanes-per-node layout): two DPP row
+// rotations combine the four quads of each 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950) combine the rows.
+__device__ __forceinline__ uint32_t or_mod4(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true);  // row_ror:4
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = r[0] | r[1];
+  const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return q[0] | q[1];
 }
+__device__ __forceinline__ uint64_t or_mod4_64(uint64_t v) { return ((uint64_t)or_mod4((uint32_t)(v >> 32)) << 32) | or_mod4((uint32_t)v); }
 
 __device__ __forceinline__ Rec expand(const Rec8 q) {
   Rec r;
@@ -535,7 +541,10 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     live_n = fetch_live(c + nw);
     uint64_t my_new = loaded;
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint64_t nz = __ballot(loaded != 0);
+    // alive4: lane l holds the OR over the tile's nodes of word (l & 3) — the records of that word that are live in
+    // at least one node.  A record that is dead in every node of the tile (entailed higher up the search tree:
+    // siblings share their ancestors' entailments) must not drag its word onto the cold path.
+    const uint64_t alive4 = or_mod4_64(loaded);
     // ---- hot part, unrolled: level-1 test of the four words; anything else is only noted in `slow` --------------
     uint32_t slow = 0;
 #pragma unroll
@@ -547,14 +556,15 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         const uint32_t kind = rec.xk >> 28;
         const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
         if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
-          if (nz & (0x1111111111111111ull << j)) {  // some record of this word is live in some node
+          const uint64_t alive = readlane64(alive4, j);
+          if (alive) {  // some record of this word is live in some node
             if (kind0 == PCP_EQ) {
               slow |= 1u << j;
             } else {
               const int2* px = k.dom + slot_row<B>(rec.xk & kSlotMask);
               const int2* py = k.dom + slot_row<B>(rec.y);
               const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
-              if (__ballot(o < 0)) slow |= 1u << j;
+              if (__ballot(o < 0) & alive) slow |= 1u << j;
             }
           }
           if (jq == (uint32_t)j) steps_lane += __popcll(loaded);  // every live record of every node runs once
@@ -563,6 +573,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         }
       }
     }
+    if (PCP_ABLATE & 16) slow = 0;
     // ---- cold part, one rolled copy: flagged words (level 2 + full filter) and words outside the fast path ---------
     while (slow) {
       const uint32_t jb = __builtin_ctz(slow);
@@ -580,12 +591,9 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         if (kind0 == PCP_EQ) {
           todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, loaded, j);
         } else {
-          const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
-          const uint64_t alive = wave_or64(jq == j ? loaded : 0ull);  // records live in at least one node of the tile
-          if (__ballot(o < 0) & alive) {
-            if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
-            else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
-          }
+          // the hot part has already established that a record live somewhere in the tile is flagged
+          if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
+          else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
         }
       } else {
         const bool tern = kind > PCP_LT;
@@ -723,6 +731,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
 
   Ctr ctr;
   uint64_t steps2 = 0, steps3 = 0;
+  const unsigned long long t_begin = (PCP_ABLATE & 64) ? wall_clock64() : 0ull;  // profiling build: phase timers (100 MHz ticks)
 
   // ---- phase 1: wave 0 = every live propagator once (a slice of the table when team > 1) -----------------
   {
@@ -804,6 +813,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   }
 
   // ---- phase 3: wake-up rounds until no variable changes (IndexedDeps::react + RelaxedFifo, as waves) ------
+  const unsigned long long t_sweep = (PCP_ABLATE & 64) ? wall_clock64() : 0ull;
   const uint32_t TW = nb * Wv;
   for (;;) {
     // (a) count changed (node,var) pairs of live nodes
@@ -819,7 +829,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     }
     uint32_t off = block_exclusive_scan(cnt, tmp, &misc[M_TOTAL]);
     const uint32_t total = misc[M_TOTAL];
-    if (total == 0) break;
+    if (total == 0 || (PCP_ABLATE & 32)) break;
     if (total <= C) {
       // (b) compact them into a list with each variable's degree, prefix-sum the degrees
       for (uint32_t w = tid; w < TW; w += nth) {
@@ -847,32 +857,74 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       }
       __syncthreads();
       const uint32_t T = misc[M_ITEMS];
-      // (c) one item = one (changed var, incident record): flat, load-balanced over the whole block
       uint32_t my2 = 0, my3 = 0;
-      for (uint32_t i = tid; i < T; i += nth) {
-        uint32_t lo = 0, hi = total;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
-        const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
-        const uint32_t r = a.m.adj[a.m.adj_off[v] + (i - list_pre[lo])];
-        uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
+      // one item = one (changed var, incident record).  Runs a live record woken from variable v of node b unless a
+      // lower-numbered changed variable of the same record will run it (RelaxedFifo dedup, relaxed_fifo.rs:42-48).
+      auto run_item = [&](uint32_t b, uint32_t v, uint32_t r, uint32_t lbits, const Rec rec) {
         const uint32_t bit = 1u << (r & 31);
-        if (!(__hip_atomic_load(lw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) continue;  // unlinked (store.rs:200-207)
-        const Rec rec = a.m.recs[r];
-        // RelaxedFifo dedup (relaxed_fifo.rs:42-48): a record woken by several changed variables runs once,
-        // from the lowest-numbered one.
+        if (!(lbits & bit)) return;  // unlinked (store.rs:200-207)
         const uint32_t* cb = cur + (size_t)b * Wv;
         const uint32_t x = rec.xk & kSlotMask;
         const bool tern = (rec.xk >> 28) > PCP_LT;
-        bool skip = false;
-        if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) skip = true;
-        if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) skip = true;
-        if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) skip = true;
-        if (skip) continue;
+        if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) return;
+        if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) return;
+        if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
         const auto dm = make_dom<GLOBAL>(k, b, nxt, &ctr);
         if (tern) ++my3; else ++my2;
         if (eval_record(rec, dm)) {
+          uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
           const uint32_t old = atomicAnd(lw, ~bit);
           if (old & bit) atomicSub(&remaining[b], 1u);
+        }
+      };
+      if (T >= 32u * total) {
+        // (c1) high-degree variables (N-queens: 2997 records each): a wavefront walks an adjacency list 4 x 64 entries at
+        // a time — the index loads are coalesced, and the 4 x (live word, record) gathers that depend on them are all
+        // in flight together, instead of one dependent chain per item.
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
+        constexpr int U = 4;
+        // every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its list: a round with a
+        // single changed variable (the tail of a long cascade) is spread over the whole workgroup, not run by one wave
+        // With at least one pair per wavefront each wavefront takes whole pairs; with fewer (the tail of a long cascade:
+        // one changed variable) every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its
+        // list, so that the round is spread over the whole workgroup instead of being run by one wave.
+        const bool whole = total >= nwv;
+        for (uint32_t e = whole ? wv : 0u; e < total; e += whole ? nwv : 1u) {
+          const uint32_t id = list_id[e], b = id >> 26, v = id & ((1u << 26) - 1);
+          const uint32_t deg = list_pre[e + 1] - list_pre[e];
+          const uint32_t* ap = a.m.adj + a.m.adj_off[v];
+          const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
+          for (uint32_t k0 = whole ? 0u : wv * 64 * U; k0 < deg; k0 += (whole ? 1u : nwv) * 64 * U) {
+            uint32_t r[U], lb_[U];
+            Rec rc[U];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const uint32_t idx = k0 + u * 64 + lane;
+              ok[u] = idx < deg;
+              r[u] = ap[ok[u] ? idx : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              rc[u] = a.m.recs[r[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (ok[u]) run_item(b, v, r[u], lb_[u], rc[u]);
+          }
+        }
+      } else {
+        // (c2) low-degree variables: flat item space, load-balanced over the whole block by binary search in the
+        // degree prefix sums
+        for (uint32_t i = tid; i < T; i += nth) {
+          uint32_t lo = 0, hi = total;
+          while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
+          const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
+          const uint32_t r = a.m.adj[a.m.adj_off[v] + (i - list_pre[lo])];
+          const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
+          const uint32_t lbits = __hip_atomic_load(lrow + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          run_item(b, v, r, lbits, a.m.recs[r]);
         }
       }
       for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); }
@@ -894,6 +946,13 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
 
   // ---- phase 4: write back domains, status, counters ---------------------------------------------------
   __syncthreads();
+  if ((PCP_ABLATE & 64) && tid == 0) {  // profiling build: steps3 := sweep ticks, narrowings := rounds ticks (summed over blocks)
+    const unsigned long long t_end = wall_clock64();
+    atomicAdd((unsigned long long*)&a.stats->steps3, t_sweep - t_begin);
+    atomicAdd((unsigned long long*)&a.stats->narrowings, t_end - t_sweep);
+    atomicMax((unsigned long long*)&a.stats->failed_nodes, t_sweep - t_begin);   // slowest block's sweep
+    atomicMax((unsigned long long*)&a.stats->waves, t_end - t_sweep);            // slowest block's rounds
+  }
   if (GLOBAL) {
     bool bad = false;  // the domains are already in place; a missed failure shows as an empty domain here
     for (uint32_t v = tid; v < V; v += nth)

@@ -48,25 +48,36 @@ class DeviceSearch:
         self.c_act = torch.empty((2 * self.batch, W), dtype=i64, device=self.dev)
         self.counts = torch.zeros(4, dtype=i32, device=self.dev)
 
-    def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0) -> DeviceSearchStats:
+    def reset(self, lb0, ub0):
+        """Start a new search: the stack holds the root."""
         torch, ctx = self.torch, self.ctx
         from .engine import full_active
-        st = DeviceSearchStats()
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
         self.lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev)
         self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
-        fa = full_active(1, ctx.n_units)
         if ctx.words:
-            self.act[0] = torch.from_numpy(fa.view(np.int64)[0]).to(self.dev)
-        size = 1
-        ctx.stats_reset(stream)
-        while size > 0:
+            self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
+        self.size = 1
+        self.stats = DeviceSearchStats()
+        ctx.stats_reset(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def advance(self, all_solutions: bool = True, node_limit: int = 0, max_rounds: int = 0, keep_solutions: int = 0, batch: int = 0) -> bool:
+        """Run rounds on the current stack until it is empty, a limit is hit, or (not all_solutions) a solution is
+        found.  Returns True when the search is over (stack empty or solution found)."""
+        torch, ctx, st = self.torch, self.ctx, self.stats
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        batch = min(int(batch) if batch else self.batch, self.batch)
+        rounds = 0
+        done = False
+        while self.size > 0:
+            if max_rounds and rounds >= max_rounds:
+                break
+            size = self.size
             # popping n and pushing at most 2n children must fit: when the stack is nearly full, take fewer nodes
             # (a deeper, narrower dive) instead of overflowing
             room = self.cap - size
             if room <= 0:
                 raise RuntimeError(f"open-node stack full ({size} of {self.cap}); raise `capacity`")
-            n = min(self.batch, size, max(1, room // 2))
+            n = min(batch, size, max(1, room // 2))
             if node_limit:
                 n = min(n, node_limit - st.num_nodes)
                 if n <= 0:
@@ -78,6 +89,7 @@ class DeviceSearch:
             ctx.branch_device(n, lb, ub, act if ctx.words else None, status, self.c_lb, self.c_ub, self.c_act if ctx.words else None,
                               self.counts, stream)
             n_children, n_true, n_false, _ = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
+            rounds += 1
             st.rounds += 1
             st.num_nodes += n
             st.num_solution += n_true
@@ -88,9 +100,9 @@ class DeviceSearch:
                     st.solutions.append(r)
             size = lo
             if n_true and not all_solutions:
+                self.size = size
+                done = True
                 break
-            if size + n_children > self.cap:
-                raise RuntimeError(f"open-node stack overflow ({size + n_children} > {self.cap}); raise `capacity`")
             if n_children:
                 # reversed, so that the first node's left child ends on top of the stack (left-first DFS)
                 self.lb[size:size + n_children] = torch.flip(self.c_lb[:n_children], dims=[0])
@@ -98,7 +110,18 @@ class DeviceSearch:
                 if ctx.words:
                     self.act[size:size + n_children] = torch.flip(self.c_act[:n_children], dims=[0])
                 size += n_children
+            self.size = size
             st.max_open = max(st.max_open, size)
         s = ctx.stats_read(stream)
         st.filter_steps = s["steps"] + s["steps3"]
-        return st
+        return done or self.size == 0
+
+    def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0) -> DeviceSearchStats:
+        self.reset(lb0, ub0)
+        self.advance(all_solutions=all_solutions, node_limit=node_limit, keep_solutions=keep_solutions)
+        return self.stats
+
+    def top(self, k: int):
+        """The k open nodes on top of the stack (device tensors, views)."""
+        lo = max(0, self.size - k)
+        return self.lb[lo:self.size], self.ub[lo:self.size], self.act[lo:self.size]
