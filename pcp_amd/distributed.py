@@ -193,3 +193,79 @@ def parallel_search(ctx, lb0, ub0, dist, batch: int = 64, all_solutions: bool = 
     g = ParallelStats(*[int(x) for x in tot.tolist()[:4]], rounds=st.rounds, moved=int(tot[4]))
     g.solutions = st.solutions  # local solutions only
     return g
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Device-resident variant: the open-node stacks live in HBM (pcp_amd.search_device.DeviceSearch) and whole node records
+# move GPU-to-GPU — over RCCL/xGMI with backend "nccl", over gloo with CPU tensors in the tests.  Same plan, same
+# three exchange steps as above; the only host traffic is the all_gather of the stack sizes and the counters.
+# ---------------------------------------------------------------------------------------------------------------
+def balance_stacks(stack, dist) -> int:
+    """X1 + X2 on a stack object with tensors ``lb [cap,V]``, ``ub [cap,V]``, ``act [cap,W]`` and an int ``size``
+    (rows [0,size) are open nodes, the top of the stack is the end).  Senders give away their OLDEST rows (bottom of
+    the stack: closest to the root, the largest subtrees); receivers put them at the bottom too.  Returns the number
+    of rows sent (+) or received (-)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = stack.lb.device
+    mine = torch.tensor([stack.size], dtype=torch.int64, device=dev)
+    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    moves = plan_moves([int(t.item()) for t in gathered])
+    ops, incoming, delta, give = [], [], 0, 0
+    for src, dst, k in moves:
+        if rank == src:
+            for t in (stack.lb, stack.ub, stack.act):
+                ops.append(dist.P2POp(dist.isend, t[give:give + k].contiguous(), dst))
+            give += k
+            delta += k
+        elif rank == dst:
+            bufs = [torch.empty((k,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in (stack.lb, stack.ub, stack.act)]
+            for b in bufs:
+                ops.append(dist.P2POp(dist.irecv, b, src))
+            incoming.append(bufs)
+            delta -= k
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if give:  # drop the rows given away: shift the rest down
+        keep = stack.size - give
+        for t in (stack.lb, stack.ub, stack.act):
+            t[:keep] = t[give:stack.size].clone()
+        stack.size = keep
+    for bufs in incoming:  # insert received rows at the bottom
+        k = bufs[0].shape[0]
+        if stack.size + k > stack.lb.shape[0]:
+            raise RuntimeError("open-node stack overflow while receiving work; raise `capacity`")
+        for t, b in zip((stack.lb, stack.ub, stack.act), bufs):
+            t[k:stack.size + k] = t[:stack.size].clone()
+            t[:k] = b
+        stack.size += k
+    return delta
+
+
+def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4):
+    """Sharded subtree search with device-resident stacks: ``search`` is a pcp_amd.search_device.DeviceSearch of this
+    rank's GPU.  Rank 0 starts with the root; every ``rounds_per_exchange`` rounds the stacks are balanced GPU-to-GPU
+    (X1+X2) and termination / totals agreed on (X3).  Returns the global (nodes, solutions, failures, filter steps)."""
+    import torch
+    rank = dist.get_rank()
+    dev = search.lb.device
+    search.reset(lb0, ub0)
+    if rank != 0:
+        search.size = 0
+    moved = 0
+    while True:
+        if search.size > 0:
+            search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0)
+        moved += max(balance_stacks(search, dist), 0)
+        st = search.stats
+        flags = torch.tensor([search.size, st.num_solution, st.num_nodes], dtype=torch.int64, device=dev)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+        open_total, sol_total, nodes_total = (int(x) for x in flags.tolist())
+        if open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit):
+            break
+    st = search.stats
+    tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, moved], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return tuple(int(x) for x in tot.tolist())

@@ -282,6 +282,27 @@ def test_device_resident_search(ctx, n, batch):
         assert one.num_nodes == ss1["num_nodes"] and np.array_equal(one.solutions[0], sol1)
 
 
+def test_parallel_search_device_single_rank(ctx):
+    """parallel_search_device with world_size 1 (the driver's GPU box has one GPU): the exchange steps run (all_gather,
+    all_reduce) and the totals are the reference's tree."""
+    import torch
+    import torch.distributed as dist
+    from pcp_amd import distributed as D
+    from pcp_amd.search_device import DeviceSearch
+    n = 8
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        ds = DeviceSearch(ctx, batch=64, capacity=4096)
+        nodes, sols, fails, steps, moved = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist)
+    finally:
+        dist.destroy_process_group()
+    assert (nodes, sols, fails, moved) == (779, 92, 298, 0) and steps > 0
+
+
 def test_cpp_host_mirror_nqueens():
     """The C++ host side (pcp_amd/host/pcp_host.hpp) running the reference's n-queens example code
     (example/src/nqueens.rs:28-74) with every node's fixpoint on the GPU: same first solution, same node and failure

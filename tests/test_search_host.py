@@ -143,3 +143,53 @@ def test_two_rank_worklist_gloo(batch):
     sols = res[0][5] + res[1][5]
     assert len(sols) == 92 and len(set(sols)) == 92
     assert len(res[0][5]) > 0 and len(res[1][5]) > 0  # both ranks did real work
+
+
+def _stack_worker(rank, world, port, q):
+    """balance_stacks over gloo with CPU tensors: rows are tagged so that nothing is lost, duplicated or torn."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Stack:
+            pass
+        V, W, cap = 5, 3, 64
+        st = Stack()
+        st.lb = torch.zeros((cap, V), dtype=torch.int32)
+        st.ub = torch.zeros((cap, V), dtype=torch.int32)
+        st.act = torch.zeros((cap, W), dtype=torch.int64)
+        st.size = 23 if rank == 0 else 2
+        for r in range(st.size):
+            tag = 1000 * rank + r
+            st.lb[r] = tag
+            st.ub[r] = tag + 500000
+            st.act[r] = tag + 7
+        delta = D.balance_stacks(st, dist)
+        tags = st.lb[: st.size, 0].tolist()
+        ok = all((st.lb[i] == st.lb[i, 0]).all() and (st.ub[i] == st.lb[i, 0] + 500000).all() and (st.act[i] == st.lb[i, 0] + 7).all()
+                 for i in range(st.size))
+        q.put((rank, st.size, delta, tags, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_stack_balancing_gloo():
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_stack_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, d0, t0, ok0), (r1, s1, d1, t1, ok1) = res
+    assert ok0 and ok1
+    assert {s0, s1} == {12, 13} and d0 == -d1 and d0 > 0
+    assert sorted(t0 + t1) == sorted(list(range(23)) + [1000, 1001])  # every row exactly once
+    assert t0 == list(range(d0, 23))  # rank 0 gave away its oldest rows
+    assert t1[:d0] == list(range(d0)) and t1[d0:] == [1000, 1001]  # and they sit at the bottom of rank 1's stack
