@@ -427,25 +427,36 @@ __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const 
     }
     return o & 0x7fffffff;
   }
-  auto one = [&](int xn, int xu, int yn, int yu) {
-    if (PCP_ABLATE & 2) { o |= (xn ^ yu) & (xu ^ yn) & 0x7fffffff; return; }
-    if (KIND == PCP_NEQ) o |= (yu + c1 + xn) | (xu + c2 + yn);
-    else o |= ((yu - xu) + c1) | ((xn - yn) + c1) | (xu + c3 + yn);
+  // The constants are the same for every node of the tile, so the per-node work is one add per term and a running
+  // minimum (v_min3_i32 takes two nodes at a time); the constant is added once at the end: some node has
+  // t + c < 0  <=>  min(t) + c < 0.  All sums stay below 2^31 (bounds < 2^29, folded offsets < 2^30).
+  int m1 = 0x7fffffff, m2 = 0x7fffffff;
+  auto two = [&](int xn0, int xu0, int yn0, int yu0, int xn1, int xu1, int yn1, int yu1) {
+    if (PCP_ABLATE & 2) { o |= (xn0 ^ yu0) & (xu0 ^ yn0) & (xn1 ^ yu1) & (xu1 ^ yn1) & 0x7fffffff; return; }
+    if (KIND == PCP_NEQ) {
+      m1 = min(min(m1, yu0 + xn0), yu1 + xn1);
+      m2 = min(min(m2, xu0 + yn0), xu1 + yn1);
+    } else {
+      m1 = min(min(m1, yu0 - xu0), xn0 - yn0);
+      m1 = min(min(m1, yu1 - xu1), xn1 - yn1);
+      m2 = min(min(m2, xu0 + yn0), xu1 + yn1);
+    }
   };
   if (B == 1) {
     const int2 X = px[0], Y = py[0];
-    one(X.x, X.y, Y.x, Y.y);
-    return o;
-  }
+    two(X.x, X.y, Y.x, Y.y, X.x, X.y, Y.x, Y.y);
+  } else {
 #pragma unroll
-  for (int g = 0; g < B; g += 2) {
-    // node pairs are 16-byte aligned by construction (row stride (B+2)*8 bytes, even g): keep it one ds_read_b128
-    const int4 Xp = *static_cast<const int4*>(__builtin_assume_aligned(px + g, 16));
-    const int4 Yp = *static_cast<const int4*>(__builtin_assume_aligned(py + g, 16));
-    one(Xp.x, Xp.y, Yp.x, Yp.y);
-    one(Xp.z, Xp.w, Yp.z, Yp.w);
+    for (int g = 0; g < B; g += 2) {
+      // node pairs are 16-byte aligned by construction (row stride (B+2)*8 bytes, even g): keep it one ds_read_b128
+      const int4 Xp = *static_cast<const int4*>(__builtin_assume_aligned(px + g, 16));
+      const int4 Yp = *static_cast<const int4*>(__builtin_assume_aligned(py + g, 16));
+      two(Xp.x, Xp.y, Yp.x, Yp.y, Xp.z, Xp.w, Yp.z, Yp.w);
+    }
   }
-  return o;
+  if (PCP_ABLATE & 2) return o;
+  if (KIND == PCP_NEQ) return (m1 + c1) | (m2 + c2);
+  return (m1 + c1) | (m2 + c3);
 }
 
 // OR of a 32-bit value over the 16 lanes of each DPP row (quad swaps, then half-mirror, then mirror).
