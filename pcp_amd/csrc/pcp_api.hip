@@ -36,10 +36,13 @@ struct pcp_ctx {
   size_t cap_rec_unit = 0, cap_unit_first = 0;
   uint32_t n_slots = 0;
   bool has_ternary = false;
+  bool consts_fit16 = true;      // every interned constant within +-kPackedMax (packed tiles)
   size_t cap_recs = 0, cap_adj = 0, cap_adj_off = 0, cap_const = 0;
 
   // scratch
   pcp_stats* d_stats = nullptr;
+  uint32_t* d_retry = nullptr;   // packed launches: stamped with `epoch` by a tile that has to be re-run with 32-bit cells
+  uint32_t epoch = 0;
   uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
   uint32_t* d_child_base = nullptr; size_t cap_child_base = 0;  // branching scratch
   uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
@@ -57,6 +60,7 @@ struct pcp_ctx {
   int64_t opt_team = 0;             // 0 = auto
   int64_t opt_list_cap = 2048;
   int64_t opt_global_dom = 0;       // 1 = force the HBM-resident-domain variant (tests)
+  int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
 };
 
 namespace {
@@ -173,6 +177,8 @@ int32_t finalize_model(pcp_ctx* c) {
   if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
   c->compact = !tern && n_slots <= kCompactSlots && P > 0;
+  c->consts_fit16 = true;
+  for (int32_t v : consts) c->consts_fit16 &= (v >= -kPackedMax && v <= kPackedMax);
   if (c->compact) {
     std::vector<Rec8> r8(P);
     for (size_t r = 0; r < P; ++r) {
@@ -234,6 +240,7 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
   }
   if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(pcp_stats)) != hipSuccess ||
       hipMemset(c->d_stats, 0, sizeof(pcp_stats)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_retry), 4) != hipSuccess || hipMemset(c->d_retry, 0, 4) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
     delete c;
     return PCP_ERR_HIP;
@@ -246,7 +253,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -328,6 +335,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "global_dom") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "global_dom must be 0 or 1");
     c->opt_global_dom = value;
+  } else if (k == "packed") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "packed must be 0 or 1");
+    c->opt_packed = value;
   } else if (k == "list_cap") {
     if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
     c->opt_list_cap = value;
@@ -396,10 +406,31 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
     B = global_dom ? 1u : std::max<uint32_t>(1, tile_le(want));
   }
+  // Packed tiles (16-bit cells, pcp_kernels.hip LdsDom16): twice the nodes per workgroup in the same LDS and half the
+  // LDS traffic per filter step.  They need every bound within +-kPackedMax; that is checked per tile on the device
+  // while the domains are staged, and a tile that does not fit is handed back to a second launch with 32-bit cells
+  // and half the tile size (same LDS footprint, so it fits whenever the packed tile did).
+  uint32_t Bp = 0, cap_p = 0, cap_half = 0;
+  if (!use_team && !global_dom && c->opt_packed && c->compact && c->consts_fit16) {
+    const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
+    for (uint32_t t : {32u, 16u, 8u}) {
+      if (t > want) continue;
+      uint32_t cap = list_cap;
+      while (cap > 256 && !(lds_bytes_for(S, t, cap, block, true) && lds_bytes_for(S, t, cap, block, true) <= c->lds_max)) cap /= 2;
+      const size_t need = lds_bytes_for(S, t, cap, block, true);
+      if (!need || need > c->lds_max) continue;
+      const uint32_t ch = fits(t / 2);
+      if (!ch) continue;
+      Bp = t; cap_p = cap; cap_half = ch;
+      break;
+    }
+    if (Bp * 2 <= B) Bp = 0;  // a 32-bit tile with at least twice the nodes wins
+  }
   LaunchPlan plan;
   plan.block = block;
   if (use_team && !global_dom) list_cap_used = fits(1);
-  plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block);
+  if (Bp) { B = Bp; list_cap_used = cap_p; }
+  plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block, Bp != 0);
   plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
 
   LaunchArgs a;
@@ -407,6 +438,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
+  a.packed = Bp ? 1u : 0u; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -444,6 +476,16 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
+  if (Bp) {
+    // the tiles the packed kernel handed back (normally none: every block of this launch returns at once)
+    LaunchArgs a2 = a;
+    a2.packed = 0; a2.only_marked = 1; a2.nodes_per_block = Bp / 2; a2.list_cap = cap_half;
+    LaunchPlan plan2;
+    plan2.block = block;
+    plan2.lds_bytes = lds_bytes_for(S, Bp / 2, cap_half, block);
+    plan2.grid = (n_nodes + Bp / 2 - 1) / (Bp / 2);
+    HIP_TRY(c, launch_fixpoint(a2, plan2, stream));
+  }
   HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (c->has_groups && bt->active_out)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));

@@ -55,6 +55,11 @@ struct LaunchArgs {
   uint32_t team;             // G: workgroups cooperating on ONE node (nodes_per_block == 1 when team > 1)
   uint32_t list_cap;         // capacity of the per-round changed-(node,var) list in LDS
   uint32_t global_dom;       // 1 = domains stay in lb_out/ub_out (HBM/L2), for variable stores larger than LDS
+  uint32_t packed;           // 1 = 16-bit packed LDS domains (every bound within +-kPackedMax); tiles that do not fit mark
+                             //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
+  uint32_t only_marked;      // 1 = second launch of a packed call: run only tiles whose nodes carry kStatusRetry
+  uint32_t epoch;            // launch stamp compared with *retry_flag
+  uint32_t* retry_flag;      // device word of the context
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -71,6 +76,9 @@ struct LaunchArgs {
   uint64_t* team_counters;  // [n_nodes][4] steps, steps3, narrowings (merged by the tail block)
 };
 
+constexpr int32_t kPackedMax = 16383;   // |bound| limit of the packed tiles: sums of two bounds fit int16
+constexpr uint8_t kStatusRetry = 0xFE;  // internal: never visible to the caller (the second launch overwrites it)
+
 struct LaunchPlan {
   uint32_t grid;
   uint32_t block;
@@ -78,7 +86,7 @@ struct LaunchPlan {
 };
 
 // Computes the dynamic-LDS footprint for (n_slots, B, list_cap); returns 0 if it cannot fit.
-size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block);
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed = false);
 size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap);
 
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);

@@ -27,8 +27,8 @@
 #include "pcp_internal.h"
 
 // PCP_ABLATE (profiling builds only, tools/ablate.sh; results are WRONG when non-zero): bit 0 = no LDS reads in the
-// level-1 test, bit 1 = no arithmetic in it, bit 3 = no live-word I/O, bit 4 = skip the sweep's cold part, bit 5 = skip the
-// wake-up rounds.
+// level-1 test, bit 1 = no arithmetic in it, bit 2 = no record stream, bit 3 = no live-word I/O, bit 4 = skip the sweep's cold part, bit 5 = skip the
+// wake-up rounds, bit 6 = phase timers, bit 7 = timers of the sweep's segments (tools/seg_times.py).
 #ifndef PCP_ABLATE
 #define PCP_ABLATE 0
 #endif
@@ -78,6 +78,63 @@ struct LdsDom {
       mark(v);
       const int nlb = __hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (-nlb > nub) set_fail();
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Packed variant of LdsDom for tiles whose every bound lies within +-kPackedMax: one dword per (slot,node),
+// low half = -lb, high half = ub (both int16).  Half the LDS bytes and half the VALU work in the sweep's level-1 test
+// (v_pk_add_u16 / v_pk_min_i16, see fast_signs).  Narrowing one half is a compare-and-swap loop (LDS has no 16-bit
+// atomics); narrowings are rare next to tests.  A bound that crosses the other one is clamped to lb = ub + 1 resp.
+// ub = lb - 1 so that it stays representable: the node is failed, and a failed node's domains are unspecified.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pack16(int lb, int ub) { return ((uint32_t)ub << 16) | ((uint32_t)(-lb) & 0xffffu); }
+__device__ __forceinline__ int2 unpack16(uint32_t c) { return make_int2(-(int)(short)(c & 0xffffu), (int)c >> 16); }  // (lb, ub)
+
+struct LdsDom16 {
+  uint32_t* dom;    // &dom[0*BP + b]
+  uint32_t bp;      // row stride in dwords
+  uint32_t* chg;
+  uint32_t* fail;
+  uint32_t fbit;
+  Ctr* c;
+
+  __device__ __forceinline__ int2 load(uint32_t v) const { return unpack16(dom[(size_t)v * bp]); }
+  __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
+  __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    uint32_t* p = dom + (size_t)v * bp;
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nlb <= d.x) return;  // somebody else got there first
+      const uint32_t neu = pack16(min(nlb, d.y + 1), d.y);
+      const uint32_t prev = atomicCAS(p, old, neu);
+      if (prev == old) {
+        ++c->narrow;
+        mark(v);
+        if (nlb > d.y) set_fail();
+        return;
+      }
+      old = prev;
+    }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    uint32_t* p = dom + (size_t)v * bp;
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nub >= d.y) return;
+      const uint32_t neu = pack16(d.x, max(nub, d.x - 1));
+      const uint32_t prev = atomicCAS(p, old, neu);
+      if (prev == old) {
+        ++c->narrow;
+        mark(v);
+        if (nub < d.x) set_fail();
+        return;
+      }
+      old = prev;
     }
   }
 };
@@ -280,14 +337,17 @@ struct Carve {
   size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
 __host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 2u; }
+// packed tiles: dwords per slot; B + 4 = 12/20/36 for B = 8/16/32 keeps rows 16-byte aligned (one ds_read_b128 = four
+// nodes) and 16 consecutive slots on 16 distinct 4-bank groups, exactly as B/2 int2 nodes would.
+__host__ __device__ inline uint32_t row_stride16(uint32_t B) { return B + 4u; }
 // dom_slots: slots whose domains live in LDS (all of them, or only the constants in the global variant);
 // mask_slots: slots covered by the changed-variable bitmasks (always all).
-__host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t list_cap, uint32_t mask_slots) {
+__host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t list_cap, uint32_t mask_slots, bool packed = false) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t Wv = (mask_slots + 31) / 32;
   Carve c;
   size_t o = 0;
-  c.dom = o; o = up(o + (size_t)row_stride(B) * dom_slots * 8);
+  c.dom = o; o = up(o + (packed ? (size_t)row_stride16(B) * dom_slots * 4 : (size_t)row_stride(B) * dom_slots * 8));
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
@@ -299,9 +359,9 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   return c;
 }
 
-size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block) {
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed) {
   (void)block;
-  Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots);
+  Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots, packed);
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
@@ -310,11 +370,11 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 }
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_STEPS2 = 8, M_STEPS3 = 10 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10 };
 
 struct BlockCtx {
-  int2* dom;    // LDS domains [slot][bp] (LDS variant) or the constants' singleton domains [slot - n_vars] (global variant)
-  uint32_t bp;  // row stride of dom
+  void* dom;    // LDS domains [slot][bp]: int2 (-lb,ub), or packed dwords; global variant: the constants' singletons [slot - n_vars]
+  uint32_t bp;  // row stride of dom, in cells
   uint32_t S, Wv;
   uint32_t* misc;
   int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
@@ -322,20 +382,22 @@ struct BlockCtx {
   uint32_t V;
 };
 
-template <bool GLOBAL>
-struct DomOf { using type = LdsDom; };
-template <>
-struct DomOf<true> { using type = GlobalDom; };
+template <bool PACKED> struct CellOf { using type = int2; };
+template <> struct CellOf<true> { using type = uint32_t; };
 
-template <bool GLOBAL>
-__device__ __forceinline__ typename DomOf<GLOBAL>::type make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr);
-template <>
-__device__ __forceinline__ LdsDom make_dom<false>(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
-  return LdsDom{k.dom + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
-}
-template <>
-__device__ __forceinline__ GlobalDom make_dom<true>(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
-  return GlobalDom{k.glb, k.gub, k.dom, k.V, chg_next, &k.misc[M_FAIL], 1u, ctr};  // one node per block
+template <bool GLOBAL, bool PACKED> struct DomOf { using type = LdsDom; };
+template <> struct DomOf<false, true> { using type = LdsDom16; };
+template <bool PACKED> struct DomOf<true, PACKED> { using type = GlobalDom; };
+
+template <bool GLOBAL, bool PACKED>
+__device__ __forceinline__ typename DomOf<GLOBAL, PACKED>::type make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
+  if constexpr (GLOBAL) {
+    return GlobalDom{k.glb, k.gub, static_cast<int2*>(k.dom), k.V, chg_next, &k.misc[M_FAIL], 1u, ctr};  // one node per block
+  } else if constexpr (PACKED) {
+    return LdsDom16{static_cast<uint32_t*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
+  } else {
+    return LdsDom{static_cast<int2*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
+  }
 }
 
 // Fast predicate of one binary kind on the domains read for one node: a wave mask straight out of v_cmp.
@@ -359,49 +421,64 @@ __device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const 
 // one address register, all issued before the first compare so that the LDS latency is paid once per group;
 // then two or three compares per node and scalar mask logic.  (word,node) pairs with a flagged live lane are
 // returned in the bitmask for the full filter.
-template <int KIND, int B>
-__device__ __forceinline__ uint32_t fast_nodes(const int2* px, const int2* py, const int d, const uint64_t live4, const uint32_t j) {
-  // live4: lane b*kChunk + j holds word j of node b (see sweep_fast)
+template <int KIND, int B, bool PACKED, int NL>
+__device__ __forceinline__ uint32_t fast_nodes(const typename CellOf<PACKED>::type* px, const typename CellOf<PACKED>::type* py, const int d,
+                                               const uint64_t (&live)[NL], const uint32_t j) {
+  // live[h]: lane (b & 15) * kChunk + j holds word j of node b = 16 h + (b & 15)   (see sweep_fast)
   uint32_t todo = 0;
-  if (B == 1) {
-    const uint64_t word = readlane64(live4, j);
+  if constexpr (B == 1) {
+    const uint64_t word = readlane64(live[0], j);
     if (word) {
       const int2 X = px[0], Y = py[0];  // stored as (-lb, ub)
       if (fast_flag<KIND>(make_int2(-X.x, X.y), d - Y.x, Y.y + d) & word) todo = 1;
     }
     return todo;
-  }
-  constexpr int G = (B % 4 == 0) ? 4 : 2;
+  } else {
+    constexpr int G = (B % 4 == 0) ? 4 : 2;
 #pragma unroll
-  for (int g = 0; g < B; g += G) {
-    uint64_t wd[G];
-    uint64_t any = 0;
+    for (int g = 0; g < B; g += G) {
+      uint64_t wd[G];
+      uint64_t any = 0;
 #pragma unroll
-    for (int jj = 0; jj < G; ++jj) { wd[jj] = readlane64(live4, (uint32_t)(g + jj) * 4u + j); any |= wd[jj]; }
-    if (any == 0) continue;
-    int4 Xp[G / 2], Yp[G / 2];
+      for (int jj = 0; jj < G; ++jj) { wd[jj] = readlane64(live[(g + jj) >> 4], (uint32_t)((g + jj) & 15) * 4u + j); any |= wd[jj]; }
+      if (any == 0) continue;
+      if constexpr (PACKED) {
+        static_assert(!PACKED || G == 4, "packed tiles hold a multiple of four nodes");
+        const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g, 16));
+        const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g, 16));
+        const uint32_t xs[4] = {Xq.x, Xq.y, Xq.z, Xq.w}, ys[4] = {Yq.x, Yq.y, Yq.z, Yq.w};
 #pragma unroll
-    for (int jj = 0; jj < G / 2; ++jj) {
-      Xp[jj] = *static_cast<const int4*>(__builtin_assume_aligned(px + g + 2 * jj, 16));
-      Yp[jj] = *static_cast<const int4*>(__builtin_assume_aligned(py + g + 2 * jj, 16));
+        for (int jj = 0; jj < 4; ++jj) {
+          const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
+          const uint64_t f = fast_flag<KIND>(X, Y.x + d, Y.y + d) & wd[jj];
+          todo |= f ? (1u << (g + jj)) : 0u;
+        }
+      } else {
+        int4 Xp[G / 2], Yp[G / 2];
+#pragma unroll
+        for (int jj = 0; jj < G / 2; ++jj) {
+          Xp[jj] = *static_cast<const int4*>(__builtin_assume_aligned(px + g + 2 * jj, 16));
+          Yp[jj] = *static_cast<const int4*>(__builtin_assume_aligned(py + g + 2 * jj, 16));
+        }
+#pragma unroll
+        for (int jj = 0; jj < G / 2; ++jj) {
+          // LDS holds (-lb, ub)
+          const uint64_t f0 = fast_flag<KIND>(make_int2(-Xp[jj].x, Xp[jj].y), d - Yp[jj].x, Yp[jj].y + d) & wd[2 * jj];
+          const uint64_t f1 = fast_flag<KIND>(make_int2(-Xp[jj].z, Xp[jj].w), d - Yp[jj].z, Yp[jj].w + d) & wd[2 * jj + 1];
+          todo |= f0 ? (1u << (g + 2 * jj)) : 0u;
+          todo |= f1 ? (1u << (g + 2 * jj + 1)) : 0u;
+        }
+      }
     }
-#pragma unroll
-    for (int jj = 0; jj < G / 2; ++jj) {
-      // LDS holds (-lb, ub)
-      const uint64_t f0 = fast_flag<KIND>(make_int2(-Xp[jj].x, Xp[jj].y), d - Yp[jj].x, Yp[jj].y + d) & wd[2 * jj];
-      const uint64_t f1 = fast_flag<KIND>(make_int2(-Xp[jj].z, Xp[jj].w), d - Yp[jj].z, Yp[jj].w + d) & wd[2 * jj + 1];
-      todo |= f0 ? (1u << (g + 2 * jj)) : 0u;
-      todo |= f1 ? (1u << (g + 2 * jj + 1)) : 0u;
-    }
+    return __builtin_amdgcn_readfirstlane(todo);
   }
-  return __builtin_amdgcn_readfirstlane(todo);
 }
 
 // slot * BP (BP = B + 2) with the full-rate 24-bit multiply (slots < 2^26 / B fit): a 32-bit v_mul_lo_u32 is a
 // quarter-rate VALU op on gfx950, and hipcc folds shift-add sequences back into it.
-template <int B>
+template <int B, bool PACKED = false>
 __device__ __forceinline__ uint32_t slot_row(uint32_t v) {
-  return B == 1 ? v : __umul24(v, (uint32_t)(B + 2));
+  return B == 1 ? v : __umul24(v, (uint32_t)(PACKED ? B + 4 : B + 2));
 }
 
 // First-level test of the fast path: ONE sign word per lane for ALL the nodes of the tile, liveness ignored.
@@ -459,6 +536,161 @@ __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const 
   return (m1 + c1) | (m2 + c3);
 }
 
+// The same test on packed tiles (LdsDom16: low half -lb, high half ub).  One v_pk_add_u16 forms both NEQ terms of a
+// node — X + swap(Y) = (Xn + Yu, Xu + Yn), the half swap is an op_sel modifier — and one v_pk_min_i16 keeps the two
+// running minima: 2 VALU and a quarter of a ds_read_b128 per (record,node).  |bound| <= kPackedMax keeps every sum
+// inside int16; the folded offset is added in 32 bits at the end.
+// The packed ops are written as inline asm, four nodes (one ds_read_b128 per operand) per block: from the generic vector
+// form hipcc scalarised the running minimum into v_add_u16_sdwa / v_lshrrev / v_min3_i16 chains (about twice the
+// instructions), and between single-instruction asm statements it pads every dependence with an s_nop.
+// op_sel:[0,1] op_sel_hi:[1,0] = (x.lo + y.hi, x.hi + y.lo).
+__device__ __forceinline__ void neq4_16(uint32_t& mn, const uint4 X, const uint4 Y) {
+  uint32_t t0, t1, t2, t3;
+  asm("v_pk_add_u16 %1, %5, %9 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %2, %6, %10 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %3, %7, %11 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %4, %8, %12 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_min_i16 %1, %1, %2\n\t"
+      "v_pk_min_i16 %3, %3, %4\n\t"
+      "v_pk_min_i16 %0, %0, %1\n\t"
+      "v_pk_min_i16 %0, %0, %3"
+      : "+v"(mn), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
+}
+__device__ __forceinline__ void lt4_16(uint32_t& mn, uint32_t& mx, uint32_t& mn3, const uint4 X, const uint4 Y) {
+  uint32_t t0, t1, t2, t3;
+  asm("v_pk_sub_i16 %3, %7, %11\n\t"
+      "v_pk_sub_i16 %4, %8, %12\n\t"
+      "v_pk_sub_i16 %5, %9, %13\n\t"
+      "v_pk_sub_i16 %6, %10, %14\n\t"
+      "v_pk_min_i16 %0, %0, %3\n\t"
+      "v_pk_max_i16 %1, %1, %3\n\t"
+      "v_pk_min_i16 %0, %0, %4\n\t"
+      "v_pk_max_i16 %1, %1, %4\n\t"
+      "v_pk_min_i16 %0, %0, %5\n\t"
+      "v_pk_max_i16 %1, %1, %5\n\t"
+      "v_pk_min_i16 %0, %0, %6\n\t"
+      "v_pk_max_i16 %1, %1, %6\n\t"
+      "v_pk_add_u16 %3, %7, %11 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %4, %8, %12 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %5, %9, %13 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %6, %10, %14 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_min_i16 %3, %3, %4\n\t"
+      "v_pk_min_i16 %5, %5, %6\n\t"
+      "v_pk_min_i16 %2, %2, %3\n\t"
+      "v_pk_min_i16 %2, %2, %5"
+      : "+v"(mn), "+v"(mx), "+v"(mn3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
+}
+__device__ __forceinline__ int lo16(uint32_t v) { return (int)(short)(v & 0xffffu); }
+__device__ __forceinline__ int hi16(uint32_t v) { return (int)v >> 16; }
+
+template <int KIND, int B>
+__device__ __forceinline__ int fast_signs16(const uint32_t* px, const uint32_t* py, const int d) {
+  static_assert(B % 4 == 0, "packed tiles hold a multiple of four nodes");
+  const int c1 = d - 1, c2 = -d - 1, c3 = -d;
+  uint32_t mn = 0x7fff7fffu, mn3 = 0x7fff7fffu, mx = 0x80008000u;
+#pragma unroll
+  for (int g = 0; g < B; g += 4) {
+    uint32_t xs[4], ys[4];
+    if (PCP_ABLATE & 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { xs[i] = (uint32_t)(size_t)px + g + i; ys[i] = (uint32_t)(size_t)py ^ (g + i); }
+    } else {
+      const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g, 16));
+      const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g, 16));
+      xs[0] = Xq.x; xs[1] = Xq.y; xs[2] = Xq.z; xs[3] = Xq.w;
+      ys[0] = Yq.x; ys[1] = Yq.y; ys[2] = Yq.z; ys[3] = Yq.w;
+    }
+    if (PCP_ABLATE & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mn &= xs[i] ^ ys[i];
+      continue;
+    }
+    const uint4 X4 = make_uint4(xs[0], xs[1], xs[2], xs[3]), Y4 = make_uint4(ys[0], ys[1], ys[2], ys[3]);
+    if (KIND == PCP_NEQ) neq4_16(mn, X4, Y4);   // running min of (Xn + Yu, Xu + Yn)
+    else lt4_16(mn, mx, mn3, X4, Y4);           // mn.lo: min (Xn - Yn); mx.hi: max (Xu - Yu); mn3.hi: min (Xu + Yn)
+  }
+  if (KIND == PCP_NEQ) return (lo16(mn) + c1) | (hi16(mn) + c2);
+  return (lo16(mn) + c1) | (c1 - hi16(mx)) | (hi16(mn3) + c3);
+}
+
+// ---- the same test in pipelined form (whole-chunk fast block of sweep_fast) -----------------------------------------
+// A unit = the rows of one record for 8 packed / 4 unpacked nodes = 2 + 2 ds_read_b128 = 16 VGPRs.  The fast block walks
+// the units of a chunk with two row buffers: the reads of unit u+1 are issued before the arithmetic of unit u.
+constexpr int kUnitRows = 2;  // ds_read_b128 per operand and unit
+struct Rows { uint4 x[kUnitRows], y[kUnitRows]; };
+struct SignAcc { uint32_t a, b, c; };  // packed: mn, mx, mn3;  unpacked: m1, m2 (as int bits)
+template <bool PACKED> struct UnitNodes { static constexpr int value = (PACKED ? 4 : 2) * kUnitRows; };
+
+template <bool PACKED>
+__device__ __forceinline__ void load_unit(Rows& r, const typename CellOf<PACKED>::type* px, const typename CellOf<PACKED>::type* py, int g0) {
+  // g0: first node of the unit; 16 bytes = 4 packed cells or 2 int2 cells
+  constexpr int kPer = PACKED ? 4 : 2;
+#pragma unroll
+  for (int i = 0; i < kUnitRows; ++i) {
+    r.x[i] = *static_cast<const uint4*>(__builtin_assume_aligned(px + g0 + kPer * i, 16));
+    r.y[i] = *static_cast<const uint4*>(__builtin_assume_aligned(py + g0 + kPer * i, 16));
+  }
+}
+template <bool PACKED>
+__device__ __forceinline__ SignAcc acc_init() {
+  if (PACKED) return SignAcc{0x7fff7fffu, 0x80008000u, 0x7fff7fffu};
+  return SignAcc{0x7fffffffu, 0x7fffffffu, 0u};
+}
+template <int KIND, bool PACKED>
+__device__ __forceinline__ void accumulate(SignAcc& s, const Rows& r) {
+#pragma unroll
+  for (int i = 0; i < kUnitRows; ++i) {
+    if constexpr (PACKED) {
+      if (KIND == PCP_NEQ) neq4_16(s.a, r.x[i], r.y[i]);
+      else lt4_16(s.a, s.b, s.c, r.x[i], r.y[i]);
+    } else {
+      // (-lb, ub) pairs of two nodes per 16 bytes
+      const int xn0 = (int)r.x[i].x, xu0 = (int)r.x[i].y, xn1 = (int)r.x[i].z, xu1 = (int)r.x[i].w;
+      const int yn0 = (int)r.y[i].x, yu0 = (int)r.y[i].y, yn1 = (int)r.y[i].z, yu1 = (int)r.y[i].w;
+      int m1 = (int)s.a, m2 = (int)s.b;
+      if (KIND == PCP_NEQ) {
+        m1 = min(min(m1, yu0 + xn0), yu1 + xn1);
+        m2 = min(min(m2, xu0 + yn0), xu1 + yn1);
+      } else {
+        m1 = min(min(m1, yu0 - xu0), xn0 - yn0);
+        m1 = min(min(m1, yu1 - xu1), xn1 - yn1);
+        m2 = min(min(m2, xu0 + yn0), xu1 + yn1);
+      }
+      s.a = (uint32_t)m1; s.b = (uint32_t)m2;
+    }
+  }
+}
+template <int KIND, bool PACKED>
+__device__ __forceinline__ int acc_finish(const SignAcc& s, const int d) {
+  const int c1 = d - 1, c2 = -d - 1, c3 = -d;
+  if constexpr (PACKED) {
+    if (KIND == PCP_NEQ) return (lo16(s.a) + c1) | (hi16(s.a) + c2);
+    return (lo16(s.a) + c1) | (c1 - hi16(s.b)) | (hi16(s.c) + c3);
+  } else {
+    if (KIND == PCP_NEQ) return ((int)s.a + c1) | ((int)s.b + c2);
+    return ((int)s.a + c1) | ((int)s.b + c3);
+  }
+}
+// o[j] for the four words of a chunk, units double-buffered.
+template <int KIND, int B, bool PACKED>
+__device__ __forceinline__ void chunk_signs(int (&o)[4], const typename CellOf<PACKED>::type* const (&px)[4],
+                                            const typename CellOf<PACKED>::type* const (&py)[4], const int (&d)[4]) {
+  constexpr int UN = UnitNodes<PACKED>::value, UPW = B / UN, U = 4 * UPW;
+  static_assert(B % UN == 0 && UPW >= 1, "tile must be a whole number of units");
+  Rows r[2];
+  SignAcc acc = acc_init<PACKED>();
+  load_unit<PACKED>(r[0], px[0], py[0], 0);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (u + 1 < U) load_unit<PACKED>(r[(u + 1) & 1], px[(u + 1) / UPW], py[(u + 1) / UPW], ((u + 1) % UPW) * UN);
+    accumulate<KIND, PACKED>(acc, r[u & 1]);
+    if (u % UPW == UPW - 1) { o[u / UPW] = acc_finish<KIND, PACKED>(acc, d[u / UPW]); acc = acc_init<PACKED>(); }
+    __builtin_amdgcn_sched_barrier(0);  // keep the source order: hipcc otherwise clusters the reads of a whole word up front
+  }
+}
+
 // OR of a 32-bit value over the 16 lanes of each DPP row (quad swaps, then half-mirror, then mirror).
 __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
   v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
@@ -506,21 +738,30 @@ __device__ __forceinline__ Rec expand(const Rec8 q) {
 }
 __device__ __forceinline__ Rec expand(const Rec r) { return r; }
 
-template <int B, bool GLOBAL, bool COMPACT>
+template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
-  static_assert(B * kChunk <= 64, "node*CHUNK+j must fit in the 64 lanes");
+  static_assert(B <= 32 && (B <= 16 || PACKED), "node*CHUNK+j must fit in the 64 lanes of one or two live registers");
   static_assert(kChunk == 4, "the hot loop is written for four record buffers");
+  constexpr int NL = B > 16 ? 2 : 1;  // live registers per lane: register h carries nodes 16h .. 16h+15
+  using Cell = typename CellOf<PACKED>::type;
+  const Cell* const kdom = static_cast<const Cell*>(k.dom);
   const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
   const uint64_t* live_src = a.live_in;
-  const uint32_t bq = lane / kChunk, jq = lane % kChunk;  // this lane's (node, word-in-chunk) for the live-mask I/O
-  const bool io = bq < nb;
-  const uint32_t my_node = node0 + (io ? bq : 0);
-  const uint64_t* my_in = live_src ? live_src + (size_t)my_node * words : nullptr;
-  uint64_t* my_out = a.live + (size_t)my_node * words;
+  const uint32_t bq = lane / kChunk, jq = lane % kChunk;  // this lane's (node mod 16, word-in-chunk) for the live-mask I/O
+  bool io[NL];
+  const uint64_t* my_in[NL];
+  uint64_t* my_out[NL];
+#pragma unroll
+  for (int h = 0; h < NL; ++h) {
+    io[h] = bq + 16u * h < nb;
+    const uint32_t my_node = node0 + (io[h] ? bq + 16u * h : 0u);
+    my_in[h] = live_src ? live_src + (size_t)my_node * words : nullptr;
+    my_out[h] = a.live + (size_t)my_node * words;
+  }
   const uint32_t c0 = w0 / kChunk, c1 = (w1 + kChunk - 1) / kChunk;  // w0 is a multiple of kChunk
   // The stream is latency-bound, not bandwidth-bound: with one 1-KiB record load in flight per wavefront a CU moves
   // 16 KiB per memory round trip (measured: the loop skeleton alone took 73 % of the kernel).  So every wavefront
@@ -529,10 +770,10 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   // hipcc can then count them and wait with vmcnt(N>0) for the oldest load while the younger ones stay in flight; a
   // load under a divergent guard makes it fall back to vmcnt(0).
   const uint32_t last_word = words - 1;
-  auto fetch_live = [&](uint32_t c) -> uint64_t {
+  auto fetch_live = [&](uint32_t c, int h) -> uint64_t {
     const uint32_t w = c * kChunk + jq;
-    const uint64_t v = (my_in && !(PCP_ABLATE & 8)) ? my_in[min(w, last_word)] : ~0ull;
-    const bool ok = c < c1 && io && w < w1;
+    const uint64_t v = (my_in[h] && !(PCP_ABLATE & 8)) ? my_in[h][min(w, last_word)] : ~0ull;
+    const bool ok = c < c1 && io[h] && w < w1;
     return ok ? (w == last_word ? v & tail_mask : v) : 0ull;
   };
   using RecT = typename std::conditional<COMPACT, Rec8, Rec>::type;
@@ -540,51 +781,142 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
   auto fetch_rec = [&](uint32_t w) -> RecT {  // lanes past the last record read the last record; their live bit is 0
     const uint32_t r = min((min(w, last_word) << 6) + lane, P - 1);
+    if (PCP_ABLATE & 4) {  // profiling: no record stream (a synthetic NEQ record)
+      RecT q;
+      if constexpr (COMPACT) { q.xyk = (r & 511u) | (((r >> 3) & 511u) << 15); q.d = (int)(r & 7u); }
+      else { q.xk = r & 511u; q.y = (r >> 3) & 511u; q.z = 0; q.d = (int)(r & 7u); }
+      return q;
+    }
     return rec_stream[r];
   };
-  uint32_t steps_lane = 0, rem_acc = 0;
-  uint64_t live_n = fetch_live(c0 + wave);
-  RecT buf[kChunk];
+  // word j of node b sits in lane (b & 15) * kChunk + j of live register b >> 4
+  auto word_of = [&](const uint64_t (&reg)[NL], uint32_t b, uint32_t j) -> uint64_t {
+    const uint32_t l = (b & 15u) * kChunk + j;
+    if (NL == 1) return readlane64(reg[0], l);
+    const uint64_t lo = readlane64(reg[0], l), hi = readlane64(reg[NL - 1], l);
+    return b < 16u ? lo : hi;
+  };
+  uint32_t steps_lane = 0, rem_acc[NL];
 #pragma unroll
-  for (int j = 0; j < kChunk; ++j) buf[j] = fetch_rec((c0 + wave) * kChunk + j);
-  for (uint32_t c = c0 + wave; c < c1; c += nw) {
-    const uint64_t loaded = live_n;
-    live_n = fetch_live(c + nw);
-    uint64_t my_new = loaded;
+  for (int h = 0; h < NL; ++h) rem_acc[h] = 0;
+  // Two stages in ping-pong: while one chunk is processed the loads of this wavefront's next chunk are in flight, and
+  // each stage is reloaded only after its last use, straight into the registers it is read from.  (A single rotating
+  // buffer looked equivalent in the source, but its reload overlapped the last use of the old value, so hipcc loaded
+  // into fresh registers and ended every iteration with s_waitcnt vmcnt(0) + copies: the prefetch was waited for in
+  // the iteration that issued it.)
+  struct Stage { RecT buf[kChunk]; uint64_t live[NL]; };
+  auto issue = [&](Stage& st, uint32_t c) {
+#pragma unroll
+    for (int h = 0; h < NL; ++h) st.live[h] = fetch_live(c, h);
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j) st.buf[j] = fetch_rec(c * kChunk + j);
+  };
+  uint64_t seg[4] = {0, 0, 0, 0}, segw = 0;  // PCP_ABLATE & 128: s_memtime ticks per segment of process()
+  auto process = [&](const uint32_t c, const Stage& st) {
+    const uint64_t tm0 = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t loaded[NL], my_new[NL];
+    uint64_t any_live = 0;
+#pragma unroll
+    for (int h = 0; h < NL; ++h) {
+      loaded[h] = st.live[h];
+      my_new[h] = loaded[h];
+      any_live |= loaded[h];
+    }
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // alive4: lane l holds the OR over the tile's nodes of word (l & 3) — the records of that word that are live in
     // at least one node.  A record that is dead in every node of the tile (entailed higher up the search tree:
     // siblings share their ancestors' entailments) must not drag its word onto the cold path.
-    const uint64_t alive4 = or_mod4_64(loaded);
-    // ---- hot part, unrolled: level-1 test of the four words; anything else is only noted in `slow` --------------
+    const uint64_t alive4 = or_mod4_64(any_live);
+    uint64_t tm1 = 0;
+    if (PCP_ABLATE & 128) { tm1 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)alive4) & 0u); seg[0] += tm1 - tm0; }
+    // ---- hot part: level-1 test of the four words; anything else is only noted in `slow` -------------------------
     uint32_t slow = 0;
+    // Whole-chunk fast block: the 4 x 64 records are of ONE binary kind (NEQ or LT), every word has a live record, no
+    // node of the tile has failed.  Straight-line code, so the LDS reads of the next word are issued under the
+    // arithmetic of the current one and the per-word kind / liveness tests and branches disappear.
+    bool chunk_fast = false;
+    uint32_t ckind = 0;
+    if constexpr (!GLOBAL) {
+      uint32_t k_or = 0, k_and = ~0u;
 #pragma unroll
-    for (int j = 0; j < kChunk; ++j) {
-      const Rec rec = expand(buf[j]);
-      buf[j] = fetch_rec((c + nw) * kChunk + j);
-      const uint32_t w = c * kChunk + j;
-      if (w < w1) {
-        const uint32_t kind = rec.xk >> 28;
-        const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
-        if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
-          const uint64_t alive = readlane64(alive4, j);
-          if (alive) {  // some record of this word is live in some node
-            if (kind0 == PCP_EQ) {
-              slow |= 1u << j;
-            } else {
-              const int2* px = k.dom + slot_row<B>(rec.xk & kSlotMask);
-              const int2* py = k.dom + slot_row<B>(rec.y);
-              const int o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
-              if (__ballot(o < 0) & alive) slow |= 1u << j;
+      for (int j = 0; j < kChunk; ++j) {
+        uint32_t kj;
+        if constexpr (COMPACT) kj = st.buf[j].xyk >> 30; else kj = st.buf[j].xk >> 28;
+        k_or |= kj; k_and &= kj;
+      }
+      ckind = __builtin_amdgcn_readfirstlane(k_or);
+      const bool alive_all = (__ballot(alive4 != 0) & 0xFull) == 0xFull;  // lanes 0..3 hold the OR masks of words 0..3
+      chunk_fast = __all(k_or == k_and && k_or == ckind) && (ckind == PCP_NEQ || ckind == PCP_LT) && failm == 0 &&
+                   c * kChunk + (kChunk - 1) < w1 && alive_all;
+    }
+    if (chunk_fast) {
+      int o[kChunk];
+      uint64_t tw = 0;
+      if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(st.buf[0].d) & 0);
+      const Cell* px[kChunk];
+      const Cell* py[kChunk];
+      int dd[kChunk];
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const Rec rec = expand(st.buf[j]);
+        px[j] = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+        py[j] = kdom + slot_row<B, PACKED>(rec.y);
+        dd[j] = rec.d;
+      }
+      if constexpr (B % UnitNodes<PACKED>::value == 0) {
+        if (ckind == PCP_NEQ) chunk_signs<PCP_NEQ, B, PACKED>(o, px, py, dd);
+        else chunk_signs<PCP_LT, B, PACKED>(o, px, py, dd);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+          if constexpr (PACKED) o[j] = (ckind == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px[j], py[j], dd[j]) : fast_signs16<PCP_LT, B>(px[j], py[j], dd[j]);
+          else o[j] = (ckind == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px[j], py[j], dd[j]) : fast_signs<PCP_LT, B>(px[j], py[j], dd[j]);
+        }
+      }
+      if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(o[0] | o[1] | o[2] | o[3]) & 0) - tw;
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j)
+        if (__ballot(o[j] < 0) & readlane64(alive4, j)) slow |= 1u << j;
+#pragma unroll
+      for (int h = 0; h < NL; ++h) steps_lane += __popcll(loaded[h]);  // every live record of every node runs once
+    } else {
+  #pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const Rec rec = expand(st.buf[j]);
+        const uint32_t w = c * kChunk + j;
+        if (w < w1) {
+          const uint32_t kind = rec.xk >> 28;
+          const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+          if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+            const uint64_t alive = readlane64(alive4, j);
+            if (alive) {  // some record of this word is live in some node
+              if (kind0 == PCP_EQ) {
+                slow |= 1u << j;
+              } else {
+                const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+                const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
+                int o;
+                uint64_t tw = 0;
+                if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(rec.d) & 0);
+                if constexpr (PACKED) o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
+                else o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+                if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(o) & 0) - tw;
+                if (__ballot(o < 0) & alive) slow |= 1u << j;
+              }
             }
+            if (jq == (uint32_t)j) {  // every live record of every node runs once
+  #pragma unroll
+              for (int h = 0; h < NL; ++h) steps_lane += __popcll(loaded[h]);
+            }
+          } else {
+            slow |= 16u << j;  // mixed kinds / ternary / a failed node in the tile / HBM-resident domains
           }
-          if (jq == (uint32_t)j) steps_lane += __popcll(loaded);  // every live record of every node runs once
-        } else {
-          slow |= 16u << j;  // mixed kinds / ternary / a failed node in the tile / HBM-resident domains
         }
       }
     }
     if (PCP_ABLATE & 16) slow = 0;
+    uint64_t tm2 = 0;
+    if (PCP_ABLATE & 128) { tm2 = __builtin_amdgcn_s_memtime() + (slow & 0u); seg[1] += tm2 - tm1; }
     // ---- cold part, one rolled copy: flagged words (level 2 + full filter) and words outside the fast path ---------
     while (slow) {
       const uint32_t jb = __builtin_ctz(slow);
@@ -597,19 +929,16 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       uint32_t todo = 0;  // nodes to run with the full filter
       if (!generic) {
         const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
-        const int2* px = k.dom + slot_row<B>(rec.xk & kSlotMask);
-        const int2* py = k.dom + slot_row<B>(rec.y);
-        if (kind0 == PCP_EQ) {
-          todo = fast_nodes<PCP_EQ, B>(px, py, rec.d, loaded, j);
-        } else {
-          // the hot part has already established that a record live somewhere in the tile is flagged
-          if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B>(px, py, rec.d, loaded, j);
-          else todo = fast_nodes<PCP_LT, B>(px, py, rec.d, loaded, j);
-        }
+        const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+        const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
+        // (for NEQ / LT the hot part has already established that a record live somewhere in the tile is flagged)
+        if (kind0 == PCP_EQ) todo = fast_nodes<PCP_EQ, B, PACKED, NL>(px, py, rec.d, loaded, j);
+        else if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B, PACKED, NL>(px, py, rec.d, loaded, j);
+        else todo = fast_nodes<PCP_LT, B, PACKED, NL>(px, py, rec.d, loaded, j);
       } else {
         const bool tern = kind > PCP_LT;
         for (uint32_t b = 0; b < nb; ++b) {
-          const uint64_t word = readlane64(loaded, b * kChunk + j);
+          const uint64_t word = word_of(loaded, b, j);
           if (word == 0 || ((failm >> b) & 1u)) continue;
           todo |= 1u << b;
           const uint64_t t3 = __ballot(((word >> lane) & 1ull) && tern);
@@ -620,29 +949,55 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       while (todo) {
         const uint32_t b = __builtin_ctz(todo);
         todo &= todo - 1;
-        const uint64_t word = readlane64(loaded, b * kChunk + j);
+        const uint64_t word = word_of(loaded, b, j);
         bool e = false;
         if ((word >> lane) & 1ull) {
-          const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
+          const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
           e = eval_record(rec, dm);
         }
-        my_new = writelane64(my_new, word & ~__ballot(e), b * kChunk + j);
+        const uint64_t nw_word = word & ~__ballot(e);
+        const uint32_t l = (b & 15u) * kChunk + j;
+        if (NL == 1 || b < 16u) my_new[0] = writelane64(my_new[0], nw_word, l);
+        else my_new[NL - 1] = writelane64(my_new[NL - 1], nw_word, l);
       }
     }
+    uint64_t tm3 = 0;
+    if (PCP_ABLATE & 128) { tm3 = __builtin_amdgcn_s_memtime(); seg[2] += tm3 - tm2; }
     const uint32_t wl = c * kChunk + jq;
-    if (io && wl < w1) {
-      rem_acc += __popcll(my_new);
-      if (!(PCP_ABLATE & 8) && (live_src != a.live || my_new != loaded)) my_out[wl] = my_new;
+#pragma unroll
+    for (int h = 0; h < NL; ++h) {
+      if (io[h] && wl < w1) {
+        rem_acc[h] += __popcll(my_new[h]);
+        if (!(PCP_ABLATE & 8) && (live_src != a.live || my_new[h] != loaded[h])) my_out[h][wl] = my_new[h];
+      }
     }
+    if (PCP_ABLATE & 128) seg[3] += __builtin_amdgcn_s_memtime() - tm3;
+  };
+  Stage sa, sb;
+  issue(sa, c0 + wave);
+  for (uint32_t c = c0 + wave; c < c1; c += 2 * nw) {
+    issue(sb, c + nw);
+    process(c, sa);
+    issue(sa, c + 2 * nw);
+    if (c + nw < c1) process(c + nw, sb);
   }
-  if (io && rem_acc) atomicAdd(&remaining[bq], rem_acc);
+#pragma unroll
+  for (int h = 0; h < NL; ++h)
+    if (io[h] && rem_acc[h]) atomicAdd(&remaining[bq + 16u * h], rem_acc[h]);
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
+  if ((PCP_ABLATE & 128) && lane == 0) {  // profiling build: per-segment ticks summed over all wavefronts
+    atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)segw);
+    atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)seg[0]);
+    atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)seg[1]);
+    atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)seg[2]);
+    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)seg[3]);
+  }
 }
 
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
 // the live records that touch a variable in `cur`.  Rare path, generic code.
-template <bool GLOBAL>
+template <bool GLOBAL, bool PACKED>
 __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, const uint32_t* cur,
                                                uint32_t* chg_next, uint32_t& rem_sub, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -668,7 +1023,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
       const bool mine = ((word >> lane) & 1ull) && touched;
       bool e = false;
       if (mine) {
-        const auto dm = make_dom<GLOBAL>(k, b, chg_next, &ctr);
+        const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
         e = eval_record(rec, dm);
       }
       const uint64_t run = __ballot(mine), t3 = __ballot(mine && tern);
@@ -686,17 +1041,20 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 // ------------------------------------------------------------------------------------------------
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
-template <int B, bool GLOBAL, bool COMPACT>
+template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   static_assert(!GLOBAL || B == 1, "the global-domain variant runs one node per block");
+  static_assert(!PACKED || (!GLOBAL && B >= 8 && B % 4 == 0), "packed tiles: LDS-resident, a multiple of four nodes");
+  static_assert(B <= 32, "fail / todo masks are 32 bits wide");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
   const uint32_t team = a.team, C = a.list_cap;
-  constexpr uint32_t BP = (B == 1) ? 1u : (uint32_t)B + 2u;
+  constexpr uint32_t BP = PACKED ? (uint32_t)B + 4u : ((B == 1) ? 1u : (uint32_t)B + 2u);
+  using Cell = typename CellOf<PACKED>::type;
   // global variant: only the constants' singleton domains are kept in LDS (slots n_vars..S-1)
-  const Carve cv = carve(GLOBAL ? S - V : S, B, C, S);
-  int2* dom = reinterpret_cast<int2*>(smem + cv.dom);
+  const Carve cv = carve(GLOBAL ? S - V : S, B, C, S, PACKED);
+  Cell* dom = reinterpret_cast<Cell*>(smem + cv.dom);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
   uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
   uint32_t* list_id = reinterpret_cast<uint32_t*>(smem + cv.list_id);
@@ -708,6 +1066,12 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   uint32_t node0, nb, g;
   if (team > 1) { node0 = blockIdx.x / team; g = blockIdx.x % team; nb = 1; }
   else { node0 = blockIdx.x * B; g = 0; nb = min((uint32_t)B, a.n_nodes - node0); }
+  if (a.only_marked) {
+    // second launch of a packed call (pcp_api.hip): only the tiles the packed kernel handed back.  A packed tile is
+    // two of these tiles, so all nodes of this tile carry the same mark.
+    if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
+    if (a.status[node0] != kStatusRetry) return;
+  }
   const BlockCtx k{dom, BP, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
@@ -715,7 +1079,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   if (tid < (uint32_t)B) remaining[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   __syncthreads();
-  if (GLOBAL) {
+  if constexpr (GLOBAL) {
     // the node's rows in lb_out/ub_out ARE the working domains (the host copied the inputs there); only check them
     bool bad = false;
     if (g == 0)
@@ -727,18 +1091,32 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       const bool real = b < nb;
       const int32_t* lbp = a.lb_in + (size_t)(node0 + (real ? b : 0)) * V;
       const int32_t* ubp = a.ub_in + (size_t)(node0 + (real ? b : 0)) * V;
-      bool bad = false;
+      bool bad = false, oob = false;
       for (uint32_t v = tid; v < S; v += nth) {
         int2 d;
         if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
         else { d.x = d.y = a.m.const_val[v - V]; }
-        d.x = -d.x;                   // LDS holds (-lb, ub)
-        dom[(size_t)v * BP + b] = d;  // missing nodes of a tail tile mirror node 0: readable, never used
+        // missing nodes of a tail tile mirror node 0: readable, never used
+        if constexpr (PACKED) {
+          oob |= (d.x < -kPackedMax) | (d.x > kPackedMax) | (d.y < -kPackedMax) | (d.y > kPackedMax);
+          dom[(size_t)v * BP + b] = pack16(d.x, d.y);
+        } else {
+          d.x = -d.x;                   // LDS holds (-lb, ub)
+          dom[(size_t)v * BP + b] = d;
+        }
       }
       if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
+      if (PACKED && oob) atomicOr(&misc[M_OOB], 1u);
     }
   }
   __syncthreads();
+  if (PACKED && misc[M_OOB]) {
+    // some bound of this tile does not fit the packed cells: hand the tile back untouched (pcp_api.hip launches the
+    // 32-bit kernel right behind this one; it runs exactly the tiles marked here)
+    if (tid < nb) a.status[node0 + tid] = kStatusRetry;
+    if (tid == 0) atomicMax(a.retry_flag, a.epoch);
+    return;
+  }
 
   Ctr ctr;
   uint64_t steps2 = 0, steps3 = 0;
@@ -752,7 +1130,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       w0 = min(words, g * ws); w1 = min(words, w0 + ws);
     }
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
-    if (w0 < w1) sweep_fast<B, GLOBAL, COMPACT>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
+    if (w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
@@ -760,7 +1138,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   __syncthreads();
 
   // ---- phase 2 (team mode): merge this slice into the node's global arrays; the last arriver continues ---
-  if (team > 1) {
+  if constexpr (!PACKED) if (team > 1) {  // (packed tiles never run as a team: B >= 8)
     int32_t* glb = a.lb_out + (size_t)node0 * V;
     int32_t* gub = a.ub_out + (size_t)node0 * V;
     uint32_t* gchg = a.team_chg + (size_t)node0 * Wv;
@@ -880,7 +1258,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) return;
         if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) return;
         if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
-        const auto dm = make_dom<GLOBAL>(k, b, nxt, &ctr);
+        const auto dm = make_dom<GLOBAL, PACKED>(k, b, nxt, &ctr);
         if (tern) ++my3; else ++my2;
         if (eval_record(rec, dm)) {
           uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
@@ -944,7 +1322,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     } else {
       __syncthreads();
       uint32_t rem_sub = 0;
-      sweep_filtered<GLOBAL>(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
+      sweep_filtered<GLOBAL, PACKED>(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
       if (lane < nb && rem_sub) atomicSub(&remaining[lane], rem_sub);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -964,7 +1342,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     atomicMax((unsigned long long*)&a.stats->failed_nodes, t_sweep - t_begin);   // slowest block's sweep
     atomicMax((unsigned long long*)&a.stats->waves, t_end - t_sweep);            // slowest block's rounds
   }
-  if (GLOBAL) {
+  if constexpr (GLOBAL) {
     bool bad = false;  // the domains are already in place; a missed failure shows as an empty domain here
     for (uint32_t v = tid; v < V; v += nth)
       bad |= __hip_atomic_load(&k.glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > __hip_atomic_load(&k.gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -975,9 +1353,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
       bool bad = false;
       for (uint32_t v = tid; v < S; v += nth) {
-        const int2 d = dom[(size_t)v * BP + b];  // (-lb, ub)
-        bad |= -d.x > d.y;
-        if (v < V) { lbp[v] = -d.x; ubp[v] = d.y; }
+        int2 d;  // (lb, ub)
+        if constexpr (PACKED) d = unpack16(dom[(size_t)v * BP + b]);
+        else { const int2 t = dom[(size_t)v * BP + b]; d = make_int2(-t.x, t.y); }
+        bad |= d.x > d.y;
+        if (v < V) { lbp[v] = d.x; ubp[v] = d.y; }
       }
       if (bad) atomicOr(&misc[M_FAIL], 1u << b);
     }
@@ -1165,13 +1545,13 @@ hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, cons
   return hipGetLastError();
 }
 
-template <int B, bool GLOBAL, bool COMPACT>
+template <int B, bool GLOBAL, bool COMPACT, bool PACKED = false>
 static hipError_t launch_k(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL, COMPACT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL, COMPACT, PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL, COMPACT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL, COMPACT, PACKED>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 template <int B>
@@ -1179,9 +1559,19 @@ static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t
   return a.m.recs8 ? launch_k<B, false, true>(a, p, stream) : launch_k<B, false, false>(a, p, stream);
 }
 
-// nodes_per_block must be one of the instantiated tile sizes; global_dom selects the HBM-resident-domain variant.
+// nodes_per_block must be one of the instantiated tile sizes; global_dom selects the HBM-resident-domain variant,
+// packed the 16-bit tiles (compact record stream only).
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.global_dom) return a.nodes_per_block == 1 ? launch_k<1, true, false>(a, p, stream) : hipErrorInvalidValue;
+  if (a.packed) {
+    if (!a.m.recs8) return hipErrorInvalidValue;
+    switch (a.nodes_per_block) {
+      case 8: return launch_k<8, false, true, true>(a, p, stream);
+      case 16: return launch_k<16, false, true, true>(a, p, stream);
+      case 32: return launch_k<32, false, true, true>(a, p, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (a.nodes_per_block) {
     case 1: return launch_b<1>(a, p, stream);
     case 2: return launch_b<2>(a, p, stream);

@@ -30,7 +30,7 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     om = orc.OracleModel(n_vars, props)
     ref = om.consistency(lb, ub, active)
     ctx.set_model(n_vars, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
         ctx.set_option(k, v)
     got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
     assert_parity(ref[:4], got[:4], what)
@@ -107,6 +107,52 @@ def test_random_csp_launch_shapes(ctx, opts):
     both(ctx, V, props, L, U, act, f"shapes {opts}", **opts)
 
 
+@pytest.mark.parametrize("npb", [8, 16, 32])
+@pytest.mark.parametrize("seed", range(3))
+def test_packed_tiles_binary_csp(ctx, npb, seed):
+    """16-bit packed tiles (binary models, every bound within +-16383) against the oracle, and against the 32-bit
+    tiles of the same size; odd seeds are unplanted, so nodes fail and the crossing bounds get clamped."""
+    V, P, N = 90 + 20 * seed, 700 + 150 * seed, 100 + 7 * seed
+    props, lb, ub, sol = random_csp(400 + seed, V, P, planted=seed % 2 == 0, p_tern=0.0, dom=(-40, 60))
+    L, U = random_nodes(500 + seed, lb, ub, N, sol if seed % 2 == 0 else None, p_narrow=0.3 if seed % 2 == 0 else 0.05)
+    act = random_active(600 + seed, N, P, p_off=0.1)
+    both(ctx, V, props, L, U, act, f"packed npb={npb} seed={seed}", nodes_per_block=npb, packed=1)
+    both(ctx, V, props, L, U, act, f"unpacked npb={npb} seed={seed}", nodes_per_block=npb, packed=0)
+
+
+def test_packed_tiles_hand_back_wide_bounds(ctx):
+    """A tile with a bound beyond +-16383 cannot use the packed cells: it is re-run with 32-bit cells inside the same
+    call, the other tiles of the batch stay packed."""
+    V, P, N = 150, 1200, 203
+    props, lb, ub, sol = random_csp(910, V, P, planted=True, p_tern=0.0, dom=(0, 80))
+    L, U = random_nodes(911, lb, ub, N, sol, p_narrow=0.2)
+    rng = np.random.default_rng(912)
+    wide = rng.choice(N, size=9, replace=False)
+    for r in wide:  # supersets of the model's domains are legal inputs
+        v = rng.choice(V, size=3, replace=False)
+        L[r, v[0]] = -20000
+        U[r, v[1]] = 30000
+        L[r, v[2]], U[r, v[2]] = -(1 << 20), (1 << 24)
+    act = random_active(913, N, P, p_off=0.05)
+    for npb in (8, 16, 32):
+        both(ctx, V, props, L, U, act, f"hand-back npb={npb}", nodes_per_block=npb, packed=1)
+    # every tile out of range, in place (lb_in == lb_out inside pcp_propagate)
+    L[:, 0] = -17000
+    both(ctx, V, props, L, U, act, "hand-back all", nodes_per_block=16, packed=1)
+
+
+def test_packed_tiles_nqueens_frontier(ctx):
+    """N-queens-200 breadth-first frontier: packed 32-node tiles, parity with the oracle on every node."""
+    n = 200
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+        ctx.set_option(k, v)
+    from pcp_amd.search import bfs_frontier
+    L, U, A, _ = bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), 300)
+    both(ctx, n, props, L, U, A, "nqueens frontier packed", nodes_per_block=32, packed=1)
+
+
 def test_long_cascade(ctx):
     """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
     n = 300
@@ -132,7 +178,7 @@ def test_nqueens_dfs_nodes(ctx, n):
     ref = (rec["lb_out"][keep], rec["ub_out"][keep], rec["active_out"][keep], rec["status"][keep])
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 5}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(rec["lb_in"][keep], rec["ub_in"][keep], rec["active_in"][keep])
         assert_parity(ref, got[:4], f"nqueens({n}) {opts}")
@@ -155,7 +201,7 @@ def test_nqueens_1000_root_and_dive(ctx):
     ref = om.consistency(L, U, None, check_dup=False)
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 2}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(N, om.n_units))
         assert_parity(ref[:4], got[:4], f"nqueens1000 {opts}")
@@ -179,7 +225,7 @@ def test_golomb_distinct_sum_network(ctx):
     assert (ref[3] == 0).any() and (ref[3] == 2).any()
     ctx.set_model(V, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 2}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, A)
         assert_parity(ref[:4], got[:4], f"golomb {opts}")
@@ -196,7 +242,7 @@ def test_nqueens_global_distinct_search(ctx, n):
     lb0, ub0 = vs.bounds()
     ss, _, _, _ = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
         ctx.set_option(k, v)
     st = S.dfs(ctx, lb0, ub0, all_solutions=True, batch=32)
     assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
@@ -213,7 +259,7 @@ def test_config3_random_binary_csp_full_size(ctx):
     assert (ref[3] == 2).all() and ((ref[0] != L) | (ref[1] != U)).sum() > V
     ctx.set_model(V, props)
     for opts in ({}, {"force_path": 2, "team": 16}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(4, P))
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
@@ -269,7 +315,7 @@ def test_device_resident_search(ctx, n, batch):
     from pcp_amd.search_device import DeviceSearch
     props = M.nqueens_props(n)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
         ctx.set_option(k, v)
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
     ss, _, _, sol = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
