@@ -333,8 +333,9 @@ __device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32
 // BP = B + 2 (B > 1): the B nodes of one slot sit at compile-time immediate offsets of one address register,
 // node pairs are 16-byte aligned (one ds_read_b128 reads two nodes), and consecutive slots are (B+2)*8 bytes
 // = 12/20/28/36 banks apart for B = 4/8/12/16, so 16 consecutive slots start on 16 distinct 4-bank groups.
+constexpr uint32_t kSummMinTile = 4;  // tiles of at least this many nodes keep per-slot summaries
 struct Carve {
-  size_t dom, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
+  size_t dom, summ, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
 __host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 2u; }
 // packed tiles: dwords per slot; B + 4 = 12/20/36 for B = 8/16/32 keeps rows 16-byte aligned (one ds_read_b128 = four
@@ -348,6 +349,8 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   Carve c;
   size_t o = 0;
   c.dom = o; o = up(o + (packed ? (size_t)row_stride16(B) * dom_slots * 4 : (size_t)row_stride(B) * dom_slots * 8));
+  // tile summaries (level-0 test of the sweep): two cells per slot, (min -lb, min ub) and (max -lb, max ub) over the nodes
+  c.summ = o; o = up(o + (B >= kSummMinTile ? (size_t)dom_slots * 2 * (packed ? 4 : 8) : 0));
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
@@ -375,6 +378,7 @@ enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES
 struct BlockCtx {
   void* dom;    // LDS domains [slot][bp]: int2 (-lb,ub), or packed dwords; global variant: the constants' singletons [slot - n_vars]
   uint32_t bp;  // row stride of dom, in cells
+  void* summ;   // LDS tile summaries [slot][2] cells (B >= kSummMinTile)
   uint32_t S, Wv;
   uint32_t* misc;
   int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
@@ -582,6 +586,16 @@ __device__ __forceinline__ void lt4_16(uint32_t& mn, uint32_t& mx, uint32_t& mn3
       : "+v"(mn), "+v"(mx), "+v"(mn3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
 }
+__device__ __forceinline__ uint32_t pk_min(uint32_t x, uint32_t y) {
+  uint32_t r;
+  asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(short)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)v >> 16; }
 
@@ -738,6 +752,27 @@ __device__ __forceinline__ Rec expand(const Rec8 q) {
 }
 __device__ __forceinline__ Rec expand(const Rec r) { return r; }
 
+// Level-0 test of the sweep: the level-1 conditions evaluated ONCE for the whole tile on per-slot summaries
+// S0 = (min over nodes of -lb, min over nodes of ub), S1 = (max ..., max ...), taken when the domains were staged.  The minimum
+// of a sum is at least the sum of the minima (and min (a - b) >= min a - max b), so a non-negative result proves that the
+// record is a no-op in EVERY node of the tile: 2 LDS reads and ~5 VALU per record instead of 2 VALU per (record,node).
+// The summaries are not maintained while the domains narrow: a record that touches a variable narrowed during the
+// sweep is re-run by the wake-up rounds anyway, so a stale summary is the same race as reading the domain a moment
+// before the narrowing.
+template <int KIND, bool PACKED>
+__device__ __forceinline__ int level0(const typename CellOf<PACKED>::type* sx, const typename CellOf<PACKED>::type* sy, const int d) {
+  const int c1 = d - 1, c2 = -d - 1, c3 = -d;
+  if constexpr (PACKED) {
+    const uint2 X = *reinterpret_cast<const uint2*>(sx), Y = *reinterpret_cast<const uint2*>(sy);  // .x = mins, .y = maxes
+    if (KIND == PCP_NEQ) return (lo16(X.x) + hi16(Y.x) + c1) | (hi16(X.x) + lo16(Y.x) + c2);
+    return (hi16(Y.x) - hi16(X.y) + c1) | (lo16(X.x) - lo16(Y.y) + c1) | (hi16(X.x) + lo16(Y.x) + c3);
+  } else {
+    const int4 X = *reinterpret_cast<const int4*>(sx), Y = *reinterpret_cast<const int4*>(sy);  // (min n, min u, max n, max u)
+    if (KIND == PCP_NEQ) return (X.x + Y.y + c1) | (X.y + Y.x + c2);
+    return (Y.y - X.w + c1) | (X.x - Y.z + c1) | (X.y + Y.x + c3);
+  }
+}
+
 template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
@@ -831,9 +866,9 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     if (PCP_ABLATE & 128) { tm1 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)alive4) & 0u); seg[0] += tm1 - tm0; }
     // ---- hot part: level-1 test of the four words; anything else is only noted in `slow` -------------------------
     uint32_t slow = 0;
-    // Whole-chunk fast block: the 4 x 64 records are of ONE binary kind (NEQ or LT), every word has a live record, no
-    // node of the tile has failed.  Straight-line code, so the LDS reads of the next word are issued under the
-    // arithmetic of the current one and the per-word kind / liveness tests and branches disappear.
+    // Whole-chunk fast block: the 4 x 64 records are of ONE binary kind (NEQ or LT) and no node of the tile has failed.
+    // Level 0 (tile summaries) clears most words outright; the per-node level 1 runs only for what is left — as one
+    // straight-line pipelined block when all four words need it, else word by word.
     bool chunk_fast = false;
     uint32_t ckind = 0;
     if constexpr (!GLOBAL) {
@@ -845,40 +880,71 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         k_or |= kj; k_and &= kj;
       }
       ckind = __builtin_amdgcn_readfirstlane(k_or);
-      const bool alive_all = (__ballot(alive4 != 0) & 0xFull) == 0xFull;  // lanes 0..3 hold the OR masks of words 0..3
       chunk_fast = __all(k_or == k_and && k_or == ckind) && (ckind == PCP_NEQ || ckind == PCP_LT) && failm == 0 &&
-                   c * kChunk + (kChunk - 1) < w1 && alive_all;
+                   c * kChunk + (kChunk - 1) < w1;
     }
     if (chunk_fast) {
-      int o[kChunk];
-      uint64_t tw = 0;
-      if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(st.buf[0].d) & 0);
-      const Cell* px[kChunk];
-      const Cell* py[kChunk];
-      int dd[kChunk];
-#pragma unroll
-      for (int j = 0; j < kChunk; ++j) {
-        const Rec rec = expand(st.buf[j]);
-        px[j] = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
-        py[j] = kdom + slot_row<B, PACKED>(rec.y);
-        dd[j] = rec.d;
-      }
-      if constexpr (B % UnitNodes<PACKED>::value == 0) {
-        if (ckind == PCP_NEQ) chunk_signs<PCP_NEQ, B, PACKED>(o, px, py, dd);
-        else chunk_signs<PCP_LT, B, PACKED>(o, px, py, dd);
-      } else {
-#pragma unroll
-        for (int j = 0; j < kChunk; ++j) {
-          if constexpr (PACKED) o[j] = (ckind == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px[j], py[j], dd[j]) : fast_signs16<PCP_LT, B>(px[j], py[j], dd[j]);
-          else o[j] = (ckind == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px[j], py[j], dd[j]) : fast_signs<PCP_LT, B>(px[j], py[j], dd[j]);
-        }
-      }
-      if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(o[0] | o[1] | o[2] | o[3]) & 0) - tw;
-#pragma unroll
-      for (int j = 0; j < kChunk; ++j)
-        if (__ballot(o[j] < 0) & readlane64(alive4, j)) slow |= 1u << j;
 #pragma unroll
       for (int h = 0; h < NL; ++h) steps_lane += __popcll(loaded[h]);  // every live record of every node runs once
+      uint64_t tw = 0;
+      if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(st.buf[0].d) & 0);
+      // level 0: the whole tile at once, on the per-slot summaries
+      uint32_t need = 0;  // words with a live record that level 0 could not clear
+      if constexpr (B >= (int)kSummMinTile) {
+        const Cell* ksumm = static_cast<const Cell*>(k.summ);
+        int o0[kChunk];
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j) {
+          const Rec rec = expand(st.buf[j]);
+          const Cell* sx = ksumm + 2u * (rec.xk & kSlotMask);
+          const Cell* sy = ksumm + 2u * rec.y;
+          o0[j] = (ckind == PCP_NEQ) ? level0<PCP_NEQ, PACKED>(sx, sy, rec.d) : level0<PCP_LT, PACKED>(sx, sy, rec.d);
+        }
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+          if (__ballot(o0[j] < 0) & readlane64(alive4, j)) need |= 1u << j;
+      } else {
+#pragma unroll
+        for (int j = 0; j < kChunk; ++j)
+          if (readlane64(alive4, j)) need |= 1u << j;
+      }
+      // level 1: every node of the tile, for the words level 0 left over
+      bool done1 = false;
+      if constexpr (B % UnitNodes<PACKED>::value == 0) {
+        if (need == 0xFu) {
+          int o[kChunk];
+          const Cell* px[kChunk];
+          const Cell* py[kChunk];
+          int dd[kChunk];
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j) {
+            const Rec rec = expand(st.buf[j]);
+            px[j] = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+            py[j] = kdom + slot_row<B, PACKED>(rec.y);
+            dd[j] = rec.d;
+          }
+          if (ckind == PCP_NEQ) chunk_signs<PCP_NEQ, B, PACKED>(o, px, py, dd);
+          else chunk_signs<PCP_LT, B, PACKED>(o, px, py, dd);
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j)
+            if (__ballot(o[j] < 0) & readlane64(alive4, j)) slow |= 1u << j;
+          done1 = true;
+        }
+      }
+      if (!done1) {
+        while (need) {  // rolled: one copy of the per-node test
+          const uint32_t j = __builtin_ctz(need);
+          need &= need - 1;
+          const Rec rec = expand(fetch_rec(c * kChunk + j));  // L1 hit; keeps the stage registers out of a dynamic index
+          const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+          const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
+          int o;
+          if constexpr (PACKED) o = (ckind == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
+          else o = (ckind == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+          if (__ballot(o < 0) & readlane64(alive4, j)) slow |= 1u << j;
+        }
+      }
+      if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (slow & 0u) - tw;
     } else {
   #pragma unroll
       for (int j = 0; j < kChunk; ++j) {
@@ -1072,7 +1138,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
     if (a.status[node0] != kStatusRetry) return;
   }
-  const BlockCtx k{dom, BP, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
+  const BlockCtx k{dom, BP, smem + cv.summ, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   if (tid < 16) misc[tid] = 0;
@@ -1116,6 +1182,31 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (tid < nb) a.status[node0 + tid] = kStatusRetry;
     if (tid == 0) atomicMax(a.retry_flag, a.epoch);
     return;
+  }
+  if constexpr (!GLOBAL && B >= (int)kSummMinTile) {
+    // tile summaries for the sweep's level-0 test: per slot (min -lb, min ub) and (max -lb, max ub) over the tile's nodes
+    Cell* summ = reinterpret_cast<Cell*>(smem + cv.summ);
+    for (uint32_t v = tid; v < S; v += nth) {
+      if constexpr (PACKED) {
+        uint32_t mn = 0x7fff7fffu, mx = 0x80008000u;
+#pragma unroll
+        for (int b = 0; b < B; b += 4) {
+          const uint4 q = *reinterpret_cast<const uint4*>(dom + (size_t)v * BP + b);
+          mn = pk_min(pk_min(mn, q.x), pk_min(q.y, pk_min(q.z, q.w)));
+          mx = pk_max(pk_max(mx, q.x), pk_max(q.y, pk_max(q.z, q.w)));
+        }
+        summ[2 * v] = mn; summ[2 * v + 1] = mx;
+      } else {
+        int2 mn = make_int2(0x7fffffff, 0x7fffffff), mx = make_int2(-0x7fffffff - 1, -0x7fffffff - 1);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const int2 q = dom[(size_t)v * BP + b];
+          mn.x = min(mn.x, q.x); mn.y = min(mn.y, q.y); mx.x = max(mx.x, q.x); mx.y = max(mx.y, q.y);
+        }
+        summ[2 * v] = mn; summ[2 * v + 1] = mx;
+      }
+    }
+    __syncthreads();
   }
 
   Ctr ctr;
