@@ -117,6 +117,7 @@ def main():
     props = M.nqueens_props(n)
     ctx = E.Context(local_rank)
     ctx.set_model(n, props)
+    ctx.set_hull(1, n)  # the queens were allocated with Interval(1, n)  (example/src/nqueens.rs:32-35)
     ctx.set_option("block_threads", args.block_threads)
     ctx.set_option("nodes_per_block", args.nodes_per_block)
 

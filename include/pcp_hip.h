@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 1
+#define PCP_ABI_VERSION 2
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -114,6 +114,15 @@ int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
  * units, not elementary props. */
 int32_t pcp_model_truncate(pcp_ctx* ctx, uint32_t n_units);
 int32_t pcp_model_n_units(const pcp_ctx* ctx, uint32_t* n_units, uint32_t* n_props);
+/* Optional: [lo, hi] = hull of the initial domains the variables were allocated with (VStore::alloc,
+ * variable/store.rs:130-139).  Updates are monotone (variable/store.rs:156-170), so every domain of every node of the
+ * search lies inside it.  With a hull within +-16383 the engine keeps the domains as 16-bit cells (twice the nodes per
+ * workgroup) without the second, 32-bit launch it otherwise queues behind every such call for nodes that do not fit.
+ * A node whose bounds leave the declared hull is a contract violation: pcp_propagate returns PCP_ERR_CONTRACT;
+ * pcp_propagate_device leaves that node's outputs untouched, sets its status to PCP_STATUS_HULL and the next
+ * pcp_stats_read returns PCP_ERR_CONTRACT.  pcp_model_reset forgets the hull. */
+int32_t pcp_model_set_hull(pcp_ctx* ctx, int32_t lo, int32_t hi);
+#define PCP_STATUS_HULL 0xFE
 
 /* ---- propagation (≡ Consistency::consistency, propagation/store.rs:247-257) ---------------------------- */
 /* Host-buffer form: n_nodes independent spaces sharing the model.

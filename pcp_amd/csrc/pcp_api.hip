@@ -43,6 +43,8 @@ struct pcp_ctx {
   pcp_stats* d_stats = nullptr;
   uint32_t* d_retry = nullptr;   // packed launches: stamped with `epoch` by a tile that has to be re-run with 32-bit cells
   uint32_t epoch = 0;
+  bool hull_set = false; int32_t hull_lo = 0, hull_hi = 0;  // pcp_model_set_hull
+  uint32_t trusted_epoch = 0;   // epoch of the last packed launch without a retry launch (hull declared)
   uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
   uint32_t* d_child_base = nullptr; size_t cap_child_base = 0;  // branching scratch
   uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
@@ -270,6 +272,7 @@ int32_t pcp_model_reset(pcp_ctx* c, uint32_t n_vars, uint32_t set_words) {
   c->unit_of_prop.clear();
   c->n_units = 0;
   c->has_groups = false;
+  c->hull_set = false;
   c->dirty = true;
   return PCP_OK;
 }
@@ -307,6 +310,14 @@ int32_t pcp_model_truncate(pcp_ctx* c, uint32_t n_units) {
   c->has_groups = false;
   for (auto& p : c->props) c->has_groups |= p.group_kind != 0;
   c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_set_hull(pcp_ctx* c, int32_t lo, int32_t hi) {
+  if (!c) return PCP_ERR_ARG;
+  if (lo > hi) return fail(c, PCP_ERR_ARG, "empty hull");
+  if (lo < -PCP_BOUND_MAX || hi > PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "bound outside +-PCP_BOUND_MAX");
+  c->hull_set = true; c->hull_lo = lo; c->hull_hi = hi;
   return PCP_OK;
 }
 
@@ -411,7 +422,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // while the domains are staged, and a tile that does not fit is handed back to a second launch with 32-bit cells
   // and half the tile size (same LDS footprint, so it fits whenever the packed tile did).
   uint32_t Bp = 0, cap_p = 0, cap_half = 0;
-  if (!use_team && !global_dom && c->opt_packed && c->compact && c->consts_fit16) {
+  const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
+  if (!use_team && !global_dom && c->opt_packed && c->compact && c->consts_fit16 && (!c->hull_set || hull_fits16)) {
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
     for (uint32_t t : {32u, 16u, 8u}) {
       if (t > want) continue;
@@ -476,7 +488,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
-  if (Bp) {
+  if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation
+  if (Bp && !hull_fits16) {
     // the tiles the packed kernel handed back (normally none: every block of this launch returns at once)
     LaunchArgs a2 = a;
     a2.packed = 0; a2.only_marked = 1; a2.nodes_per_block = Bp / 2; a2.list_cap = cap_half;
@@ -520,7 +533,13 @@ int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
   if (!c || !out) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof(pcp_stats), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
+  uint32_t flag = 0;
+  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_retry, 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   HIP_TRY(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+  if (c->trusted_epoch && flag == c->trusted_epoch) {
+    c->trusted_epoch = 0;
+    return fail(c, PCP_ERR_CONTRACT, "a node's bounds lie outside the hull declared with pcp_model_set_hull (status PCP_STATUS_HULL)");
+  }
   return PCP_OK;
 }
 
@@ -548,6 +567,7 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   for (size_t i = 0; i < nv; ++i) {
     if (lb[i] > ub[i]) return fail(c, PCP_ERR_CONTRACT, "empty initial domain (variable/store.rs:136)");
     if (lb[i] < -PCP_BOUND_MAX || ub[i] > PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "bound outside +-PCP_BOUND_MAX");
+    if (c->hull_set && (lb[i] < c->hull_lo || ub[i] > c->hull_hi)) return fail(c, PCP_ERR_CONTRACT, "bound outside the hull declared with pcp_model_set_hull");
   }
   const uint32_t words = ((uint32_t)c->n_units + 63) / 64;
   const size_t dom_bytes = nv * 4, act_bytes = (size_t)n_nodes * words * 8;

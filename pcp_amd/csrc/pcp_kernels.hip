@@ -1113,6 +1113,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   static_assert(!PACKED || (!GLOBAL && B >= 8 && B % 4 == 0), "packed tiles: LDS-resident, a multiple of four nodes");
   static_assert(B <= 32, "fail / todo masks are 32 bits wide");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned long long t_entry = (PCP_ABLATE & 64) ? wall_clock64() : 0ull;
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, P = a.m.n_recs, words = (P + 63) >> 6;
   const uint32_t team = a.team, C = a.list_cap;
@@ -1430,8 +1431,12 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     const unsigned long long t_end = wall_clock64();
     atomicAdd((unsigned long long*)&a.stats->steps3, t_sweep - t_begin);
     atomicAdd((unsigned long long*)&a.stats->narrowings, t_end - t_sweep);
-    atomicMax((unsigned long long*)&a.stats->failed_nodes, t_sweep - t_begin);   // slowest block's sweep
-    atomicMax((unsigned long long*)&a.stats->waves, t_end - t_sweep);            // slowest block's rounds
+    if (PCP_ABLATE & 256) {
+      atomicAdd((unsigned long long*)&a.stats->failed_nodes, t_begin - t_entry);  // staging (phase 0)
+    } else {
+      atomicMax((unsigned long long*)&a.stats->failed_nodes, t_sweep - t_begin);   // slowest block's sweep
+      atomicMax((unsigned long long*)&a.stats->waves, t_end - t_sweep);            // slowest block's rounds
+    }
   }
   if constexpr (GLOBAL) {
     bool bad = false;  // the domains are already in place; a missed failure shows as an empty domain here
@@ -1482,6 +1487,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));
     if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    if ((PCP_ABLATE & 320) == 320) atomicAdd((unsigned long long*)&a.stats->nodes, wall_clock64() - t_entry);  // whole block
   }
 }
 

@@ -24,7 +24,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 # Every symbol include/pcp_hip.h declares (tests/test_abi.py checks the .so exports each of them).
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
-    "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
+    "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
     "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option",
 ]
 
@@ -85,6 +85,7 @@ def load_library():
     L.pcp_model_push_props.argtypes = [vp, u32, vp]
     L.pcp_model_truncate.argtypes = [vp, u32]
     L.pcp_model_n_units.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+    L.pcp_model_set_hull.argtypes = [vp, i32, i32]
     L.pcp_propagate.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
@@ -92,7 +93,7 @@ def load_library():
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
-    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units",
+    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
               "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
@@ -144,6 +145,10 @@ class Context:
         if len(props):
             self._check(self._L.pcp_model_push_props(self._h, len(props), _np_ptr(props)))
         self._refresh()
+
+    def set_hull(self, lo: int, hi: int):
+        """pcp_model_set_hull: hull of the variables' initial domains (VStore.alloc); forgotten by set_model."""
+        self._check(self._L.pcp_model_set_hull(self._h, int(lo), int(hi)))
 
     def truncate(self, n_units: int):
         self._check(self._L.pcp_model_truncate(self._h, n_units))

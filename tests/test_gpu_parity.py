@@ -153,6 +153,49 @@ def test_packed_tiles_nqueens_frontier(ctx):
     both(ctx, n, props, L, U, A, "nqueens frontier packed", nodes_per_block=32, packed=1)
 
 
+def test_declared_hull(ctx):
+    """pcp_model_set_hull: same answers without the retry launch; a bound outside the hull is a contract violation."""
+    import torch
+    V, P, N = 150, 1200, 203
+    props, lb, ub, sol = random_csp(910, V, P, planted=True, p_tern=0.0, dom=(0, 80))
+    L, U = random_nodes(911, lb, ub, N, sol, p_narrow=0.2)
+    act = random_active(913, N, P, p_off=0.05)
+    om = orc.OracleModel(V, props)
+    ref = om.consistency(L, U, act)
+    ctx.set_model(V, props)
+    ctx.set_hull(int(lb.min()), int(ub.max()))
+    for k, v in {"force_path": 0, "nodes_per_block": 16, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+        ctx.set_option(k, v)
+    got = ctx.propagate(L, U, act)
+    assert_parity(ref[:4], got[:4], "declared hull")
+    # host-buffer path: validated before the launch
+    L2 = L.copy(); L2[5, 7] = int(lb.min()) - 1
+    with pytest.raises(E.PcpError) as ei:
+        ctx.propagate(L2, U, act)
+    assert ei.value.code == -2
+    # device path: the offending tile keeps its inputs, its nodes get PCP_STATUS_HULL, stats_read reports the violation
+    ctx.set_hull(-20000, 20000)  # a hull too wide for the packed cells: plain 32-bit tiles, no error possible
+    got = ctx.propagate(L, U, act)
+    assert_parity(ref[:4], got[:4], "wide hull")
+    ctx.set_hull(int(lb.min()), int(ub.max()))
+    dev = torch.device("cuda:0")
+    Ld = L.copy(); Ld[40, 3] = -17000
+    t_lb, t_ub = torch.from_numpy(Ld).to(dev), torch.from_numpy(U).to(dev)
+    t_act = torch.from_numpy(act.view(np.int64)).to(dev)
+    t_st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    ctx.stats_reset()
+    ctx.propagate_device(N, t_lb, t_ub, t_lb, t_ub, t_act, t_act, t_st)
+    with pytest.raises(E.PcpError) as ei:
+        ctx.stats_read()
+    assert ei.value.code == -2
+    st = t_st.cpu().numpy()
+    assert (st[32:48] == 0xFE).all() and (st[:32] != 0xFE).all() and (st[48:] != 0xFE).all()
+    assert np.array_equal(t_lb.cpu().numpy()[32:48], Ld[32:48])
+    ok = np.ones(N, bool); ok[32:48] = False
+    assert np.array_equal(st[ok], ref[3][ok])
+    ctx.set_model(V, props)  # forgets the hull
+
+
 def test_long_cascade(ctx):
     """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
     n = 300
