@@ -36,6 +36,7 @@ struct pcp_ctx {
   size_t cap_rec_unit = 0, cap_unit_first = 0;
   uint32_t n_slots = 0;
   bool has_ternary = false;
+  uint32_t uniform_kind = 0xFFFFFFFFu;
   bool consts_fit16 = true;      // every interned constant within +-kPackedMax (packed tiles)
   size_t cap_recs = 0, cap_adj = 0, cap_adj_off = 0, cap_const = 0;
 
@@ -170,11 +171,20 @@ int32_t finalize_model(pcp_ctx* c) {
   }
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t rc;
-  if ((rc = ensure(c, c->d_recs, c->cap_recs, P))) return rc;
+  const size_t Ppad = P ? ((P + 255) / 256) * 256 + kStreamPadRecs : 0;  // see kStreamPadRecs
+  if (P) { const Rec last = recs[P - 1]; recs.resize(Ppad, last); }
+  if ((rc = ensure(c, c->d_recs, c->cap_recs, Ppad))) return rc;
   if ((rc = ensure(c, c->d_adj_off, c->cap_adj_off, adj_off.size()))) return rc;
   if ((rc = ensure(c, c->d_adj, c->cap_adj, adj.size()))) return rc;
   if ((rc = ensure(c, c->d_const, c->cap_const, consts.size()))) return rc;
-  if (P) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), P * sizeof(Rec), hipMemcpyHostToDevice));
+  if (P) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), Ppad * sizeof(Rec), hipMemcpyHostToDevice));
+  c->uniform_kind = 0xFFFFFFFFu;
+  if (P) {
+    const uint32_t k0 = recs[0].xk >> 28;
+    bool same = (k0 == PCP_NEQ || k0 == PCP_LT);
+    for (size_t r = 1; r < P && same; ++r) same = (recs[r].xk >> 28) == k0;
+    if (same) c->uniform_kind = k0;
+  }
   HIP_TRY(c, hipMemcpy(c->d_adj_off, adj_off.data(), adj_off.size() * 4, hipMemcpyHostToDevice));
   if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
@@ -182,13 +192,13 @@ int32_t finalize_model(pcp_ctx* c) {
   c->consts_fit16 = true;
   for (int32_t v : consts) c->consts_fit16 &= (v >= -kPackedMax && v <= kPackedMax);
   if (c->compact) {
-    std::vector<Rec8> r8(P);
-    for (size_t r = 0; r < P; ++r) {
+    std::vector<Rec8> r8(Ppad);
+    for (size_t r = 0; r < Ppad; ++r) {
       r8[r].xyk = (recs[r].xk & kSlotMask) | (recs[r].y << 15) | ((recs[r].xk >> 28) << 30);
       r8[r].d = recs[r].d;
     }
-    if ((rc = ensure(c, c->d_recs8, c->cap_recs8, P))) return rc;
-    HIP_TRY(c, hipMemcpy(c->d_recs8, r8.data(), P * sizeof(Rec8), hipMemcpyHostToDevice));
+    if ((rc = ensure(c, c->d_recs8, c->cap_recs8, Ppad))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_recs8, r8.data(), Ppad * sizeof(Rec8), hipMemcpyHostToDevice));
   }
   if (c->has_groups) {
     std::vector<uint32_t> first(c->n_units + 1, (uint32_t)P);
@@ -448,7 +458,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
-  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
+  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.packed = Bp ? 1u : 0u; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;

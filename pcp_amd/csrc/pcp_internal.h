@@ -45,7 +45,12 @@ struct ModelDev {
   uint32_t n_vars;
   uint32_t n_slots;  // n_vars + number of interned constants
   uint32_t has_ternary;
+  uint32_t uniform_kind;  // the kind shared by ALL records when that is NEQ or LT, else 0xFFFFFFFF (the sweep then classifies each chunk)
 };
+
+// Both record tables are padded with copies of their last record up to a multiple of 256 records plus kStreamPadRecs, so
+// that the sweep's unconditional prefetch (up to two rounds of 16 wavefronts x 4 words ahead) needs no index clamping.
+constexpr uint32_t kStreamPadRecs = 2 * 16 * 4 * 64;
 
 // Per-launch arguments of the fixpoint kernel.
 struct LaunchArgs {

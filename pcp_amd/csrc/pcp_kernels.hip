@@ -763,8 +763,12 @@ template <int KIND, bool PACKED>
 __device__ __forceinline__ int level0(const typename CellOf<PACKED>::type* sx, const typename CellOf<PACKED>::type* sy, const int d) {
   const int c1 = d - 1, c2 = -d - 1, c3 = -d;
   if constexpr (PACKED) {
+    if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
+      uint32_t t;
+      asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(*sx), "v"(*sy));
+      return (lo16(t) + c1) | (hi16(t) + c2);
+    }
     const uint2 X = *reinterpret_cast<const uint2*>(sx), Y = *reinterpret_cast<const uint2*>(sy);  // .x = mins, .y = maxes
-    if (KIND == PCP_NEQ) return (lo16(X.x) + hi16(Y.x) + c1) | (hi16(X.x) + lo16(Y.x) + c2);
     return (hi16(Y.x) - hi16(X.y) + c1) | (lo16(X.x) - lo16(Y.y) + c1) | (hi16(X.x) + lo16(Y.x) + c3);
   } else {
     const int4 X = *reinterpret_cast<const int4*>(sx), Y = *reinterpret_cast<const int4*>(sy);  // (min n, min u, max n, max u)
@@ -814,15 +818,15 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   using RecT = typename std::conditional<COMPACT, Rec8, Rec>::type;
   const RecT* rec_stream;
   if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
-  auto fetch_rec = [&](uint32_t w) -> RecT {  // lanes past the last record read the last record; their live bit is 0
-    const uint32_t r = min((min(w, last_word) << 6) + lane, P - 1);
+  auto fetch_rec = [&](uint32_t w) -> RecT {  // w is wave-uniform; the tables are padded (kStreamPadRecs): no clamping
     if (PCP_ABLATE & 4) {  // profiling: no record stream (a synthetic NEQ record)
+      const uint32_t r = (w << 6) + lane;
       RecT q;
       if constexpr (COMPACT) { q.xyk = (r & 511u) | (((r >> 3) & 511u) << 15); q.d = (int)(r & 7u); }
       else { q.xk = r & 511u; q.y = (r >> 3) & 511u; q.z = 0; q.d = (int)(r & 7u); }
       return q;
     }
-    return rec_stream[r];
+    return (rec_stream + (size_t)w * 64)[lane];
   };
   // word j of node b sits in lane (b & 15) * kChunk + j of live register b >> 4
   auto word_of = [&](const uint64_t (&reg)[NL], uint32_t b, uint32_t j) -> uint64_t {
@@ -859,11 +863,13 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     }
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     // alive4: lane l holds the OR over the tile's nodes of word (l & 3) — the records of that word that are live in
-    // at least one node.  A record that is dead in every node of the tile (entailed higher up the search tree:
-    // siblings share their ancestors' entailments) must not drag its word onto the cold path.
-    const uint64_t alive4 = or_mod4_64(any_live);
+    // at least one node (a record that is dead in every node of the tile must not drag its word onto the cold path).
+    // Computed on demand: the common chunk is cleared by level 0 without looking at the live words at all.
+    uint64_t alive4 = 0;
+    bool have_alive = false;
+    auto get_alive = [&]() { if (!have_alive) { alive4 = or_mod4_64(any_live); have_alive = true; } };
     uint64_t tm1 = 0;
-    if (PCP_ABLATE & 128) { tm1 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)alive4) & 0u); seg[0] += tm1 - tm0; }
+    if (PCP_ABLATE & 128) { tm1 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)any_live) & 0u); seg[0] += tm1 - tm0; }
     // ---- hot part: level-1 test of the four words; anything else is only noted in `slow` -------------------------
     uint32_t slow = 0;
     // Whole-chunk fast block: the 4 x 64 records are of ONE binary kind (NEQ or LT) and no node of the tile has failed.
@@ -872,16 +878,21 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     bool chunk_fast = false;
     uint32_t ckind = 0;
     if constexpr (!GLOBAL) {
-      uint32_t k_or = 0, k_and = ~0u;
+      const bool shape_ok = failm == 0 && c * kChunk + (kChunk - 1) < w1;
+      if (a.m.uniform_kind <= PCP_LT) {  // the host has checked the whole table
+        ckind = a.m.uniform_kind;
+        chunk_fast = shape_ok;
+      } else if (shape_ok) {
+        uint32_t k_or = 0, k_and = ~0u;
 #pragma unroll
-      for (int j = 0; j < kChunk; ++j) {
-        uint32_t kj;
-        if constexpr (COMPACT) kj = st.buf[j].xyk >> 30; else kj = st.buf[j].xk >> 28;
-        k_or |= kj; k_and &= kj;
+        for (int j = 0; j < kChunk; ++j) {
+          uint32_t kj;
+          if constexpr (COMPACT) kj = st.buf[j].xyk >> 30; else kj = st.buf[j].xk >> 28;
+          k_or |= kj; k_and &= kj;
+        }
+        ckind = __builtin_amdgcn_readfirstlane(k_or);
+        chunk_fast = __all(k_or == k_and && k_or == ckind) && (ckind == PCP_NEQ || ckind == PCP_LT);
       }
-      ckind = __builtin_amdgcn_readfirstlane(k_or);
-      chunk_fast = __all(k_or == k_and && k_or == ckind) && (ckind == PCP_NEQ || ckind == PCP_LT) && failm == 0 &&
-                   c * kChunk + (kChunk - 1) < w1;
     }
     if (chunk_fast) {
 #pragma unroll
@@ -900,10 +911,18 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           const Cell* sy = ksumm + 2u * rec.y;
           o0[j] = (ckind == PCP_NEQ) ? level0<PCP_NEQ, PACKED>(sx, sy, rec.d) : level0<PCP_LT, PACKED>(sx, sy, rec.d);
         }
+        uint64_t bal[kChunk];
+        bool any0 = false;
 #pragma unroll
-        for (int j = 0; j < kChunk; ++j)
-          if (__ballot(o0[j] < 0) & readlane64(alive4, j)) need |= 1u << j;
+        for (int j = 0; j < kChunk; ++j) { bal[j] = __ballot(o0[j] < 0); any0 |= bal[j] != 0; }
+        if (any0) {
+          get_alive();
+#pragma unroll
+          for (int j = 0; j < kChunk; ++j)
+            if (bal[j] & readlane64(alive4, j)) need |= 1u << j;
+        }
       } else {
+        get_alive();
 #pragma unroll
         for (int j = 0; j < kChunk; ++j)
           if (readlane64(alive4, j)) need |= 1u << j;
@@ -946,6 +965,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       }
       if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (slow & 0u) - tw;
     } else {
+      get_alive();
   #pragma unroll
       for (int j = 0; j < kChunk; ++j) {
         const Rec rec = expand(st.buf[j]);
