@@ -760,20 +760,39 @@ __device__ __forceinline__ Rec expand(const Rec r) { return r; }
 // sweep is re-run by the wake-up rounds anyway, so a stale summary is the same race as reading the domain a moment
 // before the narrowing.
 template <int KIND, bool PACKED>
-__device__ __forceinline__ int level0(const typename CellOf<PACKED>::type* sx, const typename CellOf<PACKED>::type* sy, const int d) {
-  const int c1 = d - 1, c2 = -d - 1, c3 = -d;
+__device__ __forceinline__ void level0_chunk(int (&o)[4], const typename CellOf<PACKED>::type* const (&sx)[4],
+                                             const typename CellOf<PACKED>::type* const (&sy)[4], const int (&d)[4]) {
   if constexpr (PACKED) {
     if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
-      uint32_t t;
-      asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(*sx), "v"(*sy));
-      return (lo16(t) + c1) | (hi16(t) + c2);
+      uint32_t xs[4], ys[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xs[j] = *sx[j]; ys[j] = *sy[j]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t t;
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(xs[j]), "v"(ys[j]));
+        o[j] = (lo16(t) + (d[j] - 1)) | (hi16(t) + (-d[j] - 1));
+      }
+    } else {
+      uint2 X[4], Y[4];  // .x = mins, .y = maxes
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { X[j] = *reinterpret_cast<const uint2*>(sx[j]); Y[j] = *reinterpret_cast<const uint2*>(sy[j]); }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c1 = d[j] - 1, c3 = -d[j];
+        o[j] = (hi16(Y[j].x) - hi16(X[j].y) + c1) | (lo16(X[j].x) - lo16(Y[j].y) + c1) | (hi16(X[j].x) + lo16(Y[j].x) + c3);
+      }
     }
-    const uint2 X = *reinterpret_cast<const uint2*>(sx), Y = *reinterpret_cast<const uint2*>(sy);  // .x = mins, .y = maxes
-    return (hi16(Y.x) - hi16(X.y) + c1) | (lo16(X.x) - lo16(Y.y) + c1) | (hi16(X.x) + lo16(Y.x) + c3);
   } else {
-    const int4 X = *reinterpret_cast<const int4*>(sx), Y = *reinterpret_cast<const int4*>(sy);  // (min n, min u, max n, max u)
-    if (KIND == PCP_NEQ) return (X.x + Y.y + c1) | (X.y + Y.x + c2);
-    return (Y.y - X.w + c1) | (X.x - Y.z + c1) | (X.y + Y.x + c3);
+    int4 X[4], Y[4];  // (min n, min u, max n, max u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { X[j] = *reinterpret_cast<const int4*>(sx[j]); Y[j] = *reinterpret_cast<const int4*>(sy[j]); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c1 = d[j] - 1, c2 = -d[j] - 1, c3 = -d[j];
+      if (KIND == PCP_NEQ) o[j] = (X[j].x + Y[j].y + c1) | (X[j].y + Y[j].x + c2);
+      else o[j] = (Y[j].y - X[j].w + c1) | (X[j].x - Y[j].z + c1) | (X[j].y + Y[j].x + c3);
+    }
   }
 }
 
@@ -904,13 +923,19 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       if constexpr (B >= (int)kSummMinTile) {
         const Cell* ksumm = static_cast<const Cell*>(k.summ);
         int o0[kChunk];
+        const Cell* sx[kChunk];
+        const Cell* sy[kChunk];
+        int d0[kChunk];
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
           const Rec rec = expand(st.buf[j]);
-          const Cell* sx = ksumm + 2u * (rec.xk & kSlotMask);
-          const Cell* sy = ksumm + 2u * rec.y;
-          o0[j] = (ckind == PCP_NEQ) ? level0<PCP_NEQ, PACKED>(sx, sy, rec.d) : level0<PCP_LT, PACKED>(sx, sy, rec.d);
+          sx[j] = ksumm + 2u * (rec.xk & kSlotMask);
+          sy[j] = ksumm + 2u * rec.y;
+          d0[j] = rec.d;
         }
+        // one kind branch per chunk, and the eight summary reads of a chunk go out together
+        if (ckind == PCP_NEQ) level0_chunk<PCP_NEQ, PACKED>(o0, sx, sy, d0);
+        else level0_chunk<PCP_LT, PACKED>(o0, sx, sy, d0);
         uint64_t bal[kChunk];
         bool any0 = false;
 #pragma unroll
