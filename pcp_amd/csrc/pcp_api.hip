@@ -28,6 +28,8 @@ struct pcp_ctx {
   // device model
   Rec* d_recs = nullptr;
   Rec8* d_recs8 = nullptr; size_t cap_recs8 = 0; bool compact = false;
+  WordDesc* d_wdesc = nullptr; size_t cap_wdesc = 0;
+  uint32_t word_level = 0;           // 0 = no word descriptors worth using, 1 = XNeqY words only, 2 = XLessY words too
   uint32_t* d_adj_off = nullptr;
   uint32_t* d_adj = nullptr;
   int32_t* d_const = nullptr;
@@ -64,6 +66,7 @@ struct pcp_ctx {
   int64_t opt_list_cap = 2048;
   int64_t opt_global_dom = 0;       // 1 = force the HBM-resident-domain variant (tests)
   int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
+  int64_t opt_word_level = 1;       // 1 = auto (word-group sweep with the level -1 range test on packed tiles), 0 = never
 };
 
 namespace {
@@ -200,6 +203,44 @@ int32_t finalize_model(pcp_ctx* c) {
     if ((rc = ensure(c, c->d_recs8, c->cap_recs8, Ppad))) return rc;
     HIP_TRY(c, hipMemcpy(c->d_recs8, r8.data(), Ppad * sizeof(Rec8), hipMemcpyHostToDevice));
   }
+  // word descriptors for the level -1 test of packed tiles (WordDesc, pcp_internal.h)
+  c->word_level = 0;
+  if (c->compact) {
+    const size_t W = (P + 63) / 64;
+    std::vector<WordDesc> wd(W + kStreamPadRecs / 64);
+    size_t good = 0;
+    bool any_lt = false;
+    auto lg = [](uint32_t len) { uint32_t k = 0; while ((2u << k) <= len) ++k; return k; };
+    for (size_t w = 0; w < W; ++w) {
+      const size_t r0 = w * 64, r1 = std::min(P, r0 + 64);
+      const uint32_t kind = recs[r0].xk >> 28;
+      uint32_t xlo = ~0u, xhi = 0, ylo = ~0u, yhi = 0;
+      int32_t dmin = INT32_MAX, dmax = INT32_MIN;
+      bool same = (kind == PCP_NEQ || kind == PCP_LT);
+      for (size_t r = r0; r < r1 && same; ++r) {
+        same = (recs[r].xk >> 28) == kind;
+        const uint32_t x = recs[r].xk & kSlotMask, y = recs[r].y;
+        xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
+        dmin = std::min(dmin, recs[r].d); dmax = std::max(dmax, recs[r].d);
+      }
+      WordDesc q{0, 0, 0, 0};
+      if (same && xhi - xlo < kRangeMax && yhi - ylo < kRangeMax && dmin >= -30000 && dmax <= 30000) {
+        const uint32_t kx = lg(xhi - xlo + 1), ky = lg(yhi - ylo + 1);
+        q.x = xlo | ((xhi - (1u << kx) + 1) << 16);
+        q.y = ylo | ((yhi - (1u << ky) + 1) << 16);
+        q.k = kx | (ky << 4) | ((kind == PCP_NEQ ? 1u : 2u) << 8);
+        q.d = ((uint32_t)dmin & 0xffffu) | ((uint32_t)dmax << 16);
+        ++good;
+        any_lt |= kind == PCP_LT;
+      }
+      wd[w] = q;
+    }
+    if (W && good * 2 >= W && W <= 512u * 1024u) {  // worth a sweep organised by word groups (16-bit lane counters: <= 1023 groups per wavefront)
+      if ((rc = ensure(c, c->d_wdesc, c->cap_wdesc, wd.size()))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_wdesc, wd.data(), wd.size() * sizeof(WordDesc), hipMemcpyHostToDevice));
+      c->word_level = any_lt ? 2 : 1;
+    }
+  }
   if (c->has_groups) {
     std::vector<uint32_t> first(c->n_units + 1, (uint32_t)P);
     for (size_t r = P; r-- > 0;) first[c->unit_of_prop[r]] = (uint32_t)r;
@@ -265,7 +306,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -356,6 +397,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "global_dom") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "global_dom must be 0 or 1");
     c->opt_global_dom = value;
+  } else if (k == "word_level") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "word_level must be 0 or 1");
+    c->opt_word_level = value;
   } else if (k == "packed") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "packed must be 0 or 1");
     c->opt_packed = value;
@@ -431,19 +475,21 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // LDS traffic per filter step.  They need every bound within +-kPackedMax; that is checked per tile on the device
   // while the domains are staged, and a tile that does not fit is handed back to a second launch with 32-bit cells
   // and half the tile size (same LDS footprint, so it fits whenever the packed tile did).
-  uint32_t Bp = 0, cap_p = 0, cap_half = 0;
+  uint32_t Bp = 0, cap_p = 0, cap_half = 0, wl_used = 0;
   const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
   if (!use_team && !global_dom && c->opt_packed && c->compact && c->consts_fit16 && (!c->hull_set || hull_fits16)) {
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
+    const uint32_t wl = c->opt_word_level ? c->word_level : 0;  // the word-group sweep keeps B live registers per lane: B <= 16
     for (uint32_t t : {32u, 16u, 8u}) {
-      if (t > want) continue;
+      if (t > want || (wl && t > 16)) continue;
+      auto need_for = [&](uint32_t cap) { return lds_bytes_for(S, t, cap, block, true, wl); };
       uint32_t cap = list_cap;
-      while (cap > 256 && !(lds_bytes_for(S, t, cap, block, true) && lds_bytes_for(S, t, cap, block, true) <= c->lds_max)) cap /= 2;
-      const size_t need = lds_bytes_for(S, t, cap, block, true);
+      while (cap > 256 && !(need_for(cap) && need_for(cap) <= c->lds_max)) cap /= 2;
+      const size_t need = need_for(cap);
       if (!need || need > c->lds_max) continue;
       const uint32_t ch = fits(t / 2);
       if (!ch) continue;
-      Bp = t; cap_p = cap; cap_half = ch;
+      Bp = t; cap_p = cap; cap_half = ch; wl_used = wl;
       break;
     }
     if (Bp * 2 <= B) Bp = 0;  // a 32-bit tile with at least twice the nodes wins
@@ -452,7 +498,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   plan.block = block;
   if (use_team && !global_dom) list_cap_used = fits(1);
   if (Bp) { B = Bp; list_cap_used = cap_p; }
-  plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block, Bp != 0);
+  plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block, Bp != 0, Bp ? wl_used : 0);
   plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
 
   LaunchArgs a;
@@ -460,7 +506,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
-  a.packed = Bp ? 1u : 0u; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
+  a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -502,7 +548,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (Bp && !hull_fits16) {
     // the tiles the packed kernel handed back (normally none: every block of this launch returns at once)
     LaunchArgs a2 = a;
-    a2.packed = 0; a2.only_marked = 1; a2.nodes_per_block = Bp / 2; a2.list_cap = cap_half;
+    a2.packed = 0; a2.word_level = 0; a2.only_marked = 1; a2.nodes_per_block = Bp / 2; a2.list_cap = cap_half;
     LaunchPlan plan2;
     plan2.block = block;
     plan2.lds_bytes = lds_bytes_for(S, Bp / 2, cap_half, block);

@@ -35,9 +35,24 @@ struct __attribute__((aligned(8))) Rec8 {
 static_assert(sizeof(Rec8) == 8, "Rec8 must be 8 bytes");
 constexpr uint32_t kCompactSlots = 1u << 15;
 
+// Word descriptor for the sweep's level -1 test (packed tiles): what the 64 records of one live-mask word have in
+// common.  cls = 1 (all XNeqY) or 2 (all XLessY) when the operand slots of the word span at most kRangeMax consecutive
+// slots each and every offset fits 16 bits, else 0 (the word always goes to the record-level tests).  A slot range
+// [lo, hi] is queried in the tile's range-minimum tables as min(T[k][lo], T[k][second]) with 2^k <= hi-lo+1 < 2^(k+1).
+struct __attribute__((aligned(16))) WordDesc {
+  uint32_t x;  // xlo | second_x << 16
+  uint32_t y;  // ylo | second_y << 16
+  uint32_t k;  // kx | ky << 4 | cls << 8
+  uint32_t d;  // (dmin & 0xffff) | dmax << 16     (int16 each)
+};
+static_assert(sizeof(WordDesc) == 16, "WordDesc must be 16 bytes");
+constexpr uint32_t kRangeMax = 64;    // longest slot range a descriptor may cover
+constexpr uint32_t kRangeLevels = 7;  // table levels 2^0 .. 2^6
+
 struct ModelDev {
   const Rec* recs;          // [n_recs]
   const Rec8* recs8;        // [n_recs] or null when the model is not compactable
+  const WordDesc* wdesc;    // [ceil(n_recs/64)] word descriptors, or null
   const uint32_t* adj_off;  // [n_vars + 1]  CSR var -> incident record ids (constants have no adjacency)
   const uint32_t* adj;      // [adj_off[n_vars]]
   const int32_t* const_val; // [n_slots - n_vars]
@@ -60,6 +75,8 @@ struct LaunchArgs {
   uint32_t team;             // G: workgroups cooperating on ONE node (nodes_per_block == 1 when team > 1)
   uint32_t list_cap;         // capacity of the per-round changed-(node,var) list in LDS
   uint32_t global_dom;       // 1 = domains stay in lb_out/ub_out (HBM/L2), for variable stores larger than LDS
+  uint32_t word_level;       // packed tiles only: 1 = sweep by word groups with the level -1 range test (needs m.wdesc),
+                             //     2 = the same with maximum tables as well (the model has XLessY words)
   uint32_t packed;           // 1 = 16-bit packed LDS domains (every bound within +-kPackedMax); tiles that do not fit mark
                              //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
   uint32_t only_marked;      // 1 = second launch of a packed call: run only tiles whose nodes carry kStatusRetry
@@ -91,7 +108,7 @@ struct LaunchPlan {
 };
 
 // Computes the dynamic-LDS footprint for (n_slots, B, list_cap); returns 0 if it cannot fit.
-size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed = false);
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed = false, uint32_t word_level = 0);
 size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap);
 
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);

@@ -334,6 +334,9 @@ __device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32
 // node pairs are 16-byte aligned (one ds_read_b128 reads two nodes), and consecutive slots are (B+2)*8 bytes
 // = 12/20/28/36 banks apart for B = 4/8/12/16, so 16 consecutive slots start on 16 distinct 4-bank groups.
 constexpr uint32_t kSummMinTile = 4;  // tiles of at least this many nodes keep per-slot summaries
+__host__ __device__ inline uint32_t rmq_levels(uint32_t word_level, bool max_table) {
+  return word_level == 0 ? 1u : ((max_table && word_level < 2) ? 1u : kRangeLevels);
+}
 struct Carve {
   size_t dom, summ, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
 };
@@ -343,14 +346,17 @@ __host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u 
 __host__ __device__ inline uint32_t row_stride16(uint32_t B) { return B + 4u; }
 // dom_slots: slots whose domains live in LDS (all of them, or only the constants in the global variant);
 // mask_slots: slots covered by the changed-variable bitmasks (always all).
-__host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t list_cap, uint32_t mask_slots, bool packed = false) {
+__host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t list_cap, uint32_t mask_slots, bool packed = false, uint32_t word_level = 0) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   const size_t Wv = (mask_slots + 31) / 32;
   Carve c;
   size_t o = 0;
   c.dom = o; o = up(o + (packed ? (size_t)row_stride16(B) * dom_slots * 4 : (size_t)row_stride(B) * dom_slots * 8));
   // tile summaries (level-0 test of the sweep): two cells per slot, (min -lb, min ub) and (max -lb, max ub) over the nodes
-  c.summ = o; o = up(o + (B >= kSummMinTile ? (size_t)dom_slots * 2 * (packed ? 4 : 8) : 0));
+  // packed tiles keep them as two tables Tmin[levels][slots], Tmax[levels][slots] of dwords; with the word-group sweep
+  // levels 1..5 hold the minima / maxima over 2^level consecutive slots (range queries of the level -1 test).
+  c.summ = o; o = up(o + (B >= kSummMinTile ? (packed ? (size_t)dom_slots * 4 * (rmq_levels(word_level, false) + rmq_levels(word_level, true))
+                                                     : (size_t)dom_slots * 2 * 8) : 0));
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
@@ -362,9 +368,9 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   return c;
 }
 
-size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed) {
+size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed, uint32_t word_level) {
   (void)block;
-  Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots, packed);
+  Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots, packed, packed ? word_level : 0);
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
@@ -375,10 +381,17 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
 enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10 };
 
+// Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
+// unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
+struct SummPtr {
+  const void* a;  // packed: tmin;  unpacked: summ
+  const void* b;  // packed: tmax
+};
 struct BlockCtx {
   void* dom;    // LDS domains [slot][bp]: int2 (-lb,ub), or packed dwords; global variant: the constants' singletons [slot - n_vars]
   uint32_t bp;  // row stride of dom, in cells
-  void* summ;   // LDS tile summaries [slot][2] cells (B >= kSummMinTile)
+  SummPtr summ; // LDS tile summaries (B >= kSummMinTile)
+  uint32_t rmq_stride;  // packed: dwords between two levels of a table (= slots)
   uint32_t S, Wv;
   uint32_t* misc;
   int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
@@ -760,13 +773,14 @@ __device__ __forceinline__ Rec expand(const Rec r) { return r; }
 // sweep is re-run by the wake-up rounds anyway, so a stale summary is the same race as reading the domain a moment
 // before the narrowing.
 template <int KIND, bool PACKED>
-__device__ __forceinline__ void level0_chunk(int (&o)[4], const typename CellOf<PACKED>::type* const (&sx)[4],
-                                             const typename CellOf<PACKED>::type* const (&sy)[4], const int (&d)[4]) {
+__device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, const uint32_t (&x)[4], const uint32_t (&y)[4], const int (&d)[4]) {
   if constexpr (PACKED) {
+    const uint32_t* tmin = static_cast<const uint32_t*>(sp.a);
+    const uint32_t* tmax = static_cast<const uint32_t*>(sp.b);
     if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
       uint32_t xs[4], ys[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { xs[j] = *sx[j]; ys[j] = *sy[j]; }
+      for (int j = 0; j < 4; ++j) { xs[j] = tmin[x[j]]; ys[j] = tmin[y[j]]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint32_t t;
@@ -774,19 +788,20 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const typename CellOf<
         o[j] = (lo16(t) + (d[j] - 1)) | (hi16(t) + (-d[j] - 1));
       }
     } else {
-      uint2 X[4], Y[4];  // .x = mins, .y = maxes
+      uint32_t xn[4], xx[4], yn[4], yx[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { X[j] = *reinterpret_cast<const uint2*>(sx[j]); Y[j] = *reinterpret_cast<const uint2*>(sy[j]); }
+      for (int j = 0; j < 4; ++j) { xn[j] = tmin[x[j]]; xx[j] = tmax[x[j]]; yn[j] = tmin[y[j]]; yx[j] = tmax[y[j]]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c1 = d[j] - 1, c3 = -d[j];
-        o[j] = (hi16(Y[j].x) - hi16(X[j].y) + c1) | (lo16(X[j].x) - lo16(Y[j].y) + c1) | (hi16(X[j].x) + lo16(Y[j].x) + c3);
+        o[j] = (hi16(yn[j]) - hi16(xx[j]) + c1) | (lo16(xn[j]) - lo16(yx[j]) + c1) | (hi16(xn[j]) + lo16(yn[j]) + c3);
       }
     }
   } else {
-    int4 X[4], Y[4];  // (min n, min u, max n, max u)
+    const int4* summ = static_cast<const int4*>(sp.a);  // (min n, min u, max n, max u) per slot
+    int4 X[4], Y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { X[j] = *reinterpret_cast<const int4*>(sx[j]); Y[j] = *reinterpret_cast<const int4*>(sy[j]); }
+    for (int j = 0; j < 4; ++j) { X[j] = summ[x[j]]; Y[j] = summ[y[j]]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c1 = d[j] - 1, c2 = -d[j] - 1, c3 = -d[j];
@@ -921,21 +936,19 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       // level 0: the whole tile at once, on the per-slot summaries
       uint32_t need = 0;  // words with a live record that level 0 could not clear
       if constexpr (B >= (int)kSummMinTile) {
-        const Cell* ksumm = static_cast<const Cell*>(k.summ);
         int o0[kChunk];
-        const Cell* sx[kChunk];
-        const Cell* sy[kChunk];
+        uint32_t sx[kChunk], sy[kChunk];
         int d0[kChunk];
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
           const Rec rec = expand(st.buf[j]);
-          sx[j] = ksumm + 2u * (rec.xk & kSlotMask);
-          sy[j] = ksumm + 2u * rec.y;
+          sx[j] = rec.xk & kSlotMask;
+          sy[j] = rec.y;
           d0[j] = rec.d;
         }
         // one kind branch per chunk, and the eight summary reads of a chunk go out together
-        if (ckind == PCP_NEQ) level0_chunk<PCP_NEQ, PACKED>(o0, sx, sy, d0);
-        else level0_chunk<PCP_LT, PACKED>(o0, sx, sy, d0);
+        if (ckind == PCP_NEQ) level0_chunk<PCP_NEQ, PACKED>(o0, k.summ, sx, sy, d0);
+        else level0_chunk<PCP_LT, PACKED>(o0, k.summ, sx, sy, d0);
         uint64_t bal[kChunk];
         bool any0 = false;
 #pragma unroll
@@ -1106,6 +1119,200 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Word-group sweep (packed tiles, models whose words have descriptors — WordDesc, pcp_internal.h).
+// A wavefront takes 64 consecutive words of the live masks at a time, ONE WORD PER LANE:
+//   * the B nodes' live words are B fully coalesced 512-byte row loads (lane l = word l of that node);
+//   * level -1: the lane tests its word as a whole — 64 records x B nodes — on the range-minimum tables of the tile
+//     summaries: the slots of the word's x (y) operands span a short range [lo,hi], whose (min -lb, min ub) is two
+//     table reads, and the offsets span [dmin,dmax]; the level-0 inequalities with those bounds prove that no record
+//     of the word does anything in any node.  Then nothing of the word is touched: not its records, not the domains;
+//   * the words that fail (a few percent: the variables branched on near this tile) are handed, one at a time, to the
+//     record-level tests of sweep_fast's generic path (lane = record): level 0, level 1, level 2, full filter.
+// ------------------------------------------------------------------------------------------------
+template <int B, bool COMPACT>
+__device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
+                                            uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+  static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane");
+  constexpr bool PACKED = true, GLOBAL = false;
+  using Cell = uint32_t;
+  const Cell* const kdom = static_cast<const Cell*>(k.dom);
+  const uint32_t* const tmin = static_cast<const uint32_t*>(k.summ.a);
+  const uint32_t* const tmax = static_cast<const uint32_t*>(k.summ.b);
+  const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t P = a.m.n_recs, words = (P + 63) >> 6, groups = (words + 63) >> 6;
+  const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
+  const uint64_t* live_src = a.live_in;
+  const uint32_t S = k.rmq_stride;
+  using RecT = typename std::conditional<COMPACT, Rec8, Rec>::type;
+  const RecT* rec_stream;
+  if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
+  uint32_t steps_lane = 0;
+  uint32_t racc[B / 2];  // remaining live records per node, two 16-bit lane counters per register
+#pragma unroll
+  for (int i = 0; i < B / 2; ++i) racc[i] = 0;
+  for (uint32_t g = wave; g < groups; g += nw) {
+    const uint32_t w = g * 64 + lane;
+    const bool wv = w < words;
+    const uint32_t wc = min(w, words - 1);
+    // ---- the live rows of the tile's nodes (node b: 64 consecutive words = 512 contiguous bytes) -------------------
+    uint64_t lv[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      const uint32_t node = node0 + ((uint32_t)b < nb ? (uint32_t)b : 0u);
+      uint64_t v = live_src ? live_src[(size_t)node * words + wc] : ~0ull;
+      if (wc == words - 1) v &= tail_mask;
+      lv[b] = (wv && (uint32_t)b < nb) ? v : 0ull;
+    }
+    // ---- level -1: the whole word against the range tables --------------------------------------------------------
+    const WordDesc q = a.m.wdesc[wc];
+    const uint32_t cls = (q.k >> 8) & 15u;
+    bool fail = true;
+    {
+      const uint32_t kx = q.k & 15u, ky = (q.k >> 4) & 15u;
+      const uint32_t xa = __umul24(kx, S) + (q.x & 0xffffu), xb = __umul24(kx, S) + (q.x >> 16);
+      const uint32_t ya = __umul24(ky, S) + (q.y & 0xffffu), yb = __umul24(ky, S) + (q.y >> 16);
+      const uint32_t Xn = pk_min(tmin[xa], tmin[xb]), Yn = pk_min(tmin[ya], tmin[yb]);  // (min -lb, min ub) over the range
+      const int dmin = lo16(q.d), dmax = hi16(q.d);
+      if (cls == 1) {
+        uint32_t t;
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(Xn), "v"(Yn));  // (Xn + Yu, Xu + Yn)
+        fail = ((lo16(t) + dmin - 1) | (hi16(t) - dmax - 1)) < 0;
+      } else if (cls == 2 && a.word_level >= 2) {
+        const uint32_t Xx = pk_max(tmax[xa], tmax[xb]), Yx = pk_max(tmax[ya], tmax[yb]);
+        fail = ((hi16(Yn) - hi16(Xx) + dmin - 1) | (lo16(Xn) - lo16(Yx) + dmin - 1) | (hi16(Xn) + lo16(Yn) - dmax)) < 0;
+      }
+    }
+    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint64_t alive = 0;
+#pragma unroll
+    for (int b = 0; b < B; ++b) { alive |= lv[b]; steps_lane += __popcll(lv[b]); }  // every live record of every node runs once
+    uint64_t hard = __ballot(alive != 0 && (fail || failm != 0));
+    if (PCP_ABLATE & 512) steps3 += __popcll(hard);  // profiling: words that reach the record level
+    if (PCP_ABLATE & 16) hard = 0;
+    uint32_t changed = 0;  // per lane: nodes whose word (this lane's) changed
+    // ---- record level, one word at a time (lane = record) -----------------------------------------------------------
+    // The records of up to kBatch flagged words are fetched together: the load latency (an L2 round trip) is paid once
+    // per batch instead of once per word.
+    constexpr int kBatch = 4;
+    while (hard) {
+      uint32_t jx[kBatch];
+      RecT rb[kBatch];
+      uint32_t nbat = 0;
+#pragma unroll
+      for (int t = 0; t < kBatch; ++t) {
+        if (hard) { jx[t] = __builtin_ctzll(hard); hard &= hard - 1; ++nbat; } else { jx[t] = jx[0]; }
+        rb[t] = (rec_stream + (size_t)(g * 64 + jx[t]) * 64)[lane];
+      }
+      for (uint32_t t = 0; t < nbat; ++t) {
+      uint32_t j = jx[0];
+      RecT rsel = rb[0];
+#pragma unroll
+      for (int u = 1; u < kBatch; ++u)
+        if (t == (uint32_t)u) { j = jx[u]; rsel = rb[u]; }
+      const uint64_t alive_w = readlane64(alive, j);
+      const Rec rec = expand(rsel);
+      const uint32_t kind = rec.xk >> 28;
+      const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
+      const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
+      const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
+      // (built on demand) the words of this column, one node per lane (lane b = node b), for the dynamic node loop below
+      uint64_t col = 0;
+      auto build_col = [&]() {
+#pragma unroll
+        for (int b = 0; b < B; ++b) col = writelane64(col, readlane64(lv[b], j), (uint32_t)b);
+      };
+      uint32_t todo = 0;
+      if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+        bool run2 = true;
+        if (kind0 != PCP_EQ) {
+          // level 0 on the per-slot summaries, then level 1 on every node
+          int o0;
+          {
+            const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y];
+            if (kind0 == PCP_NEQ) {
+              uint32_t t;
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(xs), "v"(ys));
+              o0 = (lo16(t) + (rec.d - 1)) | (hi16(t) + (-rec.d - 1));
+            } else {
+              const uint32_t xx = tmax[rec.xk & kSlotMask], yx = tmax[rec.y];
+              o0 = (hi16(ys) - hi16(xx) + rec.d - 1) | (lo16(xs) - lo16(yx) + rec.d - 1) | (hi16(xs) + lo16(ys) - rec.d);
+            }
+          }
+          run2 = (__ballot(o0 < 0) & alive_w) != 0;
+          if (run2) {
+            const int o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
+            run2 = (__ballot(o < 0) & alive_w) != 0;
+          }
+        }
+        if (run2) {
+          // level 2: which nodes have a live lane that would act
+          build_col();
+#pragma unroll
+          for (int g4 = 0; g4 < B; g4 += 4) {
+            const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
+            const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g4, 16));
+            const uint32_t xs[4] = {Xq.x, Xq.y, Xq.z, Xq.w}, ys[4] = {Yq.x, Yq.y, Yq.z, Yq.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
+              const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
+              uint64_t f;
+              if (kind0 == PCP_NEQ) f = fast_flag<PCP_NEQ>(X, Y.x + rec.d, Y.y + rec.d);
+              else if (kind0 == PCP_LT) f = fast_flag<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d);
+              else f = fast_flag<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d);
+              todo |= (f & wd) ? (1u << (g4 + jj)) : 0u;
+            }
+          }
+          todo = __builtin_amdgcn_readfirstlane(todo);
+        }
+      } else {
+        // mixed kinds or a failed node in the tile: every node with a live record, straight to the full filter
+        build_col();
+        for (uint32_t b = 0; b < nb; ++b)
+          if (readlane64(col, b) != 0 && !((failm >> b) & 1u)) todo |= 1u << b;
+      }
+      if (todo == 0) continue;
+      uint64_t ncol = col;
+      while (todo) {
+        const uint32_t b = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const uint64_t word = readlane64(col, b);
+        bool e = false;
+        if ((word >> lane) & 1ull) {
+          const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
+          e = eval_record(rec, dm);
+        }
+        ncol = writelane64(ncol, word & ~__ballot(e), b);
+      }
+      if (__ballot(ncol != col)) {  // some node's word lost records: back into the row registers of lane j
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const uint64_t nv = readlane64(ncol, (uint32_t)b);
+          if (lane == j && nv != lv[b]) { lv[b] = nv; changed |= 1u << b; }
+        }
+      }
+      }  // batch
+    }
+    // ---- accounting, write-back ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      racc[b / 2] += (uint32_t)__popcll(lv[b]) << (16 * (b & 1));
+      if (wv && (uint32_t)b < nb && (live_src != a.live || ((changed >> b) & 1u))) a.live[(size_t)(node0 + b) * words + w] = lv[b];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+    if (lane == 0 && (uint32_t)b < nb && r) atomicAdd(&remaining[b], r);
+  }
+  for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
+  steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
+  (void)steps3;
+}
+
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
 // the live records that touch a variable in `cur`.  Rare path, generic code.
 template <bool GLOBAL, bool PACKED>
@@ -1165,7 +1372,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   constexpr uint32_t BP = PACKED ? (uint32_t)B + 4u : ((B == 1) ? 1u : (uint32_t)B + 2u);
   using Cell = typename CellOf<PACKED>::type;
   // global variant: only the constants' singleton domains are kept in LDS (slots n_vars..S-1)
-  const Carve cv = carve(GLOBAL ? S - V : S, B, C, S, PACKED);
+  const Carve cv = carve(GLOBAL ? S - V : S, B, C, S, PACKED, PACKED ? a.word_level : 0);
   Cell* dom = reinterpret_cast<Cell*>(smem + cv.dom);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
   uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
@@ -1184,7 +1391,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
     if (a.status[node0] != kStatusRetry) return;
   }
-  const BlockCtx k{dom, BP, smem + cv.summ, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
+  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   if (tid < 16) misc[tid] = 0;
@@ -1231,9 +1438,10 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   }
   if constexpr (!GLOBAL && B >= (int)kSummMinTile) {
     // tile summaries for the sweep's level-0 test: per slot (min -lb, min ub) and (max -lb, max ub) over the tile's nodes
-    Cell* summ = reinterpret_cast<Cell*>(smem + cv.summ);
-    for (uint32_t v = tid; v < S; v += nth) {
-      if constexpr (PACKED) {
+    if constexpr (PACKED) {
+      uint32_t* tmin = reinterpret_cast<uint32_t*>(smem + cv.summ);
+      uint32_t* tmax = tmin + (size_t)S * rmq_levels(a.word_level, false);
+      for (uint32_t v = tid; v < S; v += nth) {
         uint32_t mn = 0x7fff7fffu, mx = 0x80008000u;
 #pragma unroll
         for (int b = 0; b < B; b += 4) {
@@ -1241,8 +1449,22 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           mn = pk_min(pk_min(mn, q.x), pk_min(q.y, pk_min(q.z, q.w)));
           mx = pk_max(pk_max(mx, q.x), pk_max(q.y, pk_max(q.z, q.w)));
         }
-        summ[2 * v] = mn; summ[2 * v + 1] = mx;
-      } else {
+        tmin[v] = mn; tmax[v] = mx;
+      }
+      // range tables of the level -1 test: level l holds the minimum (maximum) over slots [v, v + 2^l)
+      if (a.word_level) {
+        for (uint32_t l = 1; l < kRangeLevels; ++l) {
+          __syncthreads();
+          for (uint32_t v = tid; v < S; v += nth) {
+            const uint32_t v2 = min(v + (1u << (l - 1)), S - 1);
+            tmin[l * S + v] = pk_min(tmin[(l - 1) * S + v], tmin[(l - 1) * S + v2]);
+            if (a.word_level >= 2) tmax[l * S + v] = pk_max(tmax[(l - 1) * S + v], tmax[(l - 1) * S + v2]);
+          }
+        }
+      }
+    } else {
+      Cell* summ = reinterpret_cast<Cell*>(smem + cv.summ);
+      for (uint32_t v = tid; v < S; v += nth) {
         int2 mn = make_int2(0x7fffffff, 0x7fffffff), mx = make_int2(-0x7fffffff - 1, -0x7fffffff - 1);
 #pragma unroll
         for (int b = 0; b < B; ++b) {
@@ -1267,7 +1489,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       w0 = min(words, g * ws); w1 = min(words, w0 + ws);
     }
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
-    if (w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
+    bool swept = false;
+    if constexpr (PACKED && B <= 16) {
+      if (a.word_level) { sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, steps2, steps3, ctr); swept = true; }  // team == 1 here
+    }
+    if (!swept && w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
