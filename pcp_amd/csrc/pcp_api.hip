@@ -211,27 +211,43 @@ int32_t finalize_model(pcp_ctx* c) {
     size_t good = 0;
     bool any_lt = false;
     auto lg = [](uint32_t len) { uint32_t k = 0; while ((2u << k) <= len) ++k; return k; };
-    for (size_t w = 0; w < W; ++w) {
-      const size_t r0 = w * 64, r1 = std::min(P, r0 + 64);
+    // one part: records [r0, r1) of one binary kind whose x and y slots each span < kRangeMax and whose offsets fit int16
+    auto make_part = [&](size_t r0, size_t r1, WordPart& out) {
       const uint32_t kind = recs[r0].xk >> 28;
+      if (kind != PCP_NEQ && kind != PCP_LT) return false;
       uint32_t xlo = ~0u, xhi = 0, ylo = ~0u, yhi = 0;
       int32_t dmin = INT32_MAX, dmax = INT32_MIN;
-      bool same = (kind == PCP_NEQ || kind == PCP_LT);
-      for (size_t r = r0; r < r1 && same; ++r) {
-        same = (recs[r].xk >> 28) == kind;
+      for (size_t r = r0; r < r1; ++r) {
+        if ((recs[r].xk >> 28) != kind) return false;
         const uint32_t x = recs[r].xk & kSlotMask, y = recs[r].y;
         xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, y); yhi = std::max(yhi, y);
         dmin = std::min(dmin, recs[r].d); dmax = std::max(dmax, recs[r].d);
       }
-      WordDesc q{0, 0, 0, 0};
-      if (same && xhi - xlo < kRangeMax && yhi - ylo < kRangeMax && dmin >= -30000 && dmax <= 30000) {
-        const uint32_t kx = lg(xhi - xlo + 1), ky = lg(yhi - ylo + 1);
-        q.x = xlo | ((xhi - (1u << kx) + 1) << 16);
-        q.y = ylo | ((yhi - (1u << ky) + 1) << 16);
-        q.k = kx | (ky << 4) | ((kind == PCP_NEQ ? 1u : 2u) << 8);
-        q.d = ((uint32_t)dmin & 0xffffu) | ((uint32_t)dmax << 16);
+      if (xhi - xlo >= kRangeMax || yhi - ylo >= kRangeMax || dmin < -30000 || dmax > 30000) return false;
+      const uint32_t kx = lg(xhi - xlo + 1), ky = lg(yhi - ylo + 1);
+      out.x = xlo | ((xhi - (1u << kx) + 1) << 16);
+      out.y = ylo | ((yhi - (1u << ky) + 1) << 16);
+      out.k = kx | (ky << 4) | ((kind == PCP_NEQ ? 1u : 2u) << 8);
+      out.d = ((uint32_t)dmin & 0xffffu) | ((uint32_t)dmax << 16);
+      any_lt |= kind == PCP_LT;
+      return true;
+    };
+    for (size_t w = 0; w < W; ++w) {
+      const size_t r0 = w * 64, r1 = std::min(P, r0 + 64);
+      WordDesc q;
+      memset(&q, 0, sizeof(q));
+      if (make_part(r0, r1, q.a)) {
         ++good;
-        any_lt |= kind == PCP_LT;
+      } else {
+        size_t rs = r0 + 1;  // first change of x
+        while (rs < r1 && (recs[rs].xk & kSlotMask) == (recs[r0].xk & kSlotMask)) ++rs;
+        WordPart pa, pb;
+        if (rs < r1 && make_part(r0, rs, pa) && make_part(rs, r1, pb) && (pa.k >> 8) == (pb.k >> 8)) {
+          q.a = pa; q.b = pb; q.a.k |= 1u << 12;
+          ++good;
+        } else {
+          memset(&q, 0, sizeof(q));
+        }
       }
       wd[w] = q;
     }
@@ -479,18 +495,27 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
   if (!use_team && !global_dom && c->opt_packed && c->compact && c->consts_fit16 && (!c->hull_set || hull_fits16)) {
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
-    const uint32_t wl = c->opt_word_level ? c->word_level : 0;  // the word-group sweep keeps B live registers per lane: B <= 16
+    // The word-group sweep keeps B live registers per lane (B <= 16) and notes the words for the record level in a
+    // bitmap that borrows the changed-pair list's LDS: one u64 per 64 words, so list_cap must not drop below that.
+    const uint32_t wl_model = c->opt_word_level ? c->word_level : 0;
+    const uint32_t groups = (words + 63) / 64;
     for (uint32_t t : {32u, 16u, 8u}) {
-      if (t > want || (wl && t > 16)) continue;
-      auto need_for = [&](uint32_t cap) { return lds_bytes_for(S, t, cap, block, true, wl); };
-      uint32_t cap = list_cap;
-      while (cap > 256 && !(need_for(cap) && need_for(cap) <= c->lds_max)) cap /= 2;
-      const size_t need = need_for(cap);
-      if (!need || need > c->lds_max) continue;
-      const uint32_t ch = fits(t / 2);
-      if (!ch) continue;
-      Bp = t; cap_p = cap; cap_half = ch; wl_used = wl;
-      break;
+      if (t > want) continue;
+      for (uint32_t wl : {wl_model, 0u}) {
+        if (wl && t > 16) continue;
+        auto need_for = [&](uint32_t cap) { return lds_bytes_for(S, t, cap, block, true, wl); };
+        const uint32_t cap_min = std::max<uint32_t>(256, wl ? groups : 0);
+        uint32_t cap = std::max(list_cap, cap_min);
+        while (cap / 2 >= cap_min && !(need_for(cap) && need_for(cap) <= c->lds_max)) cap /= 2;
+        const size_t need = need_for(cap);
+        if (!need || need > c->lds_max) continue;
+        const uint32_t ch = fits(t / 2);
+        if (!ch) continue;
+        Bp = t; cap_p = cap; cap_half = ch; wl_used = wl;
+        break;
+      }
+      if (Bp) break;
+      if (!wl_model) continue;
     }
     if (Bp * 2 <= B) Bp = 0;  // a 32-bit tile with at least twice the nodes wins
   }

@@ -39,13 +39,18 @@ constexpr uint32_t kCompactSlots = 1u << 15;
 // common.  cls = 1 (all XNeqY) or 2 (all XLessY) when the operand slots of the word span at most kRangeMax consecutive
 // slots each and every offset fits 16 bits, else 0 (the word always goes to the record-level tests).  A slot range
 // [lo, hi] is queried in the tile's range-minimum tables as min(T[k][lo], T[k][second]) with 2^k <= hi-lo+1 < 2^(k+1).
-struct __attribute__((aligned(16))) WordDesc {
+struct __attribute__((aligned(16))) WordPart {
   uint32_t x;  // xlo | second_x << 16
   uint32_t y;  // ylo | second_y << 16
-  uint32_t k;  // kx | ky << 4 | cls << 8
+  uint32_t k;  // kx | ky << 4 | cls << 8 | (part b present) << 12
   uint32_t d;  // (dmin & 0xffff) | dmax << 16     (int16 each)
 };
-static_assert(sizeof(WordDesc) == 16, "WordDesc must be 16 bytes");
+// A word that straddles two x-blocks of a table sorted by x (its y operands jump back) is described as two parts, the
+// records before and after the first change of x; the word passes level -1 when both parts do.
+struct __attribute__((aligned(16))) WordDesc {
+  WordPart a, b;
+};
+static_assert(sizeof(WordDesc) == 32, "WordDesc must be 32 bytes");
 constexpr uint32_t kRangeMax = 64;    // longest slot range a descriptor may cover
 constexpr uint32_t kRangeLevels = 7;  // table levels 2^0 .. 2^6
 

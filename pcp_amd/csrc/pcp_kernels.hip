@@ -1121,19 +1121,21 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 
 // ------------------------------------------------------------------------------------------------
 // Word-group sweep (packed tiles, models whose words have descriptors — WordDesc, pcp_internal.h).
-// A wavefront takes 64 consecutive words of the live masks at a time, ONE WORD PER LANE:
+// Phase A streams the live masks, ONE WORD PER LANE, 64 consecutive words per wavefront step:
 //   * the B nodes' live words are B fully coalesced 512-byte row loads (lane l = word l of that node);
 //   * level -1: the lane tests its word as a whole — 64 records x B nodes — on the range-minimum tables of the tile
 //     summaries: the slots of the word's x (y) operands span a short range [lo,hi], whose (min -lb, min ub) is two
 //     table reads, and the offsets span [dmin,dmax]; the level-0 inequalities with those bounds prove that no record
 //     of the word does anything in any node.  Then nothing of the word is touched: not its records, not the domains;
-//   * the words that fail (a few percent: the variables branched on near this tile) are handed, one at a time, to the
-//     record-level tests of sweep_fast's generic path (lane = record): level 0, level 1, level 2, full filter.
+//   * words that fail are only noted in a bitmap (LDS: the changed-pair list's space, idle until the rounds).
+// Phase B hands the noted words (a few percent: the variables branched on near this tile, words that straddle two
+// x-blocks) to the record-level tests, lane = record: level 0, level 1, level 2, full filter.  Word w goes to wavefront
+// w mod 16; the records and the node column of four words are fetched together.
 // ------------------------------------------------------------------------------------------------
 template <int B, bool COMPACT>
 __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
-                                            uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
-  static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane");
+                                            uint32_t* remaining, uint32_t* hardmap, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+  static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane; a node column fits one DPP row");
   constexpr bool PACKED = true, GLOBAL = false;
   using Cell = uint32_t;
   const Cell* const kdom = static_cast<const Cell*>(k.dom);
@@ -1148,15 +1150,20 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
   using RecT = typename std::conditional<COMPACT, Rec8, Rec>::type;
   const RecT* rec_stream;
   if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
+  uint64_t* const hard64 = reinterpret_cast<uint64_t*>(hardmap);  // [groups]
   uint32_t steps_lane = 0;
   uint32_t racc[B / 2];  // remaining live records per node, two 16-bit lane counters per register
 #pragma unroll
   for (int i = 0; i < B / 2; ++i) racc[i] = 0;
+  const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // empty input domains
+  uint64_t tseg[2] = {0, 0};  // PCP_ABLATE & 128: s_memtime ticks of phase A / phase B
+  uint32_t n_l0 = 0, n_l1 = 0, n_l2 = 0;  // words that reached level 0 / 1 / 2
+  const uint64_t tA = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
+  // ================= phase A =================
   for (uint32_t g = wave; g < groups; g += nw) {
     const uint32_t w = g * 64 + lane;
     const bool wv = w < words;
     const uint32_t wc = min(w, words - 1);
-    // ---- the live rows of the tile's nodes (node b: 64 consecutive words = 512 contiguous bytes) -------------------
     uint64_t lv[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -1165,11 +1172,9 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
       if (wc == words - 1) v &= tail_mask;
       lv[b] = (wv && (uint32_t)b < nb) ? v : 0ull;
     }
-    // ---- level -1: the whole word against the range tables --------------------------------------------------------
-    const WordDesc q = a.m.wdesc[wc];
-    const uint32_t cls = (q.k >> 8) & 15u;
-    bool fail = true;
-    {
+    // level -1: the whole word against the range tables
+    auto part_fails = [&](const WordPart q) -> bool {
+      const uint32_t cls = (q.k >> 8) & 15u;
       const uint32_t kx = q.k & 15u, ky = (q.k >> 4) & 15u;
       const uint32_t xa = __umul24(kx, S) + (q.x & 0xffffu), xb = __umul24(kx, S) + (q.x >> 16);
       const uint32_t ya = __umul24(ky, S) + (q.y & 0xffffu), yb = __umul24(ky, S) + (q.y >> 16);
@@ -1178,53 +1183,77 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
       if (cls == 1) {
         uint32_t t;
         asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(Xn), "v"(Yn));  // (Xn + Yu, Xu + Yn)
-        fail = ((lo16(t) + dmin - 1) | (hi16(t) - dmax - 1)) < 0;
-      } else if (cls == 2 && a.word_level >= 2) {
-        const uint32_t Xx = pk_max(tmax[xa], tmax[xb]), Yx = pk_max(tmax[ya], tmax[yb]);
-        fail = ((hi16(Yn) - hi16(Xx) + dmin - 1) | (lo16(Xn) - lo16(Yx) + dmin - 1) | (hi16(Xn) + lo16(Yn) - dmax)) < 0;
+        return ((lo16(t) + dmin - 1) | (hi16(t) - dmax - 1)) < 0;
       }
-    }
-    const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (cls == 2 && a.word_level >= 2) {
+        const uint32_t Xx = pk_max(tmax[xa], tmax[xb]), Yx = pk_max(tmax[ya], tmax[yb]);
+        return ((hi16(Yn) - hi16(Xx) + dmin - 1) | (lo16(Xn) - lo16(Yx) + dmin - 1) | (hi16(Xn) + lo16(Yn) - dmax)) < 0;
+      }
+      return true;  // no descriptor: always to the record level
+    };
+    const WordPart qa = a.m.wdesc[wc].a;
+    bool fail = part_fails(qa);
+    if (!fail && ((qa.k >> 12) & 1u)) fail = part_fails(a.m.wdesc[wc].b);  // a word that straddles two x-blocks
     uint64_t alive = 0;
 #pragma unroll
-    for (int b = 0; b < B; ++b) { alive |= lv[b]; steps_lane += __popcll(lv[b]); }  // every live record of every node runs once
+    for (int b = 0; b < B; ++b) {
+      alive |= lv[b];
+      const uint32_t pc = (uint32_t)__popcll(lv[b]);
+      steps_lane += pc;                    // every live record of every node runs once
+      racc[b / 2] += pc << (16 * (b & 1));
+      if (wv && (uint32_t)b < nb && live_src != a.live) a.live[(size_t)(node0 + b) * words + w] = lv[b];
+    }
     uint64_t hard = __ballot(alive != 0 && (fail || failm != 0));
-    if (PCP_ABLATE & 512) steps3 += __popcll(hard);  // profiling: words that reach the record level
     if (PCP_ABLATE & 16) hard = 0;
-    uint32_t changed = 0;  // per lane: nodes whose word (this lane's) changed
-    // ---- record level, one word at a time (lane = record) -----------------------------------------------------------
-    // The records of up to kBatch flagged words are fetched together: the load latency (an L2 round trip) is paid once
-    // per batch instead of once per word.
-    constexpr int kBatch = 4;
-    while (hard) {
-      uint32_t jx[kBatch];
-      RecT rb[kBatch];
-      uint32_t nbat = 0;
+    if (PCP_ABLATE & 128) n_l0 += __popcll(hard);
+    if (lane == 0) hard64[g] = hard;
+  }
 #pragma unroll
-      for (int t = 0; t < kBatch; ++t) {
-        if (hard) { jx[t] = __builtin_ctzll(hard); hard &= hard - 1; ++nbat; } else { jx[t] = jx[0]; }
-        rb[t] = (rec_stream + (size_t)(g * 64 + jx[t]) * 64)[lane];
-      }
-      for (uint32_t t = 0; t < nbat; ++t) {
-      uint32_t j = jx[0];
+  for (int b = 0; b < B; ++b) {
+    uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+    if (lane == 0 && (uint32_t)b < nb && r) atomicAdd(&remaining[b], r);
+  }
+  for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
+  steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's live stores are out before anyone re-reads the rows
+  __syncthreads();
+  const uint64_t tB = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
+  // ================= phase B =================
+  uint64_t pattern = 0;  // the words of a group this wavefront takes: bit positions congruent to `wave` modulo the wavefront count
+  for (uint32_t i = wave; i < 64; i += nw) pattern |= 1ull << i;
+  constexpr int kBatch = 4;
+  uint32_t pend[kBatch];
+  uint32_t npend = 0;
+  uint64_t* const my_live = a.live + (size_t)(node0 + (lane < nb ? lane : 0u)) * words;  // lane b = node b: the word's column
+  auto flush = [&]() {
+    RecT rb[kBatch];
+    uint64_t cb[kBatch];
+#pragma unroll
+    for (int t = 0; t < kBatch; ++t) {
+      const uint32_t ww = pend[(uint32_t)t < npend ? t : 0];
+      rb[t] = (rec_stream + (size_t)ww * 64)[lane];
+      const uint64_t v = __hip_atomic_load(my_live + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: phase A stored it
+      cb[t] = lane < nb ? (ww == words - 1 ? v & tail_mask : v) : 0ull;
+    }
+    for (uint32_t t = 0; t < npend; ++t) {
+      uint32_t ww = pend[0];
       RecT rsel = rb[0];
+      uint64_t col = cb[0];
 #pragma unroll
       for (int u = 1; u < kBatch; ++u)
-        if (t == (uint32_t)u) { j = jx[u]; rsel = rb[u]; }
-      const uint64_t alive_w = readlane64(alive, j);
+        if (t == (uint32_t)u) { ww = pend[u]; rsel = rb[u]; col = cb[u]; }
+      // alive_w: OR of the column over the nodes (lanes 0..B-1 sit in one DPP row)
+      const uint64_t alive_w = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(col >> 32))) << 32) |
+                               __builtin_amdgcn_readfirstlane(row_or16((uint32_t)col));
       const Rec rec = expand(rsel);
       const uint32_t kind = rec.xk >> 28;
       const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
       const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
       const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
-      // (built on demand) the words of this column, one node per lane (lane b = node b), for the dynamic node loop below
-      uint64_t col = 0;
-      auto build_col = [&]() {
-#pragma unroll
-        for (int b = 0; b < B; ++b) col = writelane64(col, readlane64(lv[b], j), (uint32_t)b);
-      };
+      const uint32_t failnow = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       uint32_t todo = 0;
-      if (__all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+      if (__all(kind == kind0) && kind0 <= PCP_LT && failnow == 0) {
         bool run2 = true;
         if (kind0 != PCP_EQ) {
           // level 0 on the per-slot summaries, then level 1 on every node
@@ -1232,9 +1261,9 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
           {
             const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y];
             if (kind0 == PCP_NEQ) {
-              uint32_t t;
-              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(xs), "v"(ys));
-              o0 = (lo16(t) + (rec.d - 1)) | (hi16(t) + (-rec.d - 1));
+              uint32_t t2;
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(xs), "v"(ys));
+              o0 = (lo16(t2) + (rec.d - 1)) | (hi16(t2) + (-rec.d - 1));
             } else {
               const uint32_t xx = tmax[rec.xk & kSlotMask], yx = tmax[rec.y];
               o0 = (hi16(ys) - hi16(xx) + rec.d - 1) | (lo16(xs) - lo16(yx) + rec.d - 1) | (hi16(xs) + lo16(ys) - rec.d);
@@ -1242,13 +1271,14 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
           }
           run2 = (__ballot(o0 < 0) & alive_w) != 0;
           if (run2) {
+            if (PCP_ABLATE & 128) ++n_l1;
             const int o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
             run2 = (__ballot(o < 0) & alive_w) != 0;
+            if ((PCP_ABLATE & 128) && run2) ++n_l2;
           }
         }
         if (run2) {
           // level 2: which nodes have a live lane that would act
-          build_col();
 #pragma unroll
           for (int g4 = 0; g4 < B; g4 += 4) {
             const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
@@ -1269,9 +1299,8 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
         }
       } else {
         // mixed kinds or a failed node in the tile: every node with a live record, straight to the full filter
-        build_col();
         for (uint32_t b = 0; b < nb; ++b)
-          if (readlane64(col, b) != 0 && !((failm >> b) & 1u)) todo |= 1u << b;
+          if (readlane64(col, b) != 0 && !((failnow >> b) & 1u)) todo |= 1u << b;
       }
       if (todo == 0) continue;
       uint64_t ncol = col;
@@ -1286,31 +1315,34 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
         }
         ncol = writelane64(ncol, word & ~__ballot(e), b);
       }
-      if (__ballot(ncol != col)) {  // some node's word lost records: back into the row registers of lane j
-#pragma unroll
-        for (int b = 0; b < B; ++b) {
-          const uint64_t nv = readlane64(ncol, (uint32_t)b);
-          if (lane == j && nv != lv[b]) { lv[b] = nv; changed |= 1u << b; }
-        }
+      if (lane < nb && ncol != col) {  // entailed records: unlink them (store.rs:200-207)
+        my_live[ww] = ncol;
+        atomicSub(&remaining[lane], (uint32_t)(__popcll(col) - __popcll(ncol)));
       }
-      }  // batch
     }
-    // ---- accounting, write-back ---------------------------------------------------------------------------------------
+    npend = 0;
+  };
+  for (uint32_t g = 0; g < groups; ++g) {
+    uint64_t bits = hard64[g] & pattern;
+    while (bits) {
+      const uint32_t j = __builtin_ctzll(bits);
+      bits &= bits - 1;
+      // SGPR array with a dynamic index: written as selects
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      racc[b / 2] += (uint32_t)__popcll(lv[b]) << (16 * (b & 1));
-      if (wv && (uint32_t)b < nb && (live_src != a.live || ((changed >> b) & 1u))) a.live[(size_t)(node0 + b) * words + w] = lv[b];
+      for (int u = 0; u < kBatch; ++u)
+        if (npend == (uint32_t)u) pend[u] = g * 64 + j;
+      if (++npend == kBatch) flush();
     }
   }
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
-    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
-    if (lane == 0 && (uint32_t)b < nb && r) atomicAdd(&remaining[b], r);
-  }
-  for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
-  steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
+  if (npend) flush();
   (void)steps3;
+  if ((PCP_ABLATE & 128) && lane == 0) {  // profiling build (tools/seg_words.py)
+    const uint64_t tE = __builtin_amdgcn_s_memtime();
+    tseg[0] = tB - tA; tseg[1] = tE - tB;
+    atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)tseg[0]);
+    atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)tseg[1]);
+    atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)n_l0 | ((unsigned long long)n_l1 << 24) | ((unsigned long long)n_l2 << 44));
+  }
 }
 
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
@@ -1491,7 +1523,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
     bool swept = false;
     if constexpr (PACKED && B <= 16) {
-      if (a.word_level) { sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, steps2, steps3, ctr); swept = true; }  // team == 1 here
+      if (a.word_level) { sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr); swept = true; }  // team == 1 here
     }
     if (!swept && w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
