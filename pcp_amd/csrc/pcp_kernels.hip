@@ -433,6 +433,18 @@ __device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const 
   return __ballot(X.x != Yl) | __ballot(X.y != Yu) | __ballot(X.x == X.y);
 }
 
+// The lanes on which the propagator is entailed WITHOUT touching a domain (its propagate() is a no-op and is_subsumed()
+// is True): such lanes only lose their live bit, which the caller does in bulk.
+//  NEQ: the intervals are disjoint (x_neq_y.rs:71-73 via x_eq_y.rs:87-93; Interval::difference of a value outside is a no-op).
+//  LT : X.ub < Y.lb  (x_less_y.rs:90-91; then min(X.ub, Yu-1) = X.ub and max(Yl, X.lb+1) = Yl).
+//  EQ : both are the same singleton (x_eq_y.rs:87-88).
+template <int KIND>
+__device__ __forceinline__ uint64_t pure_entailed(const int2 X, const int Yl, const int Yu) {
+  if (KIND == PCP_NEQ) return __ballot(X.x > Yu) | __ballot(Yl > X.y);
+  if (KIND == PCP_LT) return __ballot(X.y < Yl);
+  return __ballot(X.x == X.y && Yl == Yu && X.x == Yl);
+}
+
 // The unrolled per-node loop of the fast path.  Nodes are taken four at a time: their x- and y-domains are two
 // ds_read_b128 each (nodes b, b+1 of one slot are 16 adjacent, 16-byte-aligned bytes) at immediate offsets of
 // one address register, all issued before the first compare so that the LDS latency is paid once per group;
@@ -1157,7 +1169,7 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
   for (int i = 0; i < B / 2; ++i) racc[i] = 0;
   const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // empty input domains
   uint64_t tseg[2] = {0, 0};  // PCP_ABLATE & 128: s_memtime ticks of phase A / phase B
-  uint32_t n_l0 = 0, n_l1 = 0, n_l2 = 0;  // words that reached level 0 / 1 / 2
+  uint32_t n_l0 = 0, n_l1 = 0, n_l2 = 0, n_bulk = 0;  // words that reached level 0 / 1 / 2; (word,node) pairs unlinked in bulk
   const uint64_t tA = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
   // ================= phase A =================
   for (uint32_t g = wave; g < groups; g += nw) {
@@ -1226,7 +1238,9 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
   uint32_t pend[kBatch];
   uint32_t npend = 0;
   uint64_t* const my_live = a.live + (size_t)(node0 + (lane < nb ? lane : 0u)) * words;  // lane b = node b: the word's column
+  uint64_t tfl[2] = {0, 0};  // PCP_ABLATE & 128: ticks waiting for a batch's loads / processing it
   auto flush = [&]() {
+    const uint64_t tf0 = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
     RecT rb[kBatch];
     uint64_t cb[kBatch];
 #pragma unroll
@@ -1236,6 +1250,14 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
       const uint64_t v = __hip_atomic_load(my_live + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: phase A stored it
       cb[t] = lane < nb ? (ww == words - 1 ? v & tail_mask : v) : 0ull;
     }
+    uint64_t tf1 = 0;
+    if (PCP_ABLATE & 128) {
+      uint32_t dep = 0;
+#pragma unroll
+      for (int t = 0; t < kBatch; ++t) dep |= (uint32_t)cb[t] | (uint32_t)rb[t].d;
+      tf1 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(dep) & 0u);
+      tfl[0] += tf1 - tf0;
+    }
     for (uint32_t t = 0; t < npend; ++t) {
       uint32_t ww = pend[0];
       RecT rsel = rb[0];
@@ -1243,6 +1265,7 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
 #pragma unroll
       for (int u = 1; u < kBatch; ++u)
         if (t == (uint32_t)u) { ww = pend[u]; rsel = rb[u]; col = cb[u]; }
+      if (PCP_ABLATE & 4096) continue;  // profiling: nothing per word
       // alive_w: OR of the column over the nodes (lanes 0..B-1 sit in one DPP row)
       const uint64_t alive_w = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(col >> 32))) << 32) |
                                __builtin_amdgcn_readfirstlane(row_or16((uint32_t)col));
@@ -1252,7 +1275,9 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
       const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
       const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
       const uint32_t failnow = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((PCP_ABLATE & 8192) && (alive_w | failnow | kind0 | (uint64_t)(size_t)px | (uint64_t)(size_t)py) != 0x123456789ull) continue;  // profiling: preamble only
       uint32_t todo = 0;
+      uint64_t ncol = col;
       if (__all(kind == kind0) && kind0 <= PCP_LT && failnow == 0) {
         bool run2 = true;
         if (kind0 != PCP_EQ) {
@@ -1270,29 +1295,63 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
             }
           }
           run2 = (__ballot(o0 < 0) & alive_w) != 0;
+          if (PCP_ABLATE & 2048) run2 = false;  // profiling: stop after level 0
           if (run2) {
             if (PCP_ABLATE & 128) ++n_l1;
             const int o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
             run2 = (__ballot(o < 0) & alive_w) != 0;
+            if (PCP_ABLATE & 1024) run2 = false;  // profiling: stop after level 1
             if ((PCP_ABLATE & 128) && run2) ++n_l2;
           }
         }
         if (run2) {
-          // level 2: which nodes have a live lane that would act
+          // level 2, node by node: lanes that are merely entailed lose their live bit here, in bulk; only nodes with a
+          // lane whose domains would change go on to the full filter
+          if (kind0 == PCP_NEQ) {
+            // packed form of fast_flag / pure_entailed for XNeqY: T = (Xn + Yu, Xu + Yn); something happens iff
+            // T.lo + d - 1 < 0 or T.hi - d - 1 < 0, and it is a pure entailment iff T.lo + d < 0 or T.hi - d < 0
+            // (saturating adds: |T| <= 32766, |d| may be larger)
+            const int dc = max(-32767, min(32767, rec.d));
+            const uint32_t c1 = ((uint32_t)(dc - 1) & 0xffffu) | ((uint32_t)(-dc - 1) << 16);
+            const uint32_t c0 = ((uint32_t)dc & 0xffffu) | ((uint32_t)(-dc) << 16);
 #pragma unroll
-          for (int g4 = 0; g4 < B; g4 += 4) {
-            const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
-            const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g4, 16));
-            const uint32_t xs[4] = {Xq.x, Xq.y, Xq.z, Xq.w}, ys[4] = {Yq.x, Yq.y, Yq.z, Yq.w};
+            for (int g4 = 0; g4 < B; g4 += 4) {
+              const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
+              const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g4, 16));
+              const uint32_t xs[4] = {Xq.x, Xq.y, Xq.z, Xq.w}, ys[4] = {Yq.x, Yq.y, Yq.z, Yq.w};
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
-              const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
-              uint64_t f;
-              if (kind0 == PCP_NEQ) f = fast_flag<PCP_NEQ>(X, Y.x + rec.d, Y.y + rec.d);
-              else if (kind0 == PCP_LT) f = fast_flag<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d);
-              else f = fast_flag<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d);
-              todo |= (f & wd) ? (1u << (g4 + jj)) : 0u;
+              for (int jj = 0; jj < 4; ++jj) {
+                const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
+                if (wd == 0) continue;
+                uint32_t F, E;
+                asm("v_pk_add_u16 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+                    "v_pk_add_i16 %1, %0, %5 clamp\n\t"
+                    "v_pk_add_i16 %0, %0, %4 clamp"
+                    : "=&v"(F), "=&v"(E) : "v"(xs[jj]), "v"(ys[jj]), "v"(c1), "v"(c0));
+                const uint64_t f = __ballot((F & 0x80008000u) != 0) & wd;
+                const uint64_t en = __ballot((E & 0x80008000u) != 0) & wd;
+                if (en) { ncol = writelane64(ncol, wd & ~en, (uint32_t)(g4 + jj)); if (PCP_ABLATE & 128) ++n_bulk; }
+                todo |= (f & ~en) ? (1u << (g4 + jj)) : 0u;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int g4 = 0; g4 < B; g4 += 4) {
+              const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
+              const uint4 Yq = *static_cast<const uint4*>(__builtin_assume_aligned(py + g4, 16));
+              const uint32_t xs[4] = {Xq.x, Xq.y, Xq.z, Xq.w}, ys[4] = {Yq.x, Yq.y, Yq.z, Yq.w};
+#pragma unroll
+              for (int jj = 0; jj < 4; ++jj) {
+                const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
+                if (wd == 0) continue;
+                const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
+                uint64_t f, en;
+                if (kind0 == PCP_LT) { f = fast_flag<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); en = pure_entailed<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); }
+                else { f = fast_flag<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d); en = pure_entailed<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d); }
+                en &= wd;
+                if (en) { ncol = writelane64(ncol, wd & ~en, (uint32_t)(g4 + jj)); if (PCP_ABLATE & 128) ++n_bulk; }
+                todo |= (f & wd & ~en) ? (1u << (g4 + jj)) : 0u;
+              }
             }
           }
           todo = __builtin_amdgcn_readfirstlane(todo);
@@ -1302,12 +1361,10 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
         for (uint32_t b = 0; b < nb; ++b)
           if (readlane64(col, b) != 0 && !((failnow >> b) & 1u)) todo |= 1u << b;
       }
-      if (todo == 0) continue;
-      uint64_t ncol = col;
       while (todo) {
         const uint32_t b = __builtin_ctz(todo);
         todo &= todo - 1;
-        const uint64_t word = readlane64(col, b);
+        const uint64_t word = readlane64(ncol, b);  // without the lanes already unlinked in bulk
         bool e = false;
         if ((word >> lane) & 1ull) {
           const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
@@ -1321,17 +1378,25 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
       }
     }
     npend = 0;
+    if (PCP_ABLATE & 128) tfl[1] += __builtin_amdgcn_s_memtime() - tf1;
   };
-  for (uint32_t g = 0; g < groups; ++g) {
-    uint64_t bits = hard64[g] & pattern;
-    while (bits) {
-      const uint32_t j = __builtin_ctzll(bits);
-      bits &= bits - 1;
-      // SGPR array with a dynamic index: written as selects
+  for (uint32_t base = 0; base < groups; base += 64) {  // 64 groups per step: lane l looks at group base + l
+    const uint64_t mine = (base + lane < groups) ? (hard64[base + lane] & pattern) : 0ull;
+    uint64_t have = __ballot(mine != 0);
+    while (have) {
+      const uint32_t l = __builtin_ctzll(have);
+      have &= have - 1;
+      uint64_t bits = readlane64(mine, l);
+      const uint32_t g = base + l;
+      while (bits) {
+        const uint32_t j = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        // SGPR array with a dynamic index: written as selects
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u)
-        if (npend == (uint32_t)u) pend[u] = g * 64 + j;
-      if (++npend == kBatch) flush();
+        for (int u = 0; u < kBatch; ++u)
+          if (npend == (uint32_t)u) pend[u] = g * 64 + j;
+        if (++npend == kBatch) flush();
+      }
     }
   }
   if (npend) flush();
@@ -1342,6 +1407,8 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
     atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)tseg[0]);
     atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)tseg[1]);
     atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)n_l0 | ((unsigned long long)n_l1 << 24) | ((unsigned long long)n_l2 << 44));
+    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)tfl[0]);
+    atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)tfl[1]);
   }
 }
 

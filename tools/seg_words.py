@@ -23,3 +23,4 @@ waves = N // 16 * 16
 f = s["failed_nodes"]
 print("kernel %.3f ms; per wavefront: loads + level -1 %.0f ticks, record level %.0f ticks; words reaching level 0: %d, level 1: %d, level 2: %d (per launch)"
       % (ctx.last_kernel_ms(), s["steps3"] / waves, s["narrowings"] / waves, f & 0xFFFFFF, (f >> 24) & 0xFFFFF, f >> 44))
+print("  phase B per wavefront: waiting for batch loads %.0f ticks, processing %.0f ticks" % (s["waves"] / waves, s["nodes"] / waves))
