@@ -235,10 +235,14 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (tr or {}).get("traffic_bytes"),
                 "traffic_source": (tr or {}).get("source"),
+                "traffic_GBs": ((tr or {}).get("traffic_bytes") or 0) / (k_ms * 1e-3) / 1e9 if tr else None,
+                "traffic_frac_of_peak": ((tr or {}).get("traffic_bytes") or 0) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
                 "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "algorithmic bytes = 28 B per binary filter step + 8 B per narrowing (SURVEY.md §8d); domains live in LDS and the "
-                        "record stream is shared by the nodes of a workgroup, so the HBM traffic is far below this figure (DESIGN.md §5)",
+                "note": "achieved = algorithmic bytes (28 B per binary filter step + 8 B per narrowing, SURVEY.md §8d) / kernel time; the "
+                        "kernel proves whole 64-propagator words no-ops for 16 nodes at a time from LDS-resident range tables, so "
+                        "what actually crosses HBM is the nodes' active masks (1 bit per propagator and node): `traffic` (rocprofv3 PMC, "
+                        "profiles/) and traffic_frac_of_peak are the physical roofline figures (DESIGN.md §5)",
             },
         }
         if world == 1 and args.cpu_budget > 0:

@@ -379,7 +379,7 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 }
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -825,7 +825,12 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
 
 template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
-                                           uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+                                           uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr,
+                                           const uint64_t* hard64 = nullptr) {
+  // hard64 != nullptr: second pass behind phase A of sweep_words (which has counted the live records, copied the live
+  // rows to a.live and noted in hard64 the words its range test could not clear): only chunks with a noted word are
+  // processed, in place on a.live, and `remaining` is corrected by the records that get unlinked.
+  const bool post_a = hard64 != nullptr;
   static_assert(B <= 32 && (B <= 16 || PACKED), "node*CHUNK+j must fit in the 64 lanes of one or two live registers");
   static_assert(kChunk == 4, "the hot loop is written for four record buffers");
   constexpr int NL = B > 16 ? 2 : 1;  // live registers per lane: register h carries nodes 16h .. 16h+15
@@ -835,7 +840,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
-  const uint64_t* live_src = a.live_in;
+  const uint64_t* live_src = post_a ? a.live : a.live_in;
   const uint32_t bq = lane / kChunk, jq = lane % kChunk;  // this lane's (node mod 16, word-in-chunk) for the live-mask I/O
   bool io[NL];
   const uint64_t* my_in[NL];
@@ -898,6 +903,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   };
   uint64_t seg[4] = {0, 0, 0, 0}, segw = 0;  // PCP_ABLATE & 128: s_memtime ticks per segment of process()
   auto process = [&](const uint32_t c, const Stage& st) {
+    if (post_a && ((hard64[c >> 4] >> ((c & 15u) * 4u)) & 0xFull) == 0) return;  // nothing noted in this chunk
     const uint64_t tm0 = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t loaded[NL], my_new[NL];
     uint64_t any_live = 0;
@@ -942,7 +948,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     }
     if (chunk_fast) {
 #pragma unroll
-      for (int h = 0; h < NL; ++h) steps_lane += __popcll(loaded[h]);  // every live record of every node runs once
+      for (int h = 0; h < NL; ++h) steps_lane += post_a ? 0u : (uint32_t)__popcll(loaded[h]);  // every live record of every node runs once
       uint64_t tw = 0;
       if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(st.buf[0].d) & 0);
       // level 0: the whole tile at once, on the per-slot summaries
@@ -1040,7 +1046,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
                 if (__ballot(o < 0) & alive) slow |= 1u << j;
               }
             }
-            if (jq == (uint32_t)j) {  // every live record of every node runs once
+            if (jq == (uint32_t)j && !post_a) {  // every live record of every node runs once
   #pragma unroll
               for (int h = 0; h < NL; ++h) steps_lane += __popcll(loaded[h]);
             }
@@ -1078,8 +1084,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           if (word == 0 || ((failm >> b) & 1u)) continue;
           todo |= 1u << b;
           const uint64_t t3 = __ballot(((word >> lane) & 1ull) && tern);
-          steps3 += __popcll(t3);
-          steps2 += __popcll(word) - __popcll(t3);
+          if (!post_a) { steps3 += __popcll(t3); steps2 += __popcll(word) - __popcll(t3); }
         }
       }
       while (todo) {
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 #pragma unroll
     for (int h = 0; h < NL; ++h) {
       if (io[h] && wl < w1) {
-        rem_acc[h] += __popcll(my_new[h]);
+        rem_acc[h] += post_a ? (uint32_t)(__popcll(loaded[h]) - __popcll(my_new[h])) : (uint32_t)__popcll(my_new[h]);
         if (!(PCP_ABLATE & 8) && (live_src != a.live || my_new[h] != loaded[h])) my_out[h][wl] = my_new[h];
       }
     }
@@ -1119,7 +1124,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   }
 #pragma unroll
   for (int h = 0; h < NL; ++h)
-    if (io[h] && rem_acc[h]) atomicAdd(&remaining[bq + 16u * h], rem_acc[h]);
+    if (io[h] && rem_acc[h]) { if (post_a) atomicSub(&remaining[bq + 16u * h], rem_acc[h]); else atomicAdd(&remaining[bq + 16u * h], rem_acc[h]); }
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
   if ((PCP_ABLATE & 128) && lane == 0) {  // profiling build: per-segment ticks summed over all wavefronts
@@ -1144,8 +1149,11 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 // x-blocks) to the record-level tests, lane = record: level 0, level 1, level 2, full filter.  Word w goes to wavefront
 // w mod 16; the records and the node column of four words are fetched together.
 // ------------------------------------------------------------------------------------------------
+// Returns false when phase A noted more than an eighth of the words (a tile deep in the search tree: many assigned
+// variables, whose words no range test clears): the caller then runs the chunked record-level sweep over the noted
+// words instead of phase B, which is organised for a few words.
 template <int B, bool COMPACT>
-__device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
+__device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
                                             uint32_t* remaining, uint32_t* hardmap, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane; a node column fits one DPP row");
   constexpr bool PACKED = true, GLOBAL = false;
@@ -1163,7 +1171,7 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
   const RecT* rec_stream;
   if constexpr (COMPACT) rec_stream = a.m.recs8; else rec_stream = a.m.recs;
   uint64_t* const hard64 = reinterpret_cast<uint64_t*>(hardmap);  // [groups]
-  uint32_t steps_lane = 0;
+  uint32_t steps_lane = 0, n_hard = 0;
   uint32_t racc[B / 2];  // remaining live records per node, two 16-bit lane counters per register
 #pragma unroll
   for (int i = 0; i < B / 2; ++i) racc[i] = 0;
@@ -1218,8 +1226,10 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
     uint64_t hard = __ballot(alive != 0 && (fail || failm != 0));
     if (PCP_ABLATE & 16) hard = 0;
     if (PCP_ABLATE & 128) n_l0 += __popcll(hard);
+    n_hard += __popcll(hard);
     if (lane == 0) hard64[g] = hard;
   }
+  if (lane == 0 && n_hard) atomicAdd(&k.misc[M_HARD], n_hard);
 #pragma unroll
   for (int b = 0; b < B; ++b) {
     uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
@@ -1230,6 +1240,7 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's live stores are out before anyone re-reads the rows
   __syncthreads();
+  if (k.misc[M_HARD] * 8u > words) return false;
   const uint64_t tB = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
   // ================= phase B =================
   uint64_t pattern = 0;  // the words of a group this wavefront takes: bit positions congruent to `wave` modulo the wavefront count
@@ -1410,6 +1421,7 @@ __device__ __forceinline__ void sweep_words(const LaunchArgs& a, const BlockCtx&
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)tfl[0]);
     atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)tfl[1]);
   }
+  return true;
 }
 
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
@@ -1590,7 +1602,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     // narrowings of wave 0 are recorded in `cur`, which the first wake-up round reads as its current set
     bool swept = false;
     if constexpr (PACKED && B <= 16) {
-      if (a.word_level) { sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr); swept = true; }  // team == 1 here
+      if (a.word_level) {  // team == 1 here
+        swept = true;
+        if (!sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr))
+          sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr, reinterpret_cast<const uint64_t*>(list_id));
+      }
     }
     if (!swept && w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }

@@ -30,7 +30,7 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     om = orc.OracleModel(n_vars, props)
     ref = om.consistency(lb, ub, active)
     ctx.set_model(n_vars, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
         ctx.set_option(k, v)
     got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
     assert_parity(ref[:4], got[:4], what)
@@ -146,7 +146,7 @@ def test_packed_tiles_nqueens_frontier(ctx):
     n = 200
     props = M.nqueens_props(n)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
         ctx.set_option(k, v)
     from pcp_amd.search import bfs_frontier
     L, U, A, _ = bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), 300)
@@ -164,7 +164,7 @@ def test_declared_hull(ctx):
     ref = om.consistency(L, U, act)
     ctx.set_model(V, props)
     ctx.set_hull(int(lb.min()), int(ub.max()))
-    for k, v in {"force_path": 0, "nodes_per_block": 16, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 16, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
         ctx.set_option(k, v)
     got = ctx.propagate(L, U, act)
     assert_parity(ref[:4], got[:4], "declared hull")
@@ -196,6 +196,46 @@ def test_declared_hull(ctx):
     ctx.set_model(V, props)  # forgets the hull
 
 
+def _all_pairs_model(n, kinds, seed, dom=(0, 60)):
+    """x_i (kind) x_j + d for all i < j, sorted by i: the words of the table have short slot ranges, so the packed tiles
+    sweep it by word groups with the level -1 range test (XLessY words: minimum and maximum tables)."""
+    rng = np.random.default_rng(seed)
+    sol = rng.integers(dom[0], dom[1] + 1, size=n)
+    ii, jj = np.triu_indices(n, 1)
+    P = len(ii)
+    props = np.zeros(P, dtype=M.PROP_DTYPE)
+    props["var"][:] = M.PCP_NOVAR
+    props["group"] = np.arange(P)
+    kind = rng.choice(kinds, size=P) if len(kinds) > 1 else np.full(P, kinds[0])
+    # keep runs of one kind long (whole words): switch kind per block of 64 records
+    kind = np.repeat(kind[::64], 64)[:P]
+    props["kind"] = kind
+    props["var"][:, 0] = ii
+    props["var"][:, 1] = jj
+    d = np.where(kind == M.LT, sol[ii] - sol[jj] + 1 + rng.integers(0, 8, size=P), rng.integers(-5, 6, size=P))
+    clash = (kind == M.NEQ) & (sol[ii] == sol[jj] + d)
+    d[clash] += 1
+    props["off"][:, 1] = d
+    lb = np.full(n, dom[0], np.int32); ub = np.full(n, dom[1], np.int32)
+    return props, lb, ub, sol
+
+
+@pytest.mark.parametrize("kinds", [[M.NEQ], [M.LT], [M.NEQ, M.LT]])
+@pytest.mark.parametrize("npb", [8, 16])
+def test_word_group_sweep(ctx, kinds, npb):
+    """Packed tiles with word descriptors (level -1 on range tables, phase B at the record level) against the oracle and
+    against the chunked sweep (word_level = 0); consistent nodes (long cascades), random sub-boxes (failures), ragged batch."""
+    n = 90
+    props, lb, ub, sol = _all_pairs_model(n, kinds, seed=31 + len(kinds) + npb)
+    for planted in (True, False):
+        L, U = random_nodes(77 + npb, lb, ub, 75, sol if planted else None, p_narrow=0.25 if planted else 0.08)
+        act = random_active(78, 75, len(props), p_off=0.1)
+        for wl in (1, 0):
+            both(ctx, n, props, L, U, act, f"word sweep kinds={kinds} npb={npb} planted={planted} word_level={wl}",
+                 nodes_per_block=npb, packed=1, word_level=wl)
+    ctx.set_option("word_level", 1)
+
+
 def test_long_cascade(ctx):
     """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
     n = 300
@@ -221,7 +261,7 @@ def test_nqueens_dfs_nodes(ctx, n):
     ref = (rec["lb_out"][keep], rec["ub_out"][keep], rec["active_out"][keep], rec["status"][keep])
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 5}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(rec["lb_in"][keep], rec["ub_in"][keep], rec["active_in"][keep])
         assert_parity(ref, got[:4], f"nqueens({n}) {opts}")
@@ -244,7 +284,7 @@ def test_nqueens_1000_root_and_dive(ctx):
     ref = om.consistency(L, U, None, check_dup=False)
     ctx.set_model(n, props)
     for opts in ({"force_path": 1}, {"force_path": 2}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(N, om.n_units))
         assert_parity(ref[:4], got[:4], f"nqueens1000 {opts}")
@@ -268,7 +308,7 @@ def test_golomb_distinct_sum_network(ctx):
     assert (ref[3] == 0).any() and (ref[3] == 2).any()
     ctx.set_model(V, props)
     for opts in ({"force_path": 1}, {"force_path": 1, "nodes_per_block": 2}, {"force_path": 2, "team": 3}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, A)
         assert_parity(ref[:4], got[:4], f"golomb {opts}")
@@ -285,7 +325,7 @@ def test_nqueens_global_distinct_search(ctx, n):
     lb0, ub0 = vs.bounds()
     ss, _, _, _ = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
         ctx.set_option(k, v)
     st = S.dfs(ctx, lb0, ub0, all_solutions=True, batch=32)
     assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
@@ -302,7 +342,7 @@ def test_config3_random_binary_csp_full_size(ctx):
     assert (ref[3] == 2).all() and ((ref[0] != L) | (ref[1] != U)).sum() > V
     ctx.set_model(V, props)
     for opts in ({}, {"force_path": 2, "team": 16}):
-        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, **opts}.items():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(4, P))
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
@@ -358,7 +398,7 @@ def test_device_resident_search(ctx, n, batch):
     from pcp_amd.search_device import DeviceSearch
     props = M.nqueens_props(n)
     ctx.set_model(n, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
         ctx.set_option(k, v)
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
     ss, _, _, sol = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)

@@ -11,6 +11,7 @@ from pcp_amd.search_device import DeviceSearch
 
 n = 1000; batch = 4096
 ctx = E.Context(0); ctx.set_model(n, M.nqueens_props(n))
+if os.environ.get('PCP_WORD_LEVEL'): ctx.set_option('word_level', int(os.environ['PCP_WORD_LEVEL'])); print('word_level', os.environ['PCP_WORD_LEVEL'])
 ds = DeviceSearch(ctx, batch=batch, capacity=24 * batch)
 for D in (0, 500, 3000):
     ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
