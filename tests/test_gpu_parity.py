@@ -236,6 +236,33 @@ def test_word_group_sweep(ctx, kinds, npb):
     ctx.set_option("word_level", 1)
 
 
+@pytest.mark.parametrize("n,dive", [(60, 25), (90, 60)])
+def test_packed_tiles_deep_search_nodes(ctx, n, dive):
+    """Open nodes taken from deep in a device-resident search (many assigned queens: the range tests clear little, the
+    tile switches to the chunked record-level sweep after phase A) — every variant of the engine against the oracle."""
+    from pcp_amd.search_device import DeviceSearch
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
+        ctx.set_option(k, v)
+    ds = DeviceSearch(ctx, batch=64, capacity=4096)
+    ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
+    ds.advance(max_rounds=dive, batch=1)
+    ds.advance(max_rounds=5, batch=64)
+    lb, ub, act = (t.cpu().numpy() for t in ds.top(200))
+    assert lb.shape[0] >= 64
+    A = act.view(np.uint64)
+    om = orc.OracleModel(n, props)
+    ref = om.consistency(lb, ub, A)
+    for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "word_level": 0}, {"nodes_per_block": 16, "packed": 0},
+                 {"nodes_per_block": 32}):
+        for k, v in {"packed": 1, "word_level": 1, **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(lb, ub, A)
+        assert_parity(ref[:4], got[:4], f"deep nodes n={n} {opts}")
+    ctx.set_option("nodes_per_block", 0)
+
+
 def test_long_cascade(ctx):
     """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
     n = 300
