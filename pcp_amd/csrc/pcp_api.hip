@@ -497,8 +497,9 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     const uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, (n_nodes + slots - 1) / slots);
     // The word-group sweep keeps B live registers per lane (B <= 16) and notes the words for the record level in a
     // bitmap that borrows the changed-pair list's LDS: one u64 per 64 words, so list_cap must not drop below that.
-    const uint32_t wl_model = c->opt_word_level ? c->word_level : 0;
     const uint32_t groups = (words + 63) / 64;
+    // (the sweep counts live records in 16-bit lane counters: at most 1023 groups of 64 words per wavefront)
+    const uint32_t wl_model = (c->opt_word_level && groups <= 1000u * (block / 64u)) ? c->word_level : 0;
     for (uint32_t t : {32u, 16u, 8u}) {
       if (t > want) continue;
       for (uint32_t wl : {wl_model, 0u}) {
