@@ -6,13 +6,16 @@
 // (store.rs:166-183), unlinks it when entailed (store.rs:200-207) and wakes the propagators of every
 // changed variable (store.rs:191-198, reactors/indexed_deps.rs:99-113).
 //
-// MI355X design (DESIGN.md §3):
-//  * one workgroup owns the domains of B nodes in LDS as (lb,ub) int2 pairs (ds_read_b64), narrowed with
-//    ds_max/ds_min atomics; the propagator table is streamed once per workgroup as 16-byte records
-//    (global_load_dwordx4, 1 KiB per wave instruction) and applied to all B nodes;
-//  * wave 0 is the reference's "schedule every active propagator" (store.rs:144-149) as a coalesced sweep;
-//    the 64 lanes of a wavefront hold 64 consecutive propagators = exactly one u64 word of the node's
-//    `active` BitSet, so entailment is published with one __ballot and one 8-byte store;
+// MI355X design (DESIGN.md §3, §4):
+//  * one workgroup owns the domains of a tile of B nodes in LDS, node-minor, as (-lb, ub) cells — int2, or two int16
+//    in one dword when every bound of the tile is within +-16383 (LdsDom16: twice the nodes per LDS byte, packed
+//    v_pk_* arithmetic); narrowing is ds_min / a CAS loop; the model is shared by all tiles;
+//  * the sweep (the reference's "schedule every active propagator", store.rs:144-149) is a hierarchy of tests that
+//    prove (record, node) pairs no-ops in bulk: level -1 one lane per 64-record word x all nodes on range tables of
+//    tile summaries (sweep_words), level 0 per record x all nodes on the summaries, level 1 per record x node
+//    (fast_signs / fast_signs16), level 2 per node with liveness, then the full filter (eval_record) with LDS atomics.
+//    The 64 lanes of a wavefront hold 64 consecutive propagators = one u64 word of a node's `active` BitSet, so
+//    entailment is published with one __ballot and one 8-byte store;
 //  * later waves visit only the propagators incident to changed variables (CSR var->records), found by a
 //    ballot/prefix-sum compaction of the per-node changed-variable bitmask — the IndexedDeps::react step;
 //  * when few nodes are in flight (the reference's one-node-per-call use) a node is split over a TEAM of
@@ -26,9 +29,11 @@
 
 #include "pcp_internal.h"
 
-// PCP_ABLATE (profiling builds only, tools/ablate.sh; results are WRONG when non-zero): bit 0 = no LDS reads in the
-// level-1 test, bit 1 = no arithmetic in it, bit 2 = no record stream, bit 3 = no live-word I/O, bit 4 = skip the sweep's cold part, bit 5 = skip the
-// wake-up rounds, bit 6 = phase timers, bit 7 = timers of the sweep's segments (tools/seg_times.py).
+// PCP_ABLATE (profiling builds only, tools/ablate.sh, tools/seg_*.sh; results are WRONG or counters overloaded when non-zero):
+//   1 no LDS reads in level 1 | 2 no arithmetic in level 1 | 4 no record stream | 8 no live-word I/O | 16 skip the sweep's
+//   cold part / phase B | 32 skip the wake-up rounds | 64 block phase timers (+256: staging / whole block) | 128 s_memtime
+//   segment timers of the sweeps | 512 count noted words | 1024 / 2048 stop phase B after level 1 / 0 | 4096 / 8192 phase B
+//   loads only / preamble only.
 #ifndef PCP_ABLATE
 #define PCP_ABLATE 0
 #endif

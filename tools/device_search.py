@@ -12,7 +12,7 @@ from pcp_amd.search_device import DeviceSearch
 n = int(sys.argv[1]); batch = int(sys.argv[2]); limit = int(sys.argv[3]); allsol = len(sys.argv) > 4
 ctx = E.Context(0)
 ctx.set_model(n, M.nqueens_props(n))
-ds = DeviceSearch(ctx, batch=batch, capacity=max(16 * batch, 32768))
+ds = DeviceSearch(ctx, batch=batch, capacity=max(24 * batch, limit + 2 * batch))  # near the root every node is Unknown: the stack grows by a batch per round
 lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
 ds.run(lb0, ub0, all_solutions=allsol, node_limit=min(limit, 4 * batch))  # warm-up
 torch.cuda.synchronize()
