@@ -1015,7 +1015,11 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         while (need) {  // rolled: one copy of the per-node test
           const uint32_t j = __builtin_ctz(need);
           need &= need - 1;
-          const Rec rec = expand(fetch_rec(c * kChunk + j));  // L1 hit; keeps the stage registers out of a dynamic index
+          RecT rsel = st.buf[0];  // the stage register of word j, selected without a dynamic register index
+#pragma unroll
+          for (int u = 1; u < kChunk; ++u)
+            if (j == (uint32_t)u) rsel = st.buf[u];
+          const Rec rec = expand(rsel);
           const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
           const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
           int o;
@@ -1183,6 +1187,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
   const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // empty input domains
   uint64_t tseg[2] = {0, 0};  // PCP_ABLATE & 128: s_memtime ticks of phase A / phase B
   uint32_t n_l0 = 0, n_l1 = 0, n_l2 = 0, n_bulk = 0;  // words that reached level 0 / 1 / 2; (word,node) pairs unlinked in bulk
+  (void)n_bulk;
   const uint64_t tA = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
   // ================= phase A =================
   for (uint32_t g = wave; g < groups; g += nw) {

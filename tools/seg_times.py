@@ -14,11 +14,21 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ctx = E.Context(0)
 ctx.set_model(n, M.nqueens_props(n))
-L, U, A, _ = bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), N)
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream().cuda_stream
-lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
-act = torch.from_numpy(A.view(np.int64)).to(dev)
+DIVE = int(os.environ.get("DIVE", "0"))
+if os.environ.get("PCP_WORD_LEVEL"): ctx.set_option("word_level", int(os.environ["PCP_WORD_LEVEL"]))
+if DIVE:  # a deep frontier: DIVE nodes depth-first, then 14 batched rounds (tools/deep_frontier.py)
+    from pcp_amd.search_device import DeviceSearch
+    ds = DeviceSearch(ctx, batch=N, capacity=24 * N)
+    ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
+    ds.advance(max_rounds=DIVE, batch=1)
+    ds.advance(max_rounds=14, batch=N)
+    lb, ub, act = (t.clone() for t in ds.top(N))
+else:
+    L, U, A, _ = bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), N)
+    lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+    act = torch.from_numpy(A.view(np.int64)).to(dev)
 lbo, ubo, acto = torch.empty_like(lb), torch.empty_like(ub), torch.empty_like(act)
 status = torch.zeros(N, dtype=torch.uint8, device=dev)
 for _ in range(2):  # in place on a fresh copy, like bench.py
