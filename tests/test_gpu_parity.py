@@ -358,6 +358,21 @@ def test_nqueens_global_distinct_search(ctx, n):
     assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
 
 
+@pytest.mark.parametrize("style", ["global", "join"])
+def test_grouped_units_on_packed_tiles(ctx, style):
+    """Distinct / join_distinct units (several records per `active` bit) on packed tiles with the word-group sweep: the
+    unit-level rows are expanded to record-level live rows, swept in place and contracted back."""
+    n = 40
+    vs, cs = M.nqueens(n, style if style == "global" else "join")
+    props = cs.lower(n)
+    lb0, ub0 = vs.bounds()
+    om = orc.OracleModel(n, props)
+    L, U = random_nodes(4242, lb0, ub0, 90, None, p_narrow=0.06)
+    act = random_active(4243, 90, om.n_units, p_off=0.1)
+    for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 8, "word_level": 0}, {"nodes_per_block": 16, "packed": 0}):
+        both(ctx, n, props, L, U, act, f"grouped {style} {opts}", **opts)
+
+
 def test_config3_random_binary_csp_full_size(ctx):
     """BASELINE config 3 at full size: 50 000 Interval<i32> variables (400 KB of bounds per node: more than LDS, so
     the HBM-resident-domain variant runs), 500 000 `x ◇ y + c` constraints, planted solution, long cascades."""
