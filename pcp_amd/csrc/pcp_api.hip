@@ -32,6 +32,7 @@ struct pcp_ctx {
   uint32_t word_level = 0;           // 0 = no word descriptors worth using, 1 = XNeqY words only, 2 = XLessY words too
   uint32_t* d_adj_off = nullptr;
   uint32_t* d_adj = nullptr;
+  uint2* d_adjp = nullptr; size_t cap_adjp = 0; bool have_adjp = false;
   int32_t* d_const = nullptr;
   uint32_t* d_rec_unit = nullptr;    // grouped models only: unit of each record
   uint32_t* d_unit_first = nullptr;  // grouped models only: first record of each unit (+ sentinel)
@@ -190,6 +191,19 @@ int32_t finalize_model(pcp_ctx* c) {
   }
   HIP_TRY(c, hipMemcpy(c->d_adj_off, adj_off.data(), adj_off.size() * 4, hipMemcpyHostToDevice));
   if (!adj.empty()) HIP_TRY(c, hipMemcpy(c->d_adj, adj.data(), adj.size() * 4, hipMemcpyHostToDevice));
+  c->have_adjp = false;
+  if (!tern && !adj.empty()) {  // adjacency payloads (ModelDev::adjp)
+    std::vector<uint2> adjp(adj.size());
+    std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1);
+    for (size_t r = 0; r < P; ++r) {
+      const uint32_t x = recs[r].xk & kSlotMask, y = recs[r].y, kind = recs[r].xk >> 28;
+      if (x < c->n_vars) adjp[fill[x]++] = make_uint2(y | (kind << 28), (uint32_t)recs[r].d);
+      if (y < c->n_vars) adjp[fill[y]++] = make_uint2(x | (kind << 28) | (1u << 31), (uint32_t)recs[r].d);
+    }
+    if ((rc = ensure(c, c->d_adjp, c->cap_adjp, adjp.size()))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_adjp, adjp.data(), adjp.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    c->have_adjp = true;
+  }
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
   c->compact = !tern && n_slots <= kCompactSlots && P > 0;
   c->consts_fit16 = true;
@@ -322,7 +336,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc};
+  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -529,7 +543,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
-  a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.const_val = c->d_const;
+  a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;

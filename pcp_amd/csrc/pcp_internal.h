@@ -60,6 +60,9 @@ struct ModelDev {
   const WordDesc* wdesc;    // [ceil(n_recs/64)] word descriptors, or null
   const uint32_t* adj_off;  // [n_vars + 1]  CSR var -> incident record ids (constants have no adjacency)
   const uint32_t* adj;      // [adj_off[n_vars]]
+  const uint2* adjp;        // [adj_off[n_vars]] payload of each adjacency entry of a binary-only model, or null:
+                            //   .x = the record's OTHER operand slot | kind << 28 | (this variable is the record's y) << 31,  .y = d
+                            // — the wake-up rounds rebuild the record from it instead of gathering 16 bytes per entry
   const int32_t* const_val; // [n_slots - n_vars]
   uint32_t n_recs;
   uint32_t n_vars;

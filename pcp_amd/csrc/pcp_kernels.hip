@@ -1781,10 +1781,28 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
               ok[u] = idx < deg;
               r[u] = ap[ok[u] ? idx : 0];
             }
+            if (a.m.adjp) {
+              // binary-only model: the record is rebuilt from the adjacency payload (a coalesced 8-byte stream next
+              // to the ids) — one dependent gather per entry (the live word) instead of two
+              const uint2* pp = a.m.adjp + a.m.adj_off[v];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-              lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              rc[u] = a.m.recs[r[u]];
+              for (int u = 0; u < U; ++u) {
+                const uint2 q = pp[ok[u] ? k0 + u * 64 + lane : 0];
+                const uint32_t other = q.x & kSlotMask, kind = (q.x >> 28) & 7u;
+                const bool is_y = (q.x >> 31) != 0;
+                rc[u].xk = (is_y ? other : v) | (kind << 28);
+                rc[u].y = is_y ? v : other;
+                rc[u].z = 0;
+                rc[u].d = (int32_t)q.y;
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rc[u] = a.m.recs[r[u]];
+              }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1798,10 +1816,20 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           uint32_t lo = 0, hi = total;
           while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
           const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
-          const uint32_t r = a.m.adj[a.m.adj_off[v] + (i - list_pre[lo])];
+          const uint32_t ai = a.m.adj_off[v] + (i - list_pre[lo]);
+          const uint32_t r = a.m.adj[ai];
           const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
           const uint32_t lbits = __hip_atomic_load(lrow + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          run_item(b, v, r, lbits, a.m.recs[r]);
+          Rec rec;
+          if (a.m.adjp) {
+            const uint2 q = a.m.adjp[ai];
+            const uint32_t other = q.x & kSlotMask, kind = (q.x >> 28) & 7u;
+            const bool is_y = (q.x >> 31) != 0;
+            rec.xk = (is_y ? other : v) | (kind << 28); rec.y = is_y ? v : other; rec.z = 0; rec.d = (int32_t)q.y;
+          } else {
+            rec = a.m.recs[r];
+          }
+          run_item(b, v, r, lbits, rec);
         }
       }
       for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); }
