@@ -1527,27 +1527,37 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     for (uint32_t v = V + tid; v < S; v += nth) { int2 d; d.x = d.y = a.m.const_val[v - V]; dom[v - V] = d; }
     if (bad) atomicOr(&misc[M_FAIL], 1u);
   } else {
-    for (uint32_t b = 0; b < (uint32_t)B; ++b) {
-      const bool real = b < nb;
-      const int32_t* lbp = a.lb_in + (size_t)(node0 + (real ? b : 0)) * V;
-      const int32_t* ubp = a.ub_in + (size_t)(node0 + (real ? b : 0)) * V;
-      bool bad = false, oob = false;
-      for (uint32_t v = tid; v < S; v += nth) {
-        int2 d;
-        if (v < V) { d.x = lbp[v]; d.y = ubp[v]; bad |= d.x > d.y; }
-        else { d.x = d.y = a.m.const_val[v - V]; }
-        // missing nodes of a tail tile mirror node 0: readable, never used
+    // slot-major: the 2*B bound loads of a slot (one per node row, lanes = consecutive slots: coalesced) are issued
+    // together — one memory round trip per pass instead of one per node
+    uint32_t badm = 0;
+    bool oob = false;
+    for (uint32_t v = tid; v < S; v += nth) {
+      int lbv[B], ubv[B];
+      if (v < V) {
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+          const size_t row = (size_t)(node0 + ((uint32_t)b < nb ? (uint32_t)b : 0u)) * V;  // missing nodes of a tail tile mirror node 0
+          lbv[b] = a.lb_in[row + v];
+          ubv[b] = a.ub_in[row + v];
+        }
+      } else {
+        const int cv0 = a.m.const_val[v - V];
+#pragma unroll
+        for (int b = 0; b < B; ++b) lbv[b] = ubv[b] = cv0;
+      }
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        if (lbv[b] > ubv[b] && (uint32_t)b < nb) badm |= 1u << b;  // empty input domain: the node is failed
         if constexpr (PACKED) {
-          oob |= (d.x < -kPackedMax) | (d.x > kPackedMax) | (d.y < -kPackedMax) | (d.y > kPackedMax);
-          dom[(size_t)v * BP + b] = pack16(d.x, d.y);
+          oob |= (lbv[b] < -kPackedMax) | (lbv[b] > kPackedMax) | (ubv[b] < -kPackedMax) | (ubv[b] > kPackedMax);
+          dom[(size_t)v * BP + b] = pack16(lbv[b], ubv[b]);
         } else {
-          d.x = -d.x;                   // LDS holds (-lb, ub)
-          dom[(size_t)v * BP + b] = d;
+          dom[(size_t)v * BP + b] = make_int2(-lbv[b], ubv[b]);  // LDS holds (-lb, ub)
         }
       }
-      if (bad && real) atomicOr(&misc[M_FAIL], 1u << b);  // empty input domain: the node is failed
-      if (PACKED && oob) atomicOr(&misc[M_OOB], 1u);
     }
+    if (badm) atomicOr(&misc[M_FAIL], badm);
+    if (PACKED && oob) atomicOr(&misc[M_OOB], 1u);
   }
   __syncthreads();
   if (PACKED && misc[M_OOB]) {
