@@ -52,6 +52,24 @@ __global__ void __launch_bounds__(1024) k_mode1(const uint64_t* in, uint64_t* ou
   }
 }
 
+// mode 2: the word-group sweep's pattern, read only: a wavefront step = 64 consecutive words of each of 16 node rows
+// (16 coalesced 512-byte loads in flight), popcounts summed.
+template <int ROWS>
+__global__ void __launch_bounds__(1024) k_mode2(const uint64_t* in, uint32_t* out, uint32_t words) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const uint32_t groups = (words + 63) / 64;
+  uint32_t acc = 0;
+  for (uint32_t g = wave; g < groups; g += nw) {
+    const uint32_t w = min(g * 64 + lane, words - 1);
+    uint64_t v[ROWS];
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b) v[b] = in[(size_t)(blockIdx.x * ROWS + b) * words + w];
+#pragma unroll
+    for (int b = 0; b < ROWS; ++b) acc += __popcll(v[b]);
+  }
+  if (acc == 0xFFFFFFFFu) out[0] = acc;
+}
+
 int main() {
   const uint32_t nodes = 4096, words = 23424;  // 23424 = 16 * 1464: rows 128-byte aligned
   const size_t n = (size_t)nodes * words;
@@ -73,6 +91,17 @@ int main() {
   run("mode1 128B/node depth1", [&] { hipLaunchKernelGGL(k_mode1<1>, dim3(nodes / 16), dim3(1024), 0, 0, in, out, words); });
   run("mode1 128B/node depth2", [&] { hipLaunchKernelGGL(k_mode1<2>, dim3(nodes / 16), dim3(1024), 0, 0, in, out, words); });
   run("mode1 128B/node depth4", [&] { hipLaunchKernelGGL(k_mode1<4>, dim3(nodes / 16), dim3(1024), 0, 0, in, out, words); });
+  auto run_ro = [&](const char* name, auto launch) {
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int i = 0; i < 10; ++i) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+    printf("%-28s %.3f ms  %.2f TB/s (read only)\n", name, ms, 1.0 * n * 8 / ms / 1e9);
+  };
+  run_ro("mode2 16 rows x 512B", [&] { hipLaunchKernelGGL(k_mode2<16>, dim3(nodes / 16), dim3(1024), 0, 0, in, (uint32_t*)out, words); });
+  run_ro("mode2 8 rows x 512B", [&] { hipLaunchKernelGGL(k_mode2<8>, dim3(nodes / 8), dim3(1024), 0, 0, in, (uint32_t*)out, words); });
+  run_ro("mode2 8 rows, 512 thr", [&] { hipLaunchKernelGGL(k_mode2<8>, dim3(nodes / 8), dim3(512), 0, 0, in, (uint32_t*)out, words); });
   hipMemcpyAsync(out, in, n * 8, hipMemcpyDeviceToDevice, 0); hipDeviceSynchronize();
   hipEventRecord(e0);
   for (int i = 0; i < 10; ++i) hipMemcpyAsync(out, in, n * 8, hipMemcpyDeviceToDevice, 0);
