@@ -263,6 +263,20 @@ def test_packed_tiles_deep_search_nodes(ctx, n, dive):
     ctx.set_option("nodes_per_block", 0)
 
 
+@pytest.mark.parametrize("n_nodes", [1, 17, 255, 2051, 9000])
+def test_batch_sizes_auto_tiling(ctx, n_nodes):
+    """Default launch policy over batch sizes from one node to many tiles per CU (team path, small tiles, packed 16- and
+    32-node tiles with ragged last tile): all against the oracle."""
+    n = 24
+    props = M.nqueens_props(n)
+    om = orc.OracleModel(n, props)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    L, U = random_nodes(100 + n_nodes, lb0, ub0, n_nodes, None, p_narrow=0.12)
+    act = random_active(200 + n_nodes, n_nodes, len(props), p_off=0.1)
+    ref, got = both(ctx, n, props, L, U, act, f"auto tiling n_nodes={n_nodes}")
+    assert got[4]["nodes"] == n_nodes
+
+
 def test_long_cascade(ctx):
     """x0 < x1 < ... < x299 on [0,299]: a 300-wave cascade ending in a full assignment (status True)."""
     n = 300
