@@ -1190,10 +1190,14 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
   (void)n_bulk;
   const uint64_t tA = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
   // ================= phase A =================
+  // The word's descriptor is fetched one group ahead, so that the level -1 arithmetic runs while the group's row loads
+  // are in flight instead of behind them.
+  WordPart qa_next = a.m.wdesc[min(wave * 64 + lane, words - 1)].a;
   for (uint32_t g = wave; g < groups; g += nw) {
     const uint32_t w = g * 64 + lane;
     const bool wv = w < words;
     const uint32_t wc = min(w, words - 1);
+    const WordPart qa = qa_next;
     uint64_t lv[B];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
@@ -1202,6 +1206,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       if (wc == words - 1) v &= tail_mask;
       lv[b] = (wv && (uint32_t)b < nb) ? v : 0ull;
     }
+    qa_next = a.m.wdesc[min((g + nw) * 64 + lane, words - 1)].a;
     // level -1: the whole word against the range tables
     auto part_fails = [&](const WordPart q) -> bool {
       const uint32_t cls = (q.k >> 8) & 15u;
@@ -1221,7 +1226,6 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       }
       return true;  // no descriptor: always to the record level
     };
-    const WordPart qa = a.m.wdesc[wc].a;
     bool fail = part_fails(qa);
     if (!fail && ((qa.k >> 12) & 1u)) fail = part_fails(a.m.wdesc[wc].b);  // a word that straddles two x-blocks
     uint64_t alive = 0;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include <cstdlib>
 
 template <int DEPTH>
 __global__ void __launch_bounds__(1024) k_mode0(const uint64_t* in, uint64_t* out, uint32_t words) {
@@ -70,8 +71,8 @@ __global__ void __launch_bounds__(1024) k_mode2(const uint64_t* in, uint32_t* ou
   if (acc == 0xFFFFFFFFu) out[0] = acc;
 }
 
-int main() {
-  const uint32_t nodes = 4096, words = 23424;  // 23424 = 16 * 1464: rows 128-byte aligned
+int main(int argc, char** argv) {
+  const uint32_t nodes = 4096; const uint32_t words = argc > 1 ? atoi(argv[1]) : 23424;  // 23424 = 16 * 1464: rows 128-byte aligned
   const size_t n = (size_t)nodes * words;
   uint64_t *in, *out;
   hipMalloc(&in, n * 8); hipMalloc(&out, n * 8);
