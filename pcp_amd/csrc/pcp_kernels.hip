@@ -1240,6 +1240,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     uint64_t hard = __ballot(alive != 0 && (fail || failm != 0));
     if (PCP_ABLATE & 16) hard = 0;
     if (PCP_ABLATE & 128) n_l0 += __popcll(hard);
+    if (PCP_ABLATE & 512) steps3 += __popcll(hard);  // profiling: words noted for the record level (tools/hard_words.sh)
     n_hard += __popcll(hard);
     if (lane == 0) hard64[g] = hard;
   }
