@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--nodes", type=int, default=8192, help="open nodes per GPU per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--out-of-place", action="store_true", help="write the results to separate buffers (default: in place, like Store::consistency)")
+    ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
     args = ap.parse_args()
@@ -122,17 +123,17 @@ def main():
     ctx.set_option("nodes_per_block", args.nodes_per_block)
 
     # ---- synthetic input: the breadth-first frontier of the search tree, sharded by rank --------------------
-    # Every rank expands the root to a small common frontier (>= 8 subtrees per rank), keeps the subtrees
-    # rank, rank+world, ... and expands THOSE breadth-first to its own args.nodes open nodes: per-GPU work is fixed
+    # The root is expanded to a common frontier of 8 subtrees per SHARE, with max(8, world) shares; rank r keeps the
+    # subtrees r, r+shares, ... and expands THOSE breadth-first to its own args.nodes open nodes.  Share r is the same
+    # set of nodes whatever the number of GPUs (a 1-GPU run is share 0 of the 8-GPU run): per-GPU work is fixed
     # (weak scaling) and no rank ever materialises another rank's nodes.
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
-    if world > 1:
-        L0, U0, A0, _ = S.bfs_frontier(ctx, lb0, ub0, 8 * world)
-        if L0.shape[0] < world:
-            raise SystemExit(f"common frontier has only {L0.shape[0]} open nodes for {world} ranks")
-        L, U, A, fst = S.bfs_frontier(ctx, L0[rank::world], U0[rank::world], args.nodes, active0=A0[rank::world])
-    else:
-        L, U, A, fst = S.bfs_frontier(ctx, lb0, ub0, args.nodes)
+    shares = max(8, world)
+    L0, U0, A0, _ = S.bfs_frontier(ctx, lb0, ub0, 8 * shares)
+    if L0.shape[0] < shares:
+        raise SystemExit(f"common frontier has only {L0.shape[0]} open nodes for {shares} shares")
+    share = rank if args.share < 0 else args.share % shares
+    L, U, A, fst = S.bfs_frontier(ctx, L0[share::shares], U0[share::shares], args.nodes, active0=A0[share::shares])
     if L.shape[0] < args.nodes:
         raise SystemExit(f"frontier has only {L.shape[0]} open nodes")
     t_lb_in = torch.from_numpy(L).to(dev)
@@ -220,7 +221,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"N-queens n={n}, x[i]!=x[j]+k decomposition (V={n}, P={len(props)} XNeqY), Interval<i32> domains; "
-                            f"{args.nodes} open nodes per GPU per step = breadth-first frontier of the reference search tree, one fixpoint per node, 1 launch per step, "
+                            f"{args.nodes} open nodes per GPU per step = this rank's share of the breadth-first frontier of the reference search tree, one fixpoint per node, 1 launch per step, "
                             + ("results written to separate buffers" if args.out_of_place else "in place on a fresh copy of the frontier per step"),
                 "nodes_per_gpu": args.nodes,
                 "in_place": not args.out_of_place,
