@@ -175,8 +175,12 @@ int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synch
  * stream the kernels were launched on (bench.py's roofline leg).  Synchronises on the stop event. */
 int32_t pcp_last_kernel_ms(pcp_ctx* ctx, float* ms);
 
-/* Tuning knobs (all optional).  key: "block_threads", "nodes_per_block", "force_path" (0 auto, 1 batch
- * LDS kernel, 2 team/global kernel).  Unknown key -> PCP_ERR_ARG. */
+/* Knobs (all optional; the defaults pick everything from the model and the batch).  key:
+ *   "block_threads" 256/512/1024, "nodes_per_block" 0 = auto, "force_path" (0 auto, 1 batch LDS kernel, 2 team kernel),
+ *   "team" workgroups per node, "list_cap", "global_dom" 1 = domains stay in HBM, "packed" 0 = never use 16-bit cells,
+ *   "word_level" 0 = never use the word-group sweep, "branch_reverse" 1 = pcp_branch_device writes child k of the batch
+ *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
+ * Unknown key -> PCP_ERR_ARG. */
 int32_t pcp_set_option(pcp_ctx* ctx, const char* key, int64_t value);
 
 #ifdef __cplusplus

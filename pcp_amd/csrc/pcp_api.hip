@@ -66,6 +66,7 @@ struct pcp_ctx {
   int64_t opt_team = 0;             // 0 = auto
   int64_t opt_list_cap = 2048;
   int64_t opt_global_dom = 0;       // 1 = force the HBM-resident-domain variant (tests)
+  int64_t opt_branch_reverse = 0;   // 1 = pcp_branch_device writes the children in reverse order (row n_children-1-k)
   int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
   int64_t opt_word_level = 1;       // 1 = auto (word-group sweep with the level -1 range test on packed tiles), 0 = never
 };
@@ -427,6 +428,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "global_dom") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "global_dom must be 0 or 1");
     c->opt_global_dom = value;
+  } else if (k == "branch_reverse") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "branch_reverse must be 0 or 1");
+    c->opt_branch_reverse = value;
   } else if (k == "word_level") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "word_level must be 0 or 1");
     c->opt_word_level = value;
@@ -614,7 +618,7 @@ int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const
   int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
   if (rc) return rc;
   if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 16, stream)); return PCP_OK; }
-  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, words, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, stream));
+  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, words, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
   return PCP_OK;
 }
 

@@ -130,6 +130,6 @@ hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, u
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
-                         uint32_t* counts, hipStream_t stream);
+                         uint32_t* counts, uint32_t reverse, hipStream_t stream);
 
 }  // namespace pcp

@@ -2023,10 +2023,15 @@ __global__ void __launch_bounds__(1024) branch_scan_kernel(const uint8_t* __rest
 
 __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t words, const int32_t* __restrict__ lb, const int32_t* __restrict__ ub,
                                                      const uint64_t* __restrict__ active, const uint32_t* __restrict__ child_base,
-                                                     int32_t* __restrict__ child_lb, int32_t* __restrict__ child_ub, uint64_t* __restrict__ child_active) {
+                                                     int32_t* __restrict__ child_lb, int32_t* __restrict__ child_ub, uint64_t* __restrict__ child_active,
+                                                     const uint32_t* __restrict__ counts, uint32_t reverse) {
   const uint32_t node = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   const uint32_t slot = child_base[node];
   if (slot == 0xFFFFFFFFu) return;  // not Unknown: nothing to branch on
+  // reverse: child k of the batch goes to row n_children-1-k, so that a caller that appends the rows to a LIFO stack
+  // pops the first node's left child first (left-first DFS) without reordering anything
+  const uint32_t rowL = reverse ? counts[0] - 1 - slot : slot;
+  const uint32_t rowR = reverse ? rowL - 1 : slot + 1;
   __shared__ unsigned long long best[4];
   const int32_t* plb = lb + (size_t)node * n_vars;
   const int32_t* pub = ub + (size_t)node * n_vars;
@@ -2049,10 +2054,10 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
     const long long s = (long long)plb[var] + (long long)pub[var];
     val = (int32_t)(s / 2);  // MiddleVal: C++ `/` truncates toward zero like Rust's
   }
-  int32_t* l0 = child_lb + (size_t)slot * n_vars;
-  int32_t* u0 = child_ub + (size_t)slot * n_vars;
-  int32_t* l1 = l0 + n_vars;
-  int32_t* u1 = u0 + n_vars;
+  int32_t* l0 = child_lb + (size_t)rowL * n_vars;
+  int32_t* u0 = child_ub + (size_t)rowL * n_vars;
+  int32_t* l1 = child_lb + (size_t)rowR * n_vars;
+  int32_t* u1 = child_ub + (size_t)rowR * n_vars;
   for (uint32_t v = tid; v < n_vars; v += nth) {
     const int32_t a = plb[v], b = pub[v];
     l0[v] = a;                                   // left:  x <= val
@@ -2061,19 +2066,19 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
     u1[v] = b;
   }
   const uint64_t* pa = active + (size_t)node * words;
-  uint64_t* a0 = child_active + (size_t)slot * words;
-  uint64_t* a1 = a0 + words;
+  uint64_t* a0 = child_active + (size_t)rowL * words;
+  uint64_t* a1 = child_active + (size_t)rowR * words;
   for (uint32_t w = tid; w < words; w += nth) { const uint64_t x = pa[w]; a0[w] = x; a1[w] = x; }
 }
 
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
-                         uint32_t* counts, hipStream_t stream) {
+                         uint32_t* counts, uint32_t reverse, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(1024), 0, stream, status, n_nodes, child_base, counts);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, words, lb, ub, active, child_base, child_lb, child_ub, child_active);
+  hipLaunchKernelGGL(branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, words, lb, ub, active, child_base, child_lb, child_ub, child_active, counts, reverse);
   return hipGetLastError();
 }
 

@@ -208,6 +208,8 @@ def balance_stacks(stack, dist) -> int:
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = stack.lb.device
+    if hasattr(stack, "compact"):
+        stack.compact()  # DeviceSearch keeps its open nodes as segments; the moves below work on rows [0, size)
     mine = torch.tensor([stack.size], dtype=torch.int64, device=dev)
     gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(gathered, mine)

@@ -29,6 +29,11 @@ class DeviceSearchStats:
 
 
 class DeviceSearch:
+    """The open nodes live in one device buffer of ``capacity`` rows as a list of SEGMENTS (start, length), the last
+    one on top.  A round propagates the top ``n`` rows of the last segment in place and lets `pcp_branch_device` write
+    the children straight above them, in reverse order, as a new segment: nothing is copied or reordered.  The popped
+    parents leave a hole below the new segment; it is reclaimed when that segment is used up (LIFO)."""
+
     def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None):
         import torch
         self.torch = torch
@@ -43,10 +48,34 @@ class DeviceSearch:
         self.ub = torch.empty((self.cap, V), dtype=i32, device=self.dev)
         self.act = torch.empty((self.cap, W), dtype=i64, device=self.dev)
         self.status = torch.zeros(self.batch, dtype=u8, device=self.dev)
-        self.c_lb = torch.empty((2 * self.batch, V), dtype=i32, device=self.dev)
-        self.c_ub = torch.empty((2 * self.batch, V), dtype=i32, device=self.dev)
-        self.c_act = torch.empty((2 * self.batch, W), dtype=i64, device=self.dev)
         self.counts = torch.zeros(4, dtype=i32, device=self.dev)
+        self.segs: List[List[int]] = []  # [start, length], bottom to top
+        self.stats = DeviceSearchStats()
+
+    # ---- the stack as the drivers see it ------------------------------------------------------------------------------
+    @property
+    def size(self) -> int:
+        return sum(l for _, l in self.segs)
+
+    @size.setter
+    def size(self, n: int):
+        """Rows [0, n) are the open nodes (used by balance_stacks after it has moved rows around a compacted stack)."""
+        self.segs = [[0, int(n)]] if n > 0 else []
+
+    def _top_row(self) -> int:
+        return self.segs[-1][0] + self.segs[-1][1] if self.segs else 0
+
+    def compact(self):
+        """Make the open nodes one segment starting at row 0 (order kept)."""
+        if len(self.segs) == 1 and self.segs[0][0] == 0:
+            return
+        pos = 0
+        for s, l in self.segs:
+            if l and s != pos:
+                for t in (self.lb, self.ub, self.act):
+                    t[pos:pos + l] = t[s:s + l].clone() if s < pos + l else t[s:s + l]
+            pos += l
+        self.segs = [[0, pos]] if pos else []
 
     def reset(self, lb0, ub0):
         """Start a new search: the stack holds the root."""
@@ -56,7 +85,7 @@ class DeviceSearch:
         self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
         if ctx.words:
             self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
-        self.size = 1
+        self.segs = [[0, 1]]
         self.stats = DeviceSearchStats()
         ctx.stats_reset(torch.cuda.current_stream(self.dev).cuda_stream)
 
@@ -68,25 +97,31 @@ class DeviceSearch:
         batch = min(int(batch) if batch else self.batch, self.batch)
         rounds = 0
         done = False
-        while self.size > 0:
+        ctx.set_option("branch_reverse", 1)  # children arrive in pop order (a context-wide knob: restored below)
+        while self.segs:
             if max_rounds and rounds >= max_rounds:
                 break
-            size = self.size
-            # popping n and pushing at most 2n children must fit: when the stack is nearly full, take fewer nodes
-            # (a deeper, narrower dive) instead of overflowing
-            room = self.cap - size
-            if room <= 0:
-                raise RuntimeError(f"open-node stack full ({size} of {self.cap}); raise `capacity`")
-            n = min(batch, size, max(1, room // 2))
+            start, length = self.segs[-1]
+            top = start + length
+            # the children (at most 2n rows) go right above the popped parents: when the buffer is nearly full, first
+            # squeeze out the holes, then take fewer nodes (a deeper, narrower dive) instead of overflowing
+            if self.cap - top < 2 * min(batch, length):
+                self.compact()
+                start, length = self.segs[-1]
+                top = start + length
+            room = self.cap - top
+            if room < 2:
+                raise RuntimeError(f"open-node stack full ({self.size} of {self.cap}); raise `capacity`")
+            n = min(batch, length, room // 2)
             if node_limit:
                 n = min(n, node_limit - st.num_nodes)
                 if n <= 0:
                     break
-            lo = size - n
-            lb, ub, act = self.lb[lo:size], self.ub[lo:size], self.act[lo:size]
+            lo = top - n
+            lb, ub, act = self.lb[lo:top], self.ub[lo:top], self.act[lo:top]
             status = self.status[:n]
             ctx.propagate_device(n, lb, ub, lb, ub, act if ctx.words else None, act if ctx.words else None, status, stream)
-            ctx.branch_device(n, lb, ub, act if ctx.words else None, status, self.c_lb, self.c_ub, self.c_act if ctx.words else None,
+            ctx.branch_device(n, lb, ub, act if ctx.words else None, status, self.lb[top:], self.ub[top:], self.act[top:] if ctx.words else None,
                               self.counts, stream)
             n_children, n_true, n_false, _ = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
             rounds += 1
@@ -98,23 +133,20 @@ class DeviceSearch:
                 rows = torch.nonzero(status == TRUE).flatten()[: keep_solutions - len(st.solutions)]
                 for r in lb[rows].cpu().numpy():
                     st.solutions.append(r)
-            size = lo
+            # pop the parents; the children, already in left-first order (branch_reverse), become the new top segment
+            self.segs[-1][1] = length - n
+            if self.segs[-1][1] == 0:
+                self.segs.pop()
             if n_true and not all_solutions:
-                self.size = size
                 done = True
                 break
             if n_children:
-                # reversed, so that the first node's left child ends on top of the stack (left-first DFS)
-                self.lb[size:size + n_children] = torch.flip(self.c_lb[:n_children], dims=[0])
-                self.ub[size:size + n_children] = torch.flip(self.c_ub[:n_children], dims=[0])
-                if ctx.words:
-                    self.act[size:size + n_children] = torch.flip(self.c_act[:n_children], dims=[0])
-                size += n_children
-            self.size = size
-            st.max_open = max(st.max_open, size)
+                self.segs.append([top, n_children])
+            st.max_open = max(st.max_open, self.size)
+        ctx.set_option("branch_reverse", 0)
         s = ctx.stats_read(stream)
         st.filter_steps = s["steps"] + s["steps3"]
-        return done or self.size == 0
+        return done or not self.segs
 
     def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0) -> DeviceSearchStats:
         self.reset(lb0, ub0)
@@ -123,5 +155,10 @@ class DeviceSearch:
 
     def top(self, k: int):
         """The k open nodes on top of the stack (device tensors, views)."""
-        lo = max(0, self.size - k)
-        return self.lb[lo:self.size], self.ub[lo:self.size], self.act[lo:self.size]
+        if self.segs and self.segs[-1][1] < min(k, self.size):
+            self.compact()
+        if not self.segs:
+            return self.lb[0:0], self.ub[0:0], self.act[0:0]
+        s, l = self.segs[-1]
+        lo = max(s, s + l - k)
+        return self.lb[lo:s + l], self.ub[lo:s + l], self.act[lo:s + l]
