@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=1000, help="N-queens size (BASELINE config: 1000)")
-    ap.add_argument("--nodes", type=int, default=8192, help="open nodes per GPU per step")
+    ap.add_argument("--nodes", type=int, default=16384, help="open nodes per GPU per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--out-of-place", action="store_true", help="write the results to separate buffers (default: in place, like Store::consistency)")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
