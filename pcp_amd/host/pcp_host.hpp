@@ -10,6 +10,7 @@
 //   XNeqY XEqY XLessY XLessYPlusZ XGreaterYPlusZ XEqYPlusZ XEqYMulZ, x_greater_y x_geq_y x_leq_y
 //   x_geq_y_plus_z x_leq_y_plus_z — propagators/cmp/*.rs, propagators/cmp/mod.rs:34-86
 //   Distinct / join_distinct      — propagators/distinct.rs:26-126
+//   AllEqual                      — propagators/all_equal.rs:47-64
 //   GpuCStore::alloc / consistency / label / restore — propagation/store.rs:223-230, 247-257, 306-324
 //   Space::consistency            — search/space.rs:41-43
 //   one_solution / all_solutions with FirstSmallestVar, MiddleVal, BinarySplit, StopNode
@@ -135,6 +136,21 @@ inline Propagator x_geq_y(Var x, Var y) { return x_greater_y(addition(x, 1), y);
 inline Propagator x_leq_y(Var x, Var y) { return XLessY(x, addition(y, 1)); }
 inline Propagator x_geq_y_plus_z(Var x, Var y, Var z) { return XGreaterYPlusZ(addition(x, 1), y, z); }
 inline Propagator x_leq_y_plus_z(Var x, Var y, Var z) { return XLessYPlusZ(addition(x, -1), y, z); }
+inline Propagator AllEqual(const std::vector<Var>& vars) {  // propagators/all_equal.rs:47-64: XEqY(v[i], v[i+1]) as ONE unit
+  if (vars.empty()) throw Panic("Variable array in `AllEqual` must be non-empty.");
+  Propagator p;
+  for (size_t i = 0; i + 1 < vars.size(); ++i) {
+    pcp_prop r = make_row(PCP_EQ, {vars[i], vars[i + 1]});
+    r.group_kind = 2;
+    p.rows.push_back(r);
+  }
+  if (p.rows.empty()) {  // one variable: an empty conjunction, entailed at its first evaluation
+    pcp_prop r = make_row(PCP_NEQ, {constant(0), constant(1)});
+    r.group_kind = 2;
+    p.rows.push_back(r);
+  }
+  return p;
+}
 inline Propagator Distinct(const std::vector<Var>& vars) {  // propagators/distinct.rs:63-83: ONE unit
   if (vars.empty()) throw Panic("Variable array in `Distinct` must be non-empty.");
   Propagator p;

@@ -151,6 +151,15 @@ def Distinct(vars: Sequence[View]) -> Conjunction:
     return Conjunction(fs, group_kind=2)
 
 
+def AllEqual(vars: Sequence[View]) -> Conjunction:
+    """propagators/all_equal.rs:47-64: conjunction of XEqY(vars[i], vars[i+1]), ONE unit whose dependencies are the
+    variables in order (all_equal.rs:95-102) — the same shape as Distinct's."""
+    if len(vars) == 0:
+        raise ContractViolation("Variable array in `AllEqual` must be non-empty.")
+    fs = tuple(XEqY(vars[i], vars[i + 1]) for i in range(len(vars) - 1))
+    return Conjunction(fs, group_kind=2)
+
+
 # ----------------------------------------------------------------------------------------------- stores
 class VStore:
     """variable::Store over Interval<i32> (VStoreFD, variable/mod.rs:36): just the domains."""

@@ -32,6 +32,8 @@ def build_unit(suite, case):
     ops = [_view(o) for o in case["ops"]] if "ops" in case else [M.Identity(i) for i in range(n)]
     if ctor == "Distinct":
         return M.Distinct(ops)
+    if ctor == "AllEqual":
+        return M.AllEqual(ops)
     return CTORS[ctor](*ops)
 
 
