@@ -224,6 +224,8 @@ def main():
                             f"{args.nodes} open nodes per GPU per step = this rank's share of the breadth-first frontier of the reference search tree, one fixpoint per node, 1 launch per step, "
                             + ("results written to separate buffers" if args.out_of_place else "in place on a fresh copy of the frontier per step"),
                 "nodes_per_gpu": args.nodes,
+                "domain_cells": "Interval<i32> bounds in and out; in LDS as 16-bit packed (-lb, ub) cells (every bound of the workload is within +-16383; "
+                                "checked per tile on the device), i32 arithmetic in the full filter",
                 "in_place": not args.out_of_place,
                 "fresh_inputs": args.steps if args.out_of_place else max(0, min(args.steps, len(pool) - args.warmup)),
                 "filter_steps_per_step_per_gpu": per_step["steps"] + per_step["steps3"],
