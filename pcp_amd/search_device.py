@@ -65,6 +65,18 @@ class DeviceSearch:
     def _top_row(self) -> int:
         return self.segs[-1][0] + self.segs[-1][1] if self.segs else 0
 
+    def _merge_top(self, want: int):
+        """Close the holes under the top segments until the top segment holds `want` nodes (or is the only one): only
+        the small segments on top are moved, never the bulk of the stack."""
+        while len(self.segs) > 1 and self.segs[-1][1] < want:
+            s2, l2 = self.segs.pop()
+            s1, l1 = self.segs[-1]
+            dest = s1 + l1
+            if l2 and s2 != dest:
+                for t in (self.lb, self.ub, self.act):
+                    t[dest:dest + l2] = t[s2:s2 + l2].clone() if s2 < dest + l2 else t[s2:s2 + l2]
+            self.segs[-1][1] = l1 + l2
+
     def compact(self):
         """Make the open nodes one segment starting at row 0 (order kept)."""
         if len(self.segs) == 1 and self.segs[0][0] == 0:
@@ -101,6 +113,7 @@ class DeviceSearch:
         while self.segs:
             if max_rounds and rounds >= max_rounds:
                 break
+            self._merge_top(batch)
             start, length = self.segs[-1]
             top = start + length
             # the children (at most 2n rows) go right above the popped parents: when the buffer is nearly full, first
