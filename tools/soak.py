@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Randomised soak of the packed / word-group paths against the oracle (not a pytest: run it when the kernels change).
+usage: python tools/soak.py [seconds] [seed0]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pcp_amd.engine as E
+from pcp_amd import model as M
+from oracle import oracle as orc
+from util import random_nodes, random_active, assert_parity
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = E.Context(0)
+t0, it, checked = time.time(), 0, 0
+while time.time() - t0 < budget:
+    rng = np.random.default_rng(seed0 + it)
+    n = int(rng.integers(20, 110))
+    lo = int(rng.integers(-50, 50)); hi = lo + int(rng.integers(3, 120))
+    ii, jj = np.triu_indices(n, 1)
+    if rng.random() < 0.3:  # thin the pairs out: ragged x-blocks, words that straddle several blocks
+        keep = rng.random(len(ii)) < rng.uniform(0.2, 0.9); ii, jj = ii[keep], jj[keep]
+    P = len(ii)
+    if P < 70:
+        it += 1; continue
+    sol = rng.integers(lo, hi + 1, size=n)
+    kinds = [M.NEQ, M.LT, M.EQ][: int(rng.integers(1, 4))]
+    kind = np.repeat(rng.choice(kinds, size=P // 32 + 1), 32)[:P]
+    planted = rng.random() < 0.6
+    d = np.where(kind == M.LT, sol[ii] - sol[jj] + 1 + rng.integers(0, 8, size=P), np.where(kind == M.EQ, sol[ii] - sol[jj], rng.integers(-9, 10, size=P)))
+    if not planted:
+        d = d + rng.integers(-3, 4, size=P)
+    clash = (kind == M.NEQ) & (sol[ii] == sol[jj] + d)
+    d[clash] += 1
+    props = np.zeros(P, dtype=M.PROP_DTYPE); props["var"][:] = M.PCP_NOVAR; props["group"] = np.arange(P)
+    props["kind"] = kind; props["var"][:, 0] = ii; props["var"][:, 1] = jj; props["off"][:, 1] = d
+    lb = np.full(n, lo, np.int32); ub = np.full(n, hi, np.int32)
+    N = int(rng.integers(1, 140))
+    L, U = random_nodes(seed0 + 7 * it, lb, ub, N, sol if planted else None, p_narrow=float(rng.uniform(0.02, 0.5)))
+    act = random_active(seed0 + 11 * it, N, P, p_off=float(rng.uniform(0.0, 0.4)))
+    om = orc.OracleModel(n, props)
+    ref = om.consistency(L, U, act)
+    ctx.set_model(n, props)
+    if rng.random() < 0.5:
+        ctx.set_hull(lo, hi)
+    for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "word_level": 0}, {"nodes_per_block": 32}, {}):
+        for k, v in {"nodes_per_block": 0, "packed": 1, "word_level": 1, "block_threads": int(rng.choice([256, 512, 1024])), **opts}.items():
+            ctx.set_option(k, v)
+        got = ctx.propagate(L, U, act)
+        assert_parity(ref[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} {opts}")
+        checked += 1
+    it += 1
+print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s")
