@@ -3,6 +3,7 @@ the CPU oracle on the same seeded inputs.  Bar: status equal on 
 not False, (lb,ub) and `active` bit-exact.  Integer work: no tolerance anywhere."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ from test_oracle_golden import build_unit
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -275,6 +277,14 @@ def test_batch_sizes_auto_tiling(ctx, n_nodes):
     act = random_active(200 + n_nodes, n_nodes, len(props), p_off=0.1)
     ref, got = both(ctx, n, props, L, U, act, f"auto tiling n_nodes={n_nodes}")
     assert got[4]["nodes"] == n_nodes
+
+
+def test_soak_short():
+    """Eight seconds of tools/soak.py: random all-pairs models (kinds, ragged x-blocks, hulls, batch and tile sizes) on the
+    packed / word-group paths against the oracle; the long version checked 136 000 launches."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak.py"), "8", "20260928"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "soak ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_long_cascade(ctx):
