@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 2
+#define PCP_ABI_VERSION 3
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -84,14 +84,22 @@ typedef struct {
 
 /* Counters.  A *filter step* = one evaluation of one elementary propagator's propagate()+is_subsumed()
  * (one scheduler pop, propagation/store.rs:166-175).  The reference keeps no such
- * counter.  Step counts are schedule-dependent: compare rates, never counts. */
+ * counter.  Step counts are schedule-dependent: compare rates, never counts.
+ * `steps`/`steps3` are REFERENCE-EQUIVALENT steps: every (propagator, node) pair the reference's scheduler would pop —
+ * each live propagator once in the initial sweep (init_scheduler, store.rs:144-149) plus every wake-up.  The engine
+ * proves most of the sweep's pairs no-ops in bulk (whole 64-propagator words from range tables of the tile's
+ * domains) without looking at them; `evaluated` counts the pairs that WERE looked at one by one — tested on the
+ * node's own domains (sweep level 1 / level 2, full filter) or run by a wake-up round — and `full_evals` the pairs
+ * that ran the full filter (propagate() + is_subsumed() literally, with its domain writes). */
 typedef struct {
-  uint64_t steps;        /* filter steps on binary kinds                        */
-  uint64_t steps3;       /* filter steps on ternary kinds (LT3/GT3/EQ3/MUL3)    */
-  uint64_t narrowings;   /* domain writes that strictly shrank a domain         */
-  uint64_t waves;        /* sum over nodes of fixpoint waves (>=1 per node)     */
-  uint64_t failed_nodes; /* nodes that ended PCP_FALSE                          */
-  uint64_t nodes;        /* nodes propagated                                    */
+  uint64_t steps;        /* reference-equivalent filter steps on binary kinds              */
+  uint64_t steps3;       /* the same on ternary kinds (LT3/GT3/EQ3/MUL3)                   */
+  uint64_t narrowings;   /* domain writes that strictly shrank a domain                    */
+  uint64_t waves;        /* sum over nodes of fixpoint waves (>=1 per node)                */
+  uint64_t failed_nodes; /* nodes that ended PCP_FALSE                                     */
+  uint64_t nodes;        /* nodes propagated                                               */
+  uint64_t evaluated;    /* (propagator, node) pairs tested individually on the node's domains */
+  uint64_t full_evals;   /* pairs that ran the full filter                                 */
 } pcp_stats;
 
 typedef struct pcp_ctx pcp_ctx;
@@ -174,6 +182,21 @@ int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synch
 /* Timing of the LAST pcp_propagate_device call's kernels, measured with HIP events recorded on the
  * stream the kernels were launched on (bench.py's roofline leg).  Synchronises on the stop event. */
 int32_t pcp_last_kernel_ms(pcp_ctx* ctx, float* ms);
+
+/* The launch geometry the LAST pcp_propagate_device / pcp_propagate call chose (tests pin the benchmarked path to
+ * the oracle by asserting on it; bench.py reports it). */
+typedef struct {
+  uint32_t nodes_per_block; /* B: nodes whose domains one workgroup keeps in LDS                       */
+  uint32_t team;            /* workgroups cooperating on one node (1 = batch geometry)                 */
+  uint32_t packed;          /* 1 = 16-bit packed LDS cells                                             */
+  uint32_t word_level;      /* 0 = chunked record sweep, 1/2 = word-group sweep (level -1 range test)  */
+  uint32_t global_dom;      /* 1 = domains stay in HBM (variable store larger than LDS)                */
+  uint32_t compact;         /* 1 = 8-byte record stream                                                */
+  uint32_t implicit_active; /* 1 = no `active` rows: liveness derived from the domains                 */
+  uint32_t set_mode;        /* 1 = IntervalSet (bitset) domains                                        */
+  uint32_t grid, block, lds_bytes, list_cap;
+} pcp_plan;
+int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
 
 /* Knobs (all optional; the defaults pick everything from the model and the batch).  key:
  *   "block_threads" 256/512/1024, "nodes_per_block" 0 = auto, "force_path" (0 auto, 1 batch LDS kernel, 2 team kernel),

@@ -55,6 +55,7 @@ struct pcp_ctx {
   // host-buffer path staging
   void* d_stage = nullptr; size_t cap_stage = 0;
 
+  pcp_plan last_plan{};   // geometry of the last launch (pcp_last_plan)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool ev_valid = false;
   int max_dyn_lds_set = 0;
@@ -570,13 +571,13 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   if (team > 1) {
     // per node: ticket, remaining, fail (3 words) + Wv changed words + 4 u64 counters
-    const size_t per_node_words = 4 + Wv + 8;
+    const size_t per_node_words = 4 + Wv + 2 * kTeamCounters;
     const size_t nwords = (size_t)n_nodes * per_node_words + 2;
     if ((rc = ensure(c, c->d_team, c->cap_team, nwords))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->d_team, 0, nwords * 4, stream));
     uint32_t* base = c->d_team;
-    a.team_counters = reinterpret_cast<uint64_t*>(base);                 // [n_nodes][4] u64 (8-byte aligned at base)
-    a.team_ticket = base + (size_t)n_nodes * 8;
+    a.team_counters = reinterpret_cast<uint64_t*>(base);                 // [n_nodes][kTeamCounters] u64 (8-byte aligned at base)
+    a.team_ticket = base + (size_t)n_nodes * 2 * kTeamCounters;
     a.team_remaining = a.team_ticket + n_nodes;
     a.team_fail = a.team_remaining + n_nodes;
     a.team_chg = a.team_fail + n_nodes + (n_nodes & 1);                  // keep alignment tidy
@@ -586,6 +587,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
+  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, a.global_dom, a.m.recs8 ? 1u : 0u, 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation
@@ -613,12 +615,13 @@ int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIP_TRY(c, hipSetDevice(c->device));
   const uint32_t words = (c->n_units + 63) / 64;
-  if (n_nodes && (!status || (c->n_vars && (!lb || !ub || !child_lb || !child_ub)) || (words && (!active || !child_active))))
+  // active == child_active == NULL: implicit-active nodes (domains only; liveness is derived by pcp_propagate_device)
+  if (n_nodes && (!status || (c->n_vars && (!lb || !ub || !child_lb || !child_ub)) || (words && ((active == nullptr) != (child_active == nullptr)))))
     return fail(c, PCP_ERR_ARG, "null buffer");
   int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
   if (rc) return rc;
   if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 16, stream)); return PCP_OK; }
-  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, words, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
+  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, active ? words : 0u, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
   return PCP_OK;
 }
 
@@ -640,6 +643,12 @@ int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
     c->trusted_epoch = 0;
     return fail(c, PCP_ERR_CONTRACT, "a node's bounds lie outside the hull declared with pcp_model_set_hull (status PCP_STATUS_HULL)");
   }
+  return PCP_OK;
+}
+
+int32_t pcp_last_plan(const pcp_ctx* c, pcp_plan* out) {
+  if (!c || !out) return PCP_ERR_ARG;
+  *out = c->last_plan;
   return PCP_OK;
 }
 
@@ -710,6 +719,7 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
     stats->steps = after.steps - before.steps; stats->steps3 = after.steps3 - before.steps3;
     stats->narrowings = after.narrowings - before.narrowings; stats->waves = after.waves - before.waves;
     stats->failed_nodes = after.failed_nodes - before.failed_nodes; stats->nodes = after.nodes - before.nodes;
+    stats->evaluated = after.evaluated - before.evaluated; stats->full_evals = after.full_evals - before.full_evals;
   }
   return PCP_OK;
 }

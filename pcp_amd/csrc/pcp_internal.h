@@ -103,9 +103,10 @@ struct LaunchArgs {
   uint32_t* team_chg;       // [n_nodes][chg_words]
   uint32_t* team_remaining; // [n_nodes]
   uint32_t* team_fail;      // [n_nodes]
-  uint64_t* team_counters;  // [n_nodes][4] steps, steps3, narrowings (merged by the tail block)
+  uint64_t* team_counters;  // [n_nodes][kTeamCounters] steps, steps3, narrowings, evaluated, full_evals (merged by the tail block)
 };
 
+constexpr uint32_t kTeamCounters = 6;
 constexpr int32_t kPackedMax = 16383;   // |bound| limit of the packed tiles: sums of two bounds fit int16
 constexpr uint8_t kStatusRetry = 0xFE;  // internal: never visible to the caller (the second launch overwrites it)
 

@@ -46,6 +46,11 @@ constexpr int kWave = 64;
 
 struct Ctr {  // per-thread counters, reduced once per block
   uint32_t narrow = 0;
+  uint32_t ev = 0;    // pcp_stats.evaluated: (record, node) pairs tested on the node's own domains
+  uint32_t full = 0;  // pcp_stats.full_evals: pairs that ran eval_record
+  // wave-uniform amounts are added on lane 0 only (the block reduction sums all lanes)
+  __device__ __forceinline__ void add_ev_uniform(uint32_t n) { ev += (threadIdx.x & 63u) == 0u ? n : 0u; }
+  __device__ __forceinline__ void add_full_uniform(uint32_t n) { full += (threadIdx.x & 63u) == 0u ? n : 0u; }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -368,7 +373,7 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   c.list_pre = o; o = up(o + ((size_t)list_cap + 1) * 4);
   c.tmp = o; o = up(o + 40 * 4);
   c.remaining = o; o = up(o + (size_t)B * 4);
-  c.misc = o; o = up(o + 16 * 4);
+  c.misc = o; o = up(o + 24 * 4);
   c.total = o;
   return c;
 }
@@ -384,7 +389,7 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 }
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_WORDS = 24 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -989,6 +994,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           if (readlane64(alive4, j)) need |= 1u << j;
       }
       // level 1: every node of the tile, for the words level 0 left over
+#pragma unroll
+      for (int h = 0; h < NL; ++h) ctr.ev += ((need >> jq) & 1u) ? (uint32_t)__popcll(loaded[h]) : 0u;
       bool done1 = false;
       if constexpr (B % UnitNodes<PACKED>::value == 0) {
         if (need == 0xFu) {
@@ -1054,6 +1061,10 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
                 if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(o) & 0) - tw;
                 if (__ballot(o < 0) & alive) slow |= 1u << j;
               }
+              if (jq == (uint32_t)j) {  // every live pair of this word is tested on its node's domains (level 1, or level 2 for XEqY)
+#pragma unroll
+                for (int h = 0; h < NL; ++h) ctr.ev += (uint32_t)__popcll(loaded[h]);
+              }
             }
             if (jq == (uint32_t)j && !post_a) {  // every live record of every node runs once
   #pragma unroll
@@ -1101,6 +1112,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         todo &= todo - 1;
         const uint64_t word = word_of(loaded, b, j);
         bool e = false;
+        ctr.add_full_uniform((uint32_t)__popcll(word));
+        if (generic) ctr.add_ev_uniform((uint32_t)__popcll(word));  // not counted by a level-1 / level-2 test above
         if ((word >> lane) & 1ull) {
           const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
           e = eval_record(rec, dm);
@@ -1345,6 +1358,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
               for (int jj = 0; jj < 4; ++jj) {
                 const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
                 if (wd == 0) continue;
+                ctr.add_ev_uniform((uint32_t)__popcll(wd));
                 uint32_t F, E;
                 asm("v_pk_add_u16 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
                     "v_pk_add_i16 %1, %0, %5 clamp\n\t"
@@ -1366,6 +1380,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
               for (int jj = 0; jj < 4; ++jj) {
                 const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
                 if (wd == 0) continue;
+                ctr.add_ev_uniform((uint32_t)__popcll(wd));
                 const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
                 uint64_t f, en;
                 if (kind0 == PCP_LT) { f = fast_flag<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); en = pure_entailed<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); }
@@ -1381,12 +1396,13 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       } else {
         // mixed kinds or a failed node in the tile: every node with a live record, straight to the full filter
         for (uint32_t b = 0; b < nb; ++b)
-          if (readlane64(col, b) != 0 && !((failnow >> b) & 1u)) todo |= 1u << b;
+          if (readlane64(col, b) != 0 && !((failnow >> b) & 1u)) { todo |= 1u << b; ctr.add_ev_uniform((uint32_t)__popcll(readlane64(col, b))); }
       }
       while (todo) {
         const uint32_t b = __builtin_ctz(todo);
         todo &= todo - 1;
         const uint64_t word = readlane64(ncol, b);  // without the lanes already unlinked in bulk
+        ctr.add_full_uniform((uint32_t)__popcll(word));
         bool e = false;
         if ((word >> lane) & 1ull) {
           const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
@@ -1469,6 +1485,8 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
       const uint64_t run = __ballot(mine), t3 = __ballot(mine && tern);
       steps3 += __popcll(t3);
       steps2 += __popcll(run) - __popcll(t3);
+      ctr.add_ev_uniform((uint32_t)__popcll(run));
+      ctr.add_full_uniform((uint32_t)__popcll(run));
       my_new = writelane64(my_new, word & ~__ballot(e), b);
     }
     if (lane < nb && my_new != my_word) {
@@ -1516,7 +1534,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
-  if (tid < 16) misc[tid] = 0;
+  if (tid < (uint32_t)M_WORDS) misc[tid] = 0;
   if (tid < (uint32_t)B) remaining[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   __syncthreads();
@@ -1652,11 +1670,13 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     }
     // counters: wave -> LDS -> ONE global atomic per block and counter (same-address device atomics serialise
     // at ~12 ns each: per-wave adds from a 512-block team would cost more than the sweep itself)
-    for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
+    for (int o = 32; o > 0; o >>= 1) { ctr.narrow += __shfl_down(ctr.narrow, o); ctr.ev += __shfl_down(ctr.ev, o); ctr.full += __shfl_down(ctr.full, o); }
     if (lane == 0) {
       if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]), (unsigned long long)steps2);
       if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]), (unsigned long long)steps3);
       if (ctr.narrow) atomicAdd(&misc[M_NARROW], ctr.narrow);
+      if (ctr.ev) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_EVAL]), (unsigned long long)ctr.ev);
+      if (ctr.full) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_FULL]), (unsigned long long)ctr.full);
     }
     ctr = Ctr(); steps2 = 0; steps3 = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its merge atomics have been performed
@@ -1664,11 +1684,17 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (tid == 0) {
       const unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);
       const unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]);
-      if (s2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 0], s2);
-      if (s3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 1], s3);
-      if (misc[M_NARROW]) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * 4 + 2], (unsigned long long)misc[M_NARROW]);
+      if (s2) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * kTeamCounters + 0], s2);
+      if (s3) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * kTeamCounters + 1], s3);
+      if (misc[M_NARROW]) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * kTeamCounters + 2], (unsigned long long)misc[M_NARROW]);
+      const unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[M_EVAL]);
+      const unsigned long long sfu = *reinterpret_cast<unsigned long long*>(&misc[M_FULL]);
+      if (sev) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * kTeamCounters + 3], sev);
+      if (sfu) atomicAdd((unsigned long long*)&a.team_counters[(size_t)node0 * kTeamCounters + 4], sfu);
       *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]) = 0;
       *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]) = 0;
+      *reinterpret_cast<unsigned long long*>(&misc[M_EVAL]) = 0;
+      *reinterpret_cast<unsigned long long*>(&misc[M_FULL]) = 0;
       misc[M_NARROW] = 0;
       if (remaining[0]) atomicAdd(&a.team_remaining[node0], remaining[0]);
       if (misc[M_FAIL]) atomicOr(&a.team_fail[node0], 1u);
@@ -1846,6 +1872,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); }
       my2 = __builtin_amdgcn_readfirstlane(my2); my3 = __builtin_amdgcn_readfirstlane(my3);
       steps2 += my2; steps3 += my3;
+      ctr.add_ev_uniform(my2 + my3);
+      ctr.add_full_uniform(my2 + my3);
     } else {
       __syncthreads();
       uint32_t rem_sub = 0;
@@ -1893,9 +1921,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       if (bad) atomicOr(&misc[M_FAIL], 1u << b);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) ctr.narrow += __shfl_down(ctr.narrow, o);
+  for (int o = 32; o > 0; o >>= 1) { ctr.narrow += __shfl_down(ctr.narrow, o); ctr.ev += __shfl_down(ctr.ev, o); ctr.full += __shfl_down(ctr.full, o); }
   if (lane == 0) {
     if (ctr.narrow) atomicAdd(&misc[M_NARROW], ctr.narrow);
+    if (ctr.ev) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_EVAL]), (unsigned long long)ctr.ev);
+    if (ctr.full) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_FULL]), (unsigned long long)ctr.full);
     if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]), (unsigned long long)steps2);
     if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]), (unsigned long long)steps3);
   }
@@ -1910,14 +1940,20 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);
     unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS3]);
     unsigned long long nr = misc[M_NARROW];
+    unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[M_EVAL]);
+    unsigned long long sfu = *reinterpret_cast<unsigned long long*>(&misc[M_FULL]);
     if (team > 1) {
-      s2 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s3 += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      nr += __hip_atomic_load(&a.team_counters[(size_t)node0 * 4 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sev += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sfu += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s2 += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s3 += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nr += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
     if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
     if (nr) atomicAdd((unsigned long long*)&a.stats->narrowings, nr);
+    if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
+    if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[M_WAVES]));
     atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));

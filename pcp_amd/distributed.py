@@ -215,14 +215,15 @@ def balance_stacks(stack, dist) -> int:
     dist.all_gather(gathered, mine)
     moves = plan_moves([int(t.item()) for t in gathered])
     ops, incoming, delta, give = [], [], 0, 0
+    rows = tuple(t for t in (stack.lb, stack.ub, stack.act) if t is not None)  # implicit-active stacks carry no `active` rows
     for src, dst, k in moves:
         if rank == src:
-            for t in (stack.lb, stack.ub, stack.act):
+            for t in rows:
                 ops.append(dist.P2POp(dist.isend, t[give:give + k].contiguous(), dst))
             give += k
             delta += k
         elif rank == dst:
-            bufs = [torch.empty((k,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in (stack.lb, stack.ub, stack.act)]
+            bufs = [torch.empty((k,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in rows]
             for b in bufs:
                 ops.append(dist.P2POp(dist.irecv, b, src))
             incoming.append(bufs)
@@ -232,14 +233,14 @@ def balance_stacks(stack, dist) -> int:
             req.wait()
     if give:  # drop the rows given away: shift the rest down
         keep = stack.size - give
-        for t in (stack.lb, stack.ub, stack.act):
+        for t in rows:
             t[:keep] = t[give:stack.size].clone()
         stack.size = keep
     for bufs in incoming:  # insert received rows at the bottom
         k = bufs[0].shape[0]
         if stack.size + k > stack.lb.shape[0]:
             raise RuntimeError("open-node stack overflow while receiving work; raise `capacity`")
-        for t, b in zip((stack.lb, stack.ub, stack.act), bufs):
+        for t, b in zip(rows, bufs):
             t[k:stack.size + k] = t[:stack.size].clone()
             t[:k] = b
         stack.size += k

@@ -25,12 +25,20 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
 class PcpStats(C.Structure):
-    _fields_ = [(n, C.c_uint64) for n in ("steps", "steps3", "narrowings", "waves", "failed_nodes", "nodes")]
+    _fields_ = [(n, C.c_uint64) for n in ("steps", "steps3", "narrowings", "waves", "failed_nodes", "nodes", "evaluated", "full_evals")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PcpPlan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "compact", "implicit_active", "set_mode",
+                                          "grid", "block", "lds_bytes", "list_cap")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -92,9 +100,10 @@ def load_library():
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -202,6 +211,12 @@ class Context:
         st = PcpStats()
         self._check(self._L.pcp_stats_read(self._h, C.byref(st), C.c_void_p(stream_ptr)))
         return st.as_dict()
+
+    def last_plan(self) -> dict:
+        """pcp_last_plan: the launch geometry of the last propagate call."""
+        pl = PcpPlan()
+        self._check(self._L.pcp_last_plan(self._h, C.byref(pl)))
+        return pl.as_dict()
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

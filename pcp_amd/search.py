@@ -66,23 +66,27 @@ class SearchStats:
     solutions: List[np.ndarray] = field(default_factory=list)
 
 
-def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds: int = 64, active0: Optional[np.ndarray] = None
-                 ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, SearchStats]:
+def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds: int = 64, active0: Optional[np.ndarray] = None,
+                 implicit: bool = False) -> Tuple[np.ndarray, np.ndarray, np.ndarray, SearchStats]:
     """Expand the search tree breadth-first until at least ``n_open`` open (branched, not yet propagated) nodes
     exist; returns their folded (lb, ub, active) rows, at most ``n_open`` of them, in tree order.  ``lb0/ub0`` may be
-    one root or a block of open nodes (with their ``active0`` rows) to continue from."""
+    one root or a block of open nodes (with their ``active0`` rows) to continue from.  ``implicit``: nodes are domains
+    only (no `active` rows; the engine derives liveness from the domains, include/pcp_hip.h) and A is None."""
     from .engine import full_active
     st = SearchStats()
     L = np.ascontiguousarray(lb0, np.int32)
     L = L.reshape(1, -1) if L.ndim == 1 else L
     U = np.ascontiguousarray(ub0, np.int32).reshape(L.shape)
-    A = full_active(L.shape[0], ctx.n_units) if active0 is None else np.ascontiguousarray(active0, np.uint64).reshape(L.shape[0], -1)
+    if implicit:
+        A = None
+    else:
+        A = full_active(L.shape[0], ctx.n_units) if active0 is None else np.ascontiguousarray(active0, np.uint64).reshape(L.shape[0], -1)
     for _ in range(max_rounds):
         if L.shape[0] >= n_open or L.shape[0] == 0:
             break
         ok = (L <= U).all(axis=1)  # a folded branch can be empty: that child is failed without a launch
         st.num_failed_node += int((~ok).sum())
-        L, U, A = L[ok], U[ok], A[ok]
+        L, U, A = L[ok], U[ok], (None if A is None else A[ok])
         if L.shape[0] == 0:
             break
         lb, ub, act, status, s = ctx.propagate(L, U, A)
@@ -94,9 +98,9 @@ def bfs_frontier(ctx, lb0: np.ndarray, ub0: np.ndarray, n_open: int, max_rounds:
             st.num_solution += 1
             st.solutions.append(lb[r].copy())
         unk = status == UNKNOWN
-        L, U, A = branch(lb[unk], ub[unk], act[unk])
+        L, U, A = branch(lb[unk], ub[unk], None if act is None else act[unk])
     ok = (L <= U).all(axis=1)
-    return L[ok][:n_open], U[ok][:n_open], A[ok][:n_open], st
+    return L[ok][:n_open], U[ok][:n_open], (None if A is None else A[ok][:n_open]), st
 
 
 def dfs(ctx, lb0: np.ndarray, ub0: np.ndarray, all_solutions: bool = False, node_limit: int = 0, batch: int = 1) -> SearchStats:

@@ -24,6 +24,7 @@ class DeviceSearchStats:
     num_failed_node: int = 0
     rounds: int = 0
     filter_steps: int = 0
+    evaluated: int = 0
     max_open: int = 0
     solutions: List[np.ndarray] = field(default_factory=list)
 
@@ -34,7 +35,7 @@ class DeviceSearch:
     the children straight above them, in reverse order, as a new segment: nothing is copied or reordered.  The popped
     parents leave a hole below the new segment; it is reclaimed when that segment is used up (LIFO)."""
 
-    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None):
+    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None, implicit: bool = False):
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -46,7 +47,10 @@ class DeviceSearch:
         i32, i64, u8 = torch.int32, torch.int64, torch.uint8
         self.lb = torch.empty((self.cap, V), dtype=i32, device=self.dev)
         self.ub = torch.empty((self.cap, V), dtype=i32, device=self.dev)
-        self.act = torch.empty((self.cap, W), dtype=i64, device=self.dev)
+        # implicit: a node record is its domains only — no `active` rows are kept, the engine derives liveness from the
+        # domains (a node that descends from an all-active root has active = not entailed)
+        self.implicit = bool(implicit) or not ctx.words
+        self.act = None if self.implicit else torch.empty((self.cap, W), dtype=i64, device=self.dev)
         self.status = torch.zeros(self.batch, dtype=u8, device=self.dev)
         self.counts = torch.zeros(4, dtype=i32, device=self.dev)
         self.segs: List[List[int]] = []  # [start, length], bottom to top
@@ -65,6 +69,9 @@ class DeviceSearch:
     def _top_row(self) -> int:
         return self.segs[-1][0] + self.segs[-1][1] if self.segs else 0
 
+    def _rows(self):
+        return (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
+
     def _merge_top(self, want: int):
         """Close the holes under the top segments until the top segment holds `want` nodes (or is the only one): only
         the small segments on top are moved, never the bulk of the stack."""
@@ -73,7 +80,7 @@ class DeviceSearch:
             s1, l1 = self.segs[-1]
             dest = s1 + l1
             if l2 and s2 != dest:
-                for t in (self.lb, self.ub, self.act):
+                for t in self._rows():
                     t[dest:dest + l2] = t[s2:s2 + l2].clone() if s2 < dest + l2 else t[s2:s2 + l2]
             self.segs[-1][1] = l1 + l2
 
@@ -84,7 +91,7 @@ class DeviceSearch:
         pos = 0
         for s, l in self.segs:
             if l and s != pos:
-                for t in (self.lb, self.ub, self.act):
+                for t in self._rows():
                     t[pos:pos + l] = t[s:s + l].clone() if s < pos + l else t[s:s + l]
             pos += l
         self.segs = [[0, pos]] if pos else []
@@ -95,7 +102,7 @@ class DeviceSearch:
         from .engine import full_active
         self.lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev)
         self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
-        if ctx.words:
+        if self.act is not None:
             self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
         self.segs = [[0, 1]]
         self.stats = DeviceSearchStats()
@@ -131,10 +138,11 @@ class DeviceSearch:
                 if n <= 0:
                     break
             lo = top - n
-            lb, ub, act = self.lb[lo:top], self.ub[lo:top], self.act[lo:top]
+            lb, ub = self.lb[lo:top], self.ub[lo:top]
+            act = None if self.act is None else self.act[lo:top]
             status = self.status[:n]
-            ctx.propagate_device(n, lb, ub, lb, ub, act if ctx.words else None, act if ctx.words else None, status, stream)
-            ctx.branch_device(n, lb, ub, act if ctx.words else None, status, self.lb[top:], self.ub[top:], self.act[top:] if ctx.words else None,
+            ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream)
+            ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
                               self.counts, stream)
             n_children, n_true, n_false, _ = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
             rounds += 1
@@ -159,6 +167,7 @@ class DeviceSearch:
         ctx.set_option("branch_reverse", 0)
         s = ctx.stats_read(stream)
         st.filter_steps = s["steps"] + s["steps3"]
+        st.evaluated = s.get("evaluated", 0)
         return done or not self.segs
 
     def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0) -> DeviceSearchStats:
@@ -171,7 +180,7 @@ class DeviceSearch:
         if self.segs and self.segs[-1][1] < min(k, self.size):
             self.compact()
         if not self.segs:
-            return self.lb[0:0], self.ub[0:0], self.act[0:0]
+            return self.lb[0:0], self.ub[0:0], (None if self.act is None else self.act[0:0])
         s, l = self.segs[-1]
         lo = max(s, s + l - k)
-        return self.lb[lo:s + l], self.ub[lo:s + l], self.act[lo:s + l]
+        return self.lb[lo:s + l], self.ub[lo:s + l], (None if self.act is None else self.act[lo:s + l])

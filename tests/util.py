@@ -105,50 +105,5 @@ def assert_parity(ref, got, what=""):
         assert np.array_equal(ract[ok], gact[ok]), f"{what}: active differs"
 
 
-def planted_binary_csp(seed, n_vars=50_000, n_props=500_000, dom=(0, 999)):
-    """BASELINE config 3 generator, vectorised: binary props `x ◇ y + c`, endpoints uniform
-    without self-loops, ◇ in {< 40 %, <= 20 %, != 30 %, = 10 %} lowered to LT / LT(+1) / NEQ / EQ over Addition
-    views; a planted solution s satisfies every constraint (slack U[0,20] for inequalities) so propagation never
-    fails and cascades are long."""
-    rng = splitmix64(seed)
-    lo, hi = dom
-    sol = rng.integers(lo, hi + 1, size=n_vars)
-    x = rng.integers(0, n_vars, size=n_props)
-    y = rng.integers(0, n_vars - 1, size=n_props)
-    y = np.where(y >= x, y + 1, y)  # no self-loops
-    op = rng.choice(4, size=n_props, p=[0.4, 0.2, 0.3, 0.1])  # 0 '<', 1 '<=', 2 '!=', 3 '='
-    slack = rng.integers(0, 21, size=n_props)
-    sx, sy = sol[x], sol[y]
-    c = np.zeros(n_props, np.int64)
-    c[op == 0] = (sx - sy + 1 + slack)[op == 0]          # x < y + c
-    c[op == 1] = (sx - sy + slack)[op == 1]              # x <= y + c  ==  x < y + (c+1)
-    neq = op == 2
-    c[neq] = rng.integers(-20, 21, size=int(neq.sum()))
-    clash = neq & (sx == sy + c)
-    c[clash] += 1
-    c[op == 3] = (sx - sy)[op == 3]                      # x = y + c
-    props = np.zeros(n_props, dtype=M.PROP_DTYPE)
-    props["var"][:] = M.PCP_NOVAR
-    props["group"] = np.arange(n_props)
-    props["kind"] = np.select([op <= 1, op == 2, op == 3], [M.LT, M.NEQ, M.EQ])
-    props["var"][:, 0] = x
-    props["var"][:, 1] = y
-    props["off"][:, 1] = np.where(op == 1, c + 1, c)
-    lb = np.full(n_vars, lo, np.int32)
-    ub = np.full(n_vars, hi, np.int32)
-    return props, lb, ub, sol
-
-
-def unit_narrowing_prefix(seed, lb, ub, sol, n_nodes, k=64):
-    """Node k of the config-3 batch: the root with a random prefix of k variables narrowed around the planted
-    solution (so the node stays consistent and differs from its neighbours)."""
-    rng = splitmix64(seed)
-    V = lb.shape[0]
-    L = np.tile(lb, (n_nodes, 1)).astype(np.int32)
-    U = np.tile(ub, (n_nodes, 1)).astype(np.int32)
-    for n in range(n_nodes):
-        vs = rng.choice(V, size=k, replace=False)
-        w = rng.integers(0, 40, size=k)
-        L[n, vs] = np.maximum(lb[vs], sol[vs] - w)
-        U[n, vs] = np.minimum(ub[vs], sol[vs] + rng.integers(0, 40, size=k))
-    return L, U
+# BASELINE config-3 generators live with the other workloads (bench.py measures what the tests check)
+from pcp_amd.workloads import planted_binary_csp, unit_narrowing_prefix  # noqa: E402,F401
