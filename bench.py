@@ -1,15 +1,22 @@
 #!/usr/bin/env python
 """bench.py — propagator filter-steps/sec to fixpoint on N-queens-1000 (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch: `pcp_propagate_device` runs every open node of this
-rank's batch to its propagation fixpoint (one kernel launch, inputs and outputs resident in HBM).  The batch is
-a breadth-first frontier of the reference's own search tree on N-queens n=1000 (FirstSmallestVar / MiddleVal /
-BinarySplit), `--nodes` open nodes per GPU: per-GPU work is fixed as N grows (weak scaling); nodes are
-independent, so there is no collective in the data path.  `value` = filter steps of all ranks / max-over-ranks
-wall time of the K timed steps.
+One "step" = one pass of the hot path over one batch: `pcp_propagate_device` runs every open node of this rank's batch
+to its propagation fixpoint (one kernel launch, inputs and outputs resident in HBM, in place like
+`Store::consistency(&mut vstore)`).  The batch is this rank's share of the breadth-first frontier of the reference's own
+search tree on N-queens n=1000 (FirstSmallestVar / MiddleVal / BinarySplit), `--nodes` open nodes per GPU: per-GPU work
+is fixed as N grows (weak scaling); nodes are independent, so there is no collective in the data path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under
-torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+What `value` is: REFERENCE-EQUIVALENT filter steps per second — every (propagator, node) pair the reference's scheduler
+would pop to reach the same fixpoints (each propagator of each node once in the initial sweep, store.rs:144-149, plus
+every wake-up), divided by the max-over-ranks wall time of the K timed steps.  The engine proves most of those pairs
+no-ops in bulk; `config.steps_evaluated_per_s` is the rate of pairs it actually tested one by one and
+`config.full_filter_evals_per_s` the rate of full propagate()+is_subsumed() runs.  `roofline` is PHYSICAL: the bytes the
+ABI contract forces across HBM per launch (every node's rows in once, out once) / kernel time / 8 TB/s — always <= 1.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run
+(one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  `--mode search` runs BASELINE config 5 instead (the sharded
+open-node worklist over RCCL, nodes/s).
 """
 import argparse
 import json
@@ -22,47 +29,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_BINARY, BYTES_TERNARY, BYTES_NARROWING = 28, 40, 8  # SURVEY.md §8d algorithmic bytes per filter step
+BYTES_BINARY, BYTES_TERNARY, BYTES_NARROWING = 28, 40, 8  # SURVEY.md §8d algorithmic bytes per filter step (side field only)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
-
-
-def cpu_baseline(n, props, lb, ub, act, budget_s):
-    """The oracle (a port: libpcp cannot be built here) timed on this host, single thread like the reference,
-    on a bounded sample of the SAME batch: as many of its first nodes as fit in ~budget_s."""
-    from oracle import oracle as orc
-    om = orc.OracleModel(n, props)
-    out = {}
-    for label, check in (("restatement-noassert", False), ("libpcp-restatement", True)):
-        steps, nodes, t0 = 0, 0, time.perf_counter()
-        while nodes < lb.shape[0] and (time.perf_counter() - t0) < budget_s / 2:
-            r = om.consistency(lb[nodes:nodes + 1], ub[nodes:nodes + 1], act[nodes:nodes + 1], check_dup=check)
-            steps += r[4]["steps"]
-            nodes += 1
-        dt = time.perf_counter() - t0
-        out[label] = {"steps_per_s": steps / dt, "nodes": nodes, "seconds": dt}
-    main = out["libpcp-restatement"]
-    return {
-        "value": main["steps_per_s"], "unit": "filter-steps/s", "cores": 1, "kind": "port",
-        "sample": f"first {main['nodes']} nodes of the same batch, {main['seconds']:.1f} s, structure-faithful C++ restatement "
-                  f"of libpcp incl. the duplicate-subscription assert; without that assert: {out['restatement-noassert']['steps_per_s']:.3e} steps/s "
-                  f"over {out['restatement-noassert']['nodes']} nodes",
-        "host_cpu": _cpu_name(),
-    }
-
-
-def profiled_traffic(n, nodes):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes (profiles/*traffic.json,
-    written by tools/profile_bench.sh + tools/traffic_json.py for exactly this workload), or None."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
-        try:
-            d = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        if d.get("n") == n and d.get("nodes_per_launch") == nodes:
-            best = d
-    return best
 
 
 def _cpu_name():
@@ -75,6 +43,154 @@ def _cpu_name():
     return "unknown"
 
 
+def cpu_baseline(n, props, lb, ub, act, budget_s):
+    """The oracle (a port: libpcp cannot be built here) timed on this host, single thread like the reference, on a
+    bounded sample of the SAME batch: as many of its first nodes as fit in ~budget_s.  Returns the JSON object and the
+    oracle's outputs for those nodes (bench.py compares the GPU's results with them: parity_checked_nodes)."""
+    from oracle import oracle as orc
+    om = orc.OracleModel(n, props)
+    out, keep = {}, None
+    for label, check in (("restatement-noassert", False), ("libpcp-restatement", True)):
+        steps, nodes, t0, res = 0, 0, time.perf_counter(), []
+        while nodes < lb.shape[0] and (time.perf_counter() - t0) < budget_s / 2:
+            r = om.consistency(lb[nodes:nodes + 1], ub[nodes:nodes + 1], None if act is None else act[nodes:nodes + 1], check_dup=check)
+            res.append(r[:4])
+            steps += r[4]["steps"]
+            nodes += 1
+        dt = time.perf_counter() - t0
+        out[label] = {"steps_per_s": steps / dt, "nodes": nodes, "seconds": dt}
+        if not check:
+            keep = res
+    main = out["libpcp-restatement"]
+    obj = {
+        "value": main["steps_per_s"], "unit": "filter-steps/s", "cores": 1, "kind": "port",
+        "sample": f"first {main['nodes']} nodes of the same batch, {main['seconds']:.1f} s, structure-faithful C++ restatement "
+                  f"of libpcp incl. the duplicate-subscription assert; without that assert: {out['restatement-noassert']['steps_per_s']:.3e} steps/s "
+                  f"over {out['restatement-noassert']['nodes']} nodes",
+        "host_cpu": _cpu_name(),
+    }
+    return obj, keep
+
+
+def profiled_traffic(tag_key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*traffic.json, written
+    by tools/profile_bench.sh + tools/traffic_json.py for exactly this workload), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if all(d.get(k) == v for k, v in tag_key.items()):
+            best = d
+    return best
+
+
+class Leg:
+    """One timed workload: K launches of pcp_propagate_device, each in place on its own fresh copy of the batch (staged in
+    HBM beforehand), HIP-event time per launch, counters per launch, compulsory bytes per launch."""
+
+    def __init__(self, ctx, torch, name, lb, ub, act, compulsory_bytes, note=""):
+        self.ctx, self.torch, self.name, self.note = ctx, torch, name, note
+        self.lb, self.ub, self.act = lb, ub, act
+        self.n = lb.shape[0]
+        self.bytes = compulsory_bytes
+        self.status = torch.zeros(self.n, dtype=torch.uint8, device=lb.device)
+
+    def run(self, launches=5, warmup=1):
+        ctx, torch = self.ctx, self.torch
+        stream = torch.cuda.current_stream().cuda_stream
+        copies = [(self.lb.clone(), self.ub.clone(), None if self.act is None else self.act.clone()) for _ in range(launches + warmup)]
+        for i in range(warmup):
+            l, u, a = copies[i]
+            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream)
+        torch.cuda.synchronize()
+        ctx.stats_reset(stream)
+        ms = []
+        for i in range(launches):
+            l, u, a = copies[warmup + i]
+            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream)
+            ms.append(ctx.last_kernel_ms())
+        st = ctx.stats_read(stream)
+        per = {k: v / launches for k, v in st.items()}
+        med = float(np.median(ms))
+        steps = per["steps"] + per["steps3"]
+        self.result = {
+            "name": self.name, "nodes": self.n, "launches": launches,
+            "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
+            "steps_per_launch": steps, "evaluated_per_launch": per["evaluated"], "full_evals_per_launch": per["full_evals"],
+            "narrowings_per_launch": per["narrowings"], "waves_per_node": per["waves"] / self.n,
+            "steps_per_s": steps / (med * 1e-3), "evaluated_per_s": per["evaluated"] / (med * 1e-3),
+            "nodes_per_s": self.n / (med * 1e-3),
+            "compulsory_bytes_per_launch": self.bytes,
+            "hbm_frac": self.bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "status_false_true_unknown": np.bincount(self.status.cpu().numpy(), minlength=3)[:3].tolist(),
+            "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "implicit_active", "grid")},
+        }
+        if self.note:
+            self.result["note"] = self.note
+        return self.result
+
+
+def node_bytes(V, words, explicit):
+    """Compulsory HBM bytes per node and launch, in place: bounds rows read once and written once (8 B per variable each way);
+    with explicit `active` rows additionally the row read once (its few changed words written back are not counted)."""
+    return 16 * V + (8 * words if explicit else 0)
+
+
+def run_search_mode(args, torch, dist, world, rank, dev):
+    """BASELINE config 5: N-queens-n parallel subtree search, the open-node worklist sharded over the ranks and balanced
+    GPU-to-GPU over RCCL (pcp_amd.distributed.parallel_search_device), on a fixed node budget."""
+    import pcp_amd.engine as E
+    from pcp_amd import model as M
+    from pcp_amd import distributed as D
+    from pcp_amd.search_device import DeviceSearch
+    n = args.n
+    ctx = E.Context(dev.index)
+    ctx.set_model(n, M.nqueens_props(n))
+    ctx.set_hull(1, n)
+    batch = args.search_batch
+    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    if world == 1 and not dist.is_initialized():
+        # a single GPU still goes through the process group (RCCL with one rank): same driver, same exchange steps
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    grp = dist
+    # warm-up: a short search (kernels loaded, buffers touched)
+    D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, node_limit=min(args.node_budget, 8 * batch), rounds_per_exchange=args.rounds_per_exchange)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    info = {}
+    nodes, sols, fails, steps, moved = D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, node_limit=args.node_budget,
+                                                                 rounds_per_exchange=args.rounds_per_exchange, info=info)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t_dt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
+    dt = float(t_dt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: sharded open-node worklist)",
+            "value": steps / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {
+                "workload": f"N-queens n={n} parallel subtree search, first {args.node_budget} nodes of the tree (all ranks together), device-resident stacks, "
+                            f"batch {batch} nodes per round and GPU, worklist balanced every {args.rounds_per_exchange} rounds by all_gather + pairwise send/recv (RCCL)",
+                "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails, "moved_records": moved,
+                "exchange_seconds_rank0": info.get("exchange_s"), "exchange_share_rank0": (info.get("exchange_s") or 0) / dt, "exchanges": info.get("exchanges"),
+                "record_bytes": 8 * n, "parallelism": f"worklist sharded over {world} GPU(s)",
+            },
+        }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,10 +199,16 @@ def main():
     ap.add_argument("--n", type=int, default=1000, help="N-queens size (BASELINE config: 1000)")
     ap.add_argument("--nodes", type=int, default=16384, help="open nodes per GPU per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
-    ap.add_argument("--out-of-place", action="store_true", help="write the results to separate buffers (default: in place, like Store::consistency)")
+    ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
+                    help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,c3,c4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
+    ap.add_argument("--mode", choices=["propagate", "search"], default="propagate")
+    ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
+    ap.add_argument("--search-batch", type=int, default=4096)
+    ap.add_argument("--rounds-per-exchange", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -110,9 +232,14 @@ def main():
         g.build()  # a no-op when the prebuilt libraries match the sources (content hash)
     if world > 1:
         dist.barrier()
+    if args.mode == "search":
+        run_search_mode(args, torch, dist, world, rank, dev)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return
     import pcp_amd.engine as E
     from pcp_amd import model as M
-    from pcp_amd import search as S
+    from pcp_amd import workloads as W
 
     n = args.n
     props = M.nqueens_props(n)
@@ -121,49 +248,33 @@ def main():
     ctx.set_hull(1, n)  # the queens were allocated with Interval(1, n)  (example/src/nqueens.rs:32-35)
     ctx.set_option("block_threads", args.block_threads)
     ctx.set_option("nodes_per_block", args.nodes_per_block)
+    implicit = args.active == "implicit"
+    V, words = n, ctx.words
 
-    # ---- synthetic input: the breadth-first frontier of the search tree, sharded by rank --------------------
-    # The root is expanded to a common frontier of 8 subtrees per SHARE, with max(8, world) shares; rank r keeps the
-    # subtrees r, r+shares, ... and expands THOSE breadth-first to its own args.nodes open nodes.  Share r is the same
-    # set of nodes whatever the number of GPUs (a 1-GPU run is share 0 of the 8-GPU run): per-GPU work is fixed
-    # (weak scaling) and no rank ever materialises another rank's nodes.
-    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    # ---- synthetic input: this rank's share of the breadth-first frontier (pcp_amd.workloads.nqueens_frontier) --------
     shares = max(8, world)
-    L0, U0, A0, _ = S.bfs_frontier(ctx, lb0, ub0, 8 * shares)
-    if L0.shape[0] < shares:
-        raise SystemExit(f"common frontier has only {L0.shape[0]} open nodes for {shares} shares")
     share = rank if args.share < 0 else args.share % shares
-    L, U, A, fst = S.bfs_frontier(ctx, L0[share::shares], U0[share::shares], args.nodes, active0=A0[share::shares])
-    if L.shape[0] < args.nodes:
-        raise SystemExit(f"frontier has only {L.shape[0]} open nodes")
+    L, U, A = W.nqueens_frontier(ctx, n, args.nodes, share=share, shares=shares, implicit=implicit)
     t_lb_in = torch.from_numpy(L).to(dev)
     t_ub_in = torch.from_numpy(U).to(dev)
-    t_act_in = torch.from_numpy(A.view(np.int64)).to(dev)
+    t_act_in = None if A is None else torch.from_numpy(A.view(np.int64)).to(dev)
     t_status = torch.zeros(args.nodes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    n_probe = min(args.steps, 10)  # untimed steps after the timed ones, for the per-launch HIP-event time
+    n_probe = min(args.steps, 10)  # untimed steps after the timed ones, for the per-launch HIP-event times
     total_steps = args.warmup + args.steps + n_probe
-    if args.out_of_place:
-        t_lb_out, t_ub_out, t_act_out = torch.empty_like(t_lb_in), torch.empty_like(t_ub_in), torch.empty_like(t_act_in)
-        pool = []
-    else:
-        # In place, as the reference's Store::consistency(&mut vstore) works and as the search loop calls the engine: every
-        # step gets its OWN copy of the frontier, staged in HBM before the timed region (288 GB: 0.8 GB per copy at the
-        # default size).  If K exceeds what fits, the pool is cycled and the later steps see already-propagated nodes
-        # (same sweep, nothing left to narrow) — reported as fresh_inputs < steps.
-        copy_bytes = t_lb_in.numel() * 4 * 2 + t_act_in.numel() * 8
-        free_b, _ = torch.cuda.mem_get_info(dev)
-        n_pool = max(1, min(total_steps, int(free_b * 0.6 // copy_bytes)))
-        pool = [(t_lb_in.clone(), t_ub_in.clone(), t_act_in.clone()) for _ in range(n_pool)]
+    # In place, as the reference's Store::consistency(&mut vstore) works and as the search loop calls the engine: every
+    # step gets its OWN copy of the frontier, staged in HBM before the timed region.  If K exceeds what fits, the pool is
+    # cycled and the later steps see already-propagated nodes — reported as fresh_inputs < steps.
+    copy_bytes = t_lb_in.numel() * 8 + (0 if t_act_in is None else t_act_in.numel() * 8)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    n_pool = max(1, min(total_steps, int(free_b * 0.5 // copy_bytes)))
+    pool = [(t_lb_in.clone(), t_ub_in.clone(), None if t_act_in is None else t_act_in.clone()) for _ in range(n_pool)]
     step_no = [0]
 
     def step():
-        if args.out_of_place:
-            ctx.propagate_device(args.nodes, t_lb_in, t_ub_in, t_lb_out, t_ub_out, t_act_in, t_act_out, t_status, stream)
-        else:
-            lb_, ub_, act_ = pool[step_no[0] % len(pool)]
-            step_no[0] += 1
-            ctx.propagate_device(args.nodes, lb_, ub_, lb_, ub_, act_, act_, t_status, stream)
+        lb_, ub_, act_ = pool[step_no[0] % len(pool)]
+        step_no[0] += 1
+        ctx.propagate_device(args.nodes, lb_, ub_, lb_, ub_, act_, act_, t_status, stream)
 
     def barrier():
         if world > 1:
@@ -175,7 +286,6 @@ def main():
     barrier()
     ctx.stats_reset(stream)
     torch.cuda.synchronize()
-    kernel_ms = []
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -183,29 +293,34 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    # HIP-event time of the fixpoint kernel of each step would need a sync per step; take it from a second,
-    # untimed pass over the same steps so that the timed region stays free of host syncs.
+    # HIP-event time of the fixpoint kernel of each step would need a sync per step; take it from a second, untimed pass
+    # over the same steps so that the timed region stays free of host syncs.
+    kernel_ms = []
     for _ in range(n_probe):
         step()
         kernel_ms.append(ctx.last_kernel_ms())
     st = ctx.stats_read(stream)
-    # stats now cover args.steps + len(kernel_ms) identical steps
-    per_step = {k: v / (args.steps + len(kernel_ms)) for k, v in st.items()}
+    plan = ctx.last_plan()
+    per_step = {k: v / (args.steps + len(kernel_ms)) for k, v in st.items()}  # stats cover steps + probes, all identical
     steps_rank = (per_step["steps"] + per_step["steps3"]) * args.steps
+    eval_rank = per_step["evaluated"] * args.steps
+    full_rank = per_step["full_evals"] * args.steps
 
     t_dt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    t_steps = torch.tensor([steps_rank], dtype=torch.float64, device=dev)
+    t_cnt = torch.tensor([steps_rank, eval_rank, full_rank], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_steps, op=dist.ReduceOp.SUM)
-    dt_max, steps_all = float(t_dt.item()), float(t_steps.item())
+        dist.all_reduce(t_cnt, op=dist.ReduceOp.SUM)
+    dt_max = float(t_dt.item())
+    steps_all, eval_all, full_all = (float(x) for x in t_cnt.tolist())
 
     status = t_status.cpu().numpy()
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms))
-        tr = profiled_traffic(n, args.nodes)
+        k_ms = float(np.median(kernel_ms))
+        compulsory = args.nodes * node_bytes(V, words, not implicit)
         alg_bytes = BYTES_BINARY * per_step["steps"] + BYTES_TERNARY * per_step["steps3"] + BYTES_NARROWING * per_step["narrowings"]
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        tr = profiled_traffic({"n": n, "nodes_per_launch": args.nodes, "active": args.active})
+        achieved = compulsory / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000",
             "value": steps_all / dt_max,
@@ -220,39 +335,144 @@ def main():
             "dtype": "i32",
             "data": "synthetic",
             "config": {
-                "workload": f"N-queens n={n}, x[i]!=x[j]+k decomposition (V={n}, P={len(props)} XNeqY), Interval<i32> domains; "
-                            f"{args.nodes} open nodes per GPU per step = this rank's share of the breadth-first frontier of the reference search tree, one fixpoint per node, 1 launch per step, "
-                            + ("results written to separate buffers" if args.out_of_place else "in place on a fresh copy of the frontier per step"),
+                "workload": f"N-queens n={n}, x[i]!=x[j]+k decomposition (V={n}, P={len(props)} XNeqY), Interval<i32> domains (NOT the reference's default FDSpace/IntervalSet "
+                            f"mode: bounds-only propagation, in which near-root nodes narrow almost nothing); {args.nodes} open nodes per GPU per step = this rank's share of the "
+                            f"breadth-first frontier of the search tree, one fixpoint per node, 1 launch per step, in place on a fresh copy of the frontier per step; "
+                            + ("nodes are domains only (implicit `active`: every unit active on entry, liveness derived from the domains)" if implicit
+                               else "nodes carry explicit `active` rows (183 KB per node)"),
+                "value_is": "reference-equivalent filter steps per second: the (propagator, node) pairs the reference's scheduler would pop to reach the same fixpoints; "
+                            "most are proven no-ops in bulk (range tests over whole 64-propagator words) and never looked at individually",
+                "steps_evaluated_per_s": eval_all / dt_max,
+                "full_filter_evals_per_s": full_all / dt_max,
+                "nodes_per_s": args.nodes * world * args.steps / dt_max,
                 "nodes_per_gpu": args.nodes,
-                "domain_cells": "Interval<i32> bounds in and out; in LDS as 16-bit packed (-lb, ub) cells (every bound of the workload is within +-16383; "
-                                "checked per tile on the device), i32 arithmetic in the full filter",
-                "in_place": not args.out_of_place,
-                "fresh_inputs": args.steps if args.out_of_place else max(0, min(args.steps, len(pool) - args.warmup)),
+                "active_rows": args.active,
+                "plan": plan,
+                "domain_cells": "Interval<i32> bounds in and out; in LDS as 16-bit packed (-lb, ub) cells (declared hull [1,n]), i32 arithmetic in the full filter",
+                "fresh_inputs": max(0, min(args.steps, len(pool) - args.warmup)),
                 "filter_steps_per_step_per_gpu": per_step["steps"] + per_step["steps3"],
+                "evaluated_per_step_per_gpu": per_step["evaluated"],
+                "full_evals_per_step_per_gpu": per_step["full_evals"],
                 "narrowings_per_step_per_gpu": per_step["narrowings"],
                 "fixpoint_waves_per_node": per_step["waves"] / args.nodes,
-                "status_counts_false_true_unknown": np.bincount(status, minlength=3).tolist(),
+                "status_counts_false_true_unknown": np.bincount(status, minlength=3)[:3].tolist(),
+                "kernel_ms_per_launch": {"min": float(min(kernel_ms)), "median": k_ms, "max": float(max(kernel_ms)), "launches": len(kernel_ms)},
                 "parallelism": f"nodes sharded over {world} GPU(s), no data-path collective",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (tr or {}).get("traffic_bytes"),
                 "traffic_source": (tr or {}).get("source"),
-                "traffic_GBs": ((tr or {}).get("traffic_bytes") or 0) / (k_ms * 1e-3) / 1e9 if tr else None,
-                "traffic_frac_of_peak": ((tr or {}).get("traffic_bytes") or 0) / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
                 "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "achieved = algorithmic bytes (28 B per binary filter step + 8 B per narrowing, SURVEY.md §8d) / kernel time; the "
-                        "kernel proves whole 64-propagator words no-ops for 16 nodes at a time from LDS-resident range tables, so "
-                        "what actually crosses HBM is the nodes' active masks (1 bit per propagator and node): `traffic` (rocprofv3 PMC, "
-                        "profiles/) and traffic_frac_of_peak are the physical roofline figures (DESIGN.md §5)",
+                "compulsory_bytes_per_launch": compulsory,
+                "model": "achieved = compulsory HBM bytes per launch / median HIP-event kernel time: every node's (lb, ub) rows read once and written once "
+                         "(16 B per variable and node)" + ("" if implicit else " plus its `active` row read once (8 B per 64 propagators)")
+                         + "; the model tables (word descriptors, records) are shared by all tiles and stay in L2.  `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of the "
+                           "committed rocprofv3 PMC passes (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes), per launch",
+                "algorithmic_bytes_per_launch_survey_8d": alg_bytes,
+                "algorithmic_frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "algorithmic_note": "SURVEY.md §8d's 28 B per reference-equivalent step; far above 1 because those bytes are never moved (domains live in LDS, whole words are "
+                                    "cleared from range tables) — a labelled side figure, not the roofline",
             },
         }
+        legs_req = args.legs
+        if legs_req == "auto":
+            legs_req = "explicit,c2,deep500,deep3000,c3,c4" if world == 1 else "none"
+        legs = []
         if world == 1 and args.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(n, props, L, U, A, args.cpu_budget)
+            out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
+            # parity of the measured launch itself: the nodes the CPU leg just computed, against the GPU's results for the
+            # same nodes (pool[0] was propagated in place by the first warm-up step)
+            k = len(ref)
+            g_lb, g_ub = pool[0][0][:k].cpu().numpy(), pool[0][1][:k].cpu().numpy()
+            g_act = None if pool[0][2] is None else pool[0][2][:k].cpu().numpy().view(np.uint64)
+            if implicit:  # materialise the `active` rows of those nodes on request
+                _, _, g_act, _, _ = ctx.propagate_implicit(L[:k], U[:k], want_active=True)
+            for i, (r_lb, r_ub, r_act, r_st) in enumerate(ref):
+                if int(r_st[0]) != int(status[i]):
+                    raise SystemExit(f"PARITY FAILURE: node {i} status {int(status[i])} != oracle {int(r_st[0])}")
+                if int(r_st[0]) != 0 and not (np.array_equal(r_lb[0], g_lb[i]) and np.array_equal(r_ub[0], g_ub[i]) and np.array_equal(r_act[0], g_act[i])):
+                    raise SystemExit(f"PARITY FAILURE: node {i} differs from the oracle")
+            out["config"]["parity_checked_nodes"] = k
+        if legs_req != "none":
+            legs = side_legs(ctx, torch, dev, n, props, args, set(legs_req.split(",")), L, U)
+        out["config"]["legs"] = legs
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def side_legs(ctx, torch, dev, n, props, args, want, L, U):
+    """The other BASELINE configurations, each timed by HIP events on a few launches."""
+    import pcp_amd.engine as E
+    from pcp_amd import model as M
+    from pcp_amd import workloads as W
+    from pcp_amd.search_device import DeviceSearch
+    legs = []
+    V, words = n, ctx.words
+
+    def reset_opts():
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "team": 0, "global_dom": 0, "packed": 1, "word_level": 1}.items():
+            ctx.set_option(k, v)
+
+    if "explicit" in want:  # the same frontier with explicit `active` rows (round 1's node format and headline)
+        reset_opts()
+        ctx.set_option("nodes_per_block", args.nodes_per_block)
+        shares = 8
+        Le, Ue, Ae = W.nqueens_frontier(ctx, n, args.nodes, share=0 if args.share < 0 else args.share % shares, shares=shares, implicit=False)
+        leg = Leg(ctx, torch, "C2-frontier-explicit-active-rows", torch.from_numpy(Le).to(dev), torch.from_numpy(Ue).to(dev), torch.from_numpy(Ae.view(np.int64)).to(dev),
+                  Le.shape[0] * node_bytes(V, words, True), "the same frontier with node = domains + 183 KB `active` row (round 1's headline configuration)")
+        legs.append(leg.run(launches=3, warmup=1))
+        del leg, Le, Ue, Ae
+    if "c2" in want:
+        # C2 as surveyed: DFS with a node limit of 256, ONE pcp_propagate_device(n_nodes=1) per node (team path), branching on the device
+        reset_opts()
+        ds = DeviceSearch(ctx, batch=1, capacity=1024, implicit=True)
+        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+        ds.run(lb0, ub0, all_solutions=False, node_limit=32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = ds.run(lb0, ub0, all_solutions=False, node_limit=256)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        legs.append({"name": "C2-dfs-256-one-node-per-call", "nodes": st.num_nodes, "seconds": dt, "us_per_node": dt / st.num_nodes * 1e6,
+                     "steps_per_s": st.filter_steps / dt, "evaluated_per_s": st.evaluated / dt, "last_kernel_us": ctx.last_kernel_ms() * 1e3,
+                     "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "implicit_active", "grid")},
+                     "note": "per node: one pcp_propagate_device(n_nodes=1) + pcp_branch_device + a 16-byte D2H of the counters (the round's only sync)"})
+        del ds
+    for dive in (500, 3000):
+        if f"deep{dive}" in want:
+            reset_opts()
+            lb, ub, _ = W.nqueens_deep(ctx, n, dive, 4096, implicit=True)
+            reset_opts()
+            assigned = float((lb == ub).sum(dim=1).float().mean().item())
+            leg = Leg(ctx, torch, f"C2-deep-dive-{dive}", lb, ub, None, lb.shape[0] * node_bytes(V, words, False),
+                      f"4096 open nodes {dive} nodes down a left-first DFS dive ({assigned:.0f} queens assigned on average)")
+            legs.append(leg.run(launches=5, warmup=1))
+            del leg, lb, ub
+    if "c3" in want:
+        reset_opts()
+        V3, P3, N3 = 50_000, 500_000, 4096
+        p3, lb3, ub3, sol3 = W.planted_binary_csp(0xC3, V3, P3)
+        L3, U3 = W.unit_narrowing_prefix(0xC3 + 1, lb3, ub3, sol3, N3)
+        ctx.set_model(V3, p3)
+        leg = Leg(ctx, torch, "C3-random-binary-csp-50k-vars-500k-props", torch.from_numpy(L3).to(dev), torch.from_numpy(U3).to(dev), None,
+                  N3 * node_bytes(V3, ctx.words, False), "4096 nodes, planted solution, unit-narrowing prefixes; domains stay in HBM (400 KB per node)")
+        legs.append(leg.run(launches=3, warmup=1))
+        del leg
+    if "c4" in want:
+        reset_opts()
+        p4, L4, U4, A4 = W.golomb_frontier(ctx, 4096)
+        V4 = L4.shape[1]
+        leg = Leg(ctx, torch, "C4-golomb-distinct-sum-network", torch.from_numpy(L4).to(dev), torch.from_numpy(U4).to(dev),
+                  torch.from_numpy(A4.view(np.int64)).to(dev), L4.shape[0] * node_bytes(V4, ctx.words, True),
+                  f"{L4.shape[0]} open nodes of the BinarySplit expansion, V={V4}, {len(p4)} elementary filters in {ctx.n_units} units (one Distinct of 990)")
+        legs.append(leg.run(launches=5, warmup=1))
+        del leg
+    # back to the headline model for anything that follows
+    ctx.set_model(n, props)
+    ctx.set_hull(1, n)
+    return legs
 
 
 if __name__ == "__main__":

@@ -70,6 +70,7 @@ struct pcp_ctx {
   int64_t opt_branch_reverse = 0;   // 1 = pcp_branch_device writes the children in reverse order (row n_children-1-k)
   int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
   int64_t opt_word_level = 1;       // 1 = auto (word-group sweep with the level -1 range test on packed tiles), 0 = never
+  int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
 };
 
 namespace {
@@ -438,6 +439,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "packed") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "packed must be 0 or 1");
     c->opt_packed = value;
+  } else if (k == "implicit_active") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "implicit_active must be 0 or 1");
+    c->opt_implicit = value;
   } else if (k == "list_cap") {
     if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
     c->opt_list_cap = value;
@@ -464,6 +468,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const uint32_t block = (uint32_t)c->opt_block;
   const uint32_t list_cap = (uint32_t)c->opt_list_cap;
 
+  const bool implicit = bt->active_in == nullptr && c->opt_implicit;  // see below (a.live == nullptr)
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
   // tile sizes the kernel is instantiated for (pcp_kernels.hip launch_fixpoint)
   static const uint32_t kTiles[] = {16, 12, 8, 4, 2, 1};
@@ -521,7 +526,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     const uint32_t wl_model = (c->opt_word_level && groups <= 1000u * (block / 64u)) ? c->word_level : 0;
     for (uint32_t t : {32u, 16u, 8u}) {
       if (t > want) continue;
-      for (uint32_t wl : {wl_model, 0u}) {
+      // implicit nodes: the maximum tables as well (word_level 2) — the level -1 test then also clears words that are
+      // entailed throughout the tile, which it otherwise has to hand to the record level at every node again
+      const uint32_t wl_first = (implicit && wl_model) ? 2u : wl_model;
+      for (uint32_t wl : {wl_first, wl_model, 0u}) {
         if (wl && t > 16) continue;
         auto need_for = [&](uint32_t cap) { return lds_bytes_for(S, t, cap, block, true, wl); };
         const uint32_t cap_min = std::max<uint32_t>(256, wl ? groups : 0);
@@ -557,7 +565,13 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.status = bt->status;
   a.stats = c->d_stats;
   const uint32_t unit_words = (c->n_units + 63) / 64;
-  if (c->has_groups) {
+  // active_in == NULL: every unit active on entry.  Then liveness needs no rows at all: a unit that is entailed runs as a
+  // no-op, so "active" can be DERIVED (inactive <=> entailed under the current domains) and the node is its
+  // domains only — the implicit-active path (a.live == nullptr).  Results are identical to the explicit path by construction.
+  if (implicit) {
+    a.live_in = nullptr;
+    a.live = nullptr;
+  } else if (c->has_groups) {
     // record-level live rows in scratch, seeded from the unit-level `active` rows (in place for the kernel)
     if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
     HIP_TRY(c, launch_expand_units(c->d_rec_unit, P, unit_words, bt->active_in, c->d_live, n_nodes, stream));
@@ -587,7 +601,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
-  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, a.global_dom, a.m.recs8 ? 1u : 0u, 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
+  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation
@@ -602,7 +616,16 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, launch_fixpoint(a2, plan2, stream));
   }
   HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
-  if (c->has_groups && bt->active_out)
+  if (implicit && bt->active_out && P) {
+    // the `active` rows on request: record r is live iff it is not entailed under the final domains
+    if (c->has_groups) {
+      if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+      HIP_TRY(c, launch_derive_active(a.m, bt->lb_out, bt->ub_out, c->d_live, n_nodes, stream));
+      HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
+    } else {
+      HIP_TRY(c, launch_derive_active(a.m, bt->lb_out, bt->ub_out, bt->active_out, n_nodes, stream));
+    }
+  } else if (c->has_groups && bt->active_out)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
   c->ev_valid = true;
   return PCP_OK;

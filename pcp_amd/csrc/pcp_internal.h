@@ -95,7 +95,8 @@ struct LaunchArgs {
   int32_t* lb_out;
   int32_t* ub_out;
   const uint64_t* live_in;  // [n_nodes][words] or null = all live
-  uint64_t* live;           // [n_nodes][words] working + output live mask (never null)
+  uint64_t* live;           // [n_nodes][words] working + output live mask; null = IMPLICIT: no live rows at all, every record is
+                            //     taken as live and the status comes from an entailment scan of the final domains
   uint8_t* status;
   pcp_stats* stats;         // device counters
   // team mode scratch (per node): arrival ticket, merged changed mask, remaining counter, fail flag
@@ -127,6 +128,9 @@ hipError_t launch_expand_units(const uint32_t* rec_unit, uint32_t n_recs, uint32
                                uint32_t n_nodes, hipStream_t stream);
 hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, uint32_t n_recs, const uint64_t* live, uint64_t* active_out,
                                  uint32_t n_nodes, hipStream_t stream);
+
+// Implicit-active nodes: record-level live rows from the final domains (live bit = the record is not entailed).
+hipError_t launch_derive_active(const ModelDev& m, const int32_t* lb, const int32_t* ub, uint64_t* live, uint32_t n_nodes, hipStream_t stream);
 
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,

@@ -37,6 +37,12 @@
 #ifndef PCP_ABLATE
 #define PCP_ABLATE 0
 #endif
+// This file is compiled twice (__graft_entry__.build, in parallel): PCP_TU == 0 emits the kernels that work on explicit
+// `active` rows plus every utility kernel and host helper; PCP_TU == 1 emits only the IMPLICIT-active instantiations of the
+// fixpoint kernel (nodes are domains only, liveness is derived: a propagator is inactive iff it is entailed).
+#ifndef PCP_TU
+#define PCP_TU 0
+#endif
 
 namespace pcp {
 
@@ -378,6 +384,7 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   return c;
 }
 
+#if PCP_TU == 0
 size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed, uint32_t word_level) {
   (void)block;
   Carve c = carve(n_slots, nodes_per_block, list_cap, n_slots, packed, packed ? word_level : 0);
@@ -387,9 +394,10 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
   Carve c = carve(n_slots - n_vars, 1, list_cap, n_slots);
   return c.total <= 160 * 1024 ? c.total : 0;
 }
+#endif  // PCP_TU == 0
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_WORDS = 24 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_WORDS = 24 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -436,8 +444,19 @@ __device__ __forceinline__ typename DomOf<GLOBAL, PACKED>::type make_dom(const B
 //      alone and the two are not disjoint); symmetrically for Y = {u}; two singletons never satisfy it.
 //  LT  (x_less_y.rs:87-109): x.ub drops iff X.y >= Yu, y.lb rises iff Yl <= X.x, entailed iff X.y < Yl.
 //  EQ  (x_eq_y.rs:87-107): x ∩ y differs from x or y iff a bound differs; entailed iff both are one singleton.
-template <int KIND>
+//
+// IMPLICIT (no `active` rows: nothing is ever unlinked, so entailment is of no interest during the fixpoint): a clear bit
+// only has to prove that no domain narrows and nothing fails.
+//  NEQ narrows only with a singleton on one side that equals a bound of the other side: X = {v}, v == Yl or v == Yu, or
+//      Y = {u}, u == X.lb or u == X.ub; all four cases (and the failure X = Y = {v}) have X.lb == Yu or X.ub == Yl.
+//  LT  narrows iff X.ub >= Yu or Yl <= X.lb (a failure X.lb >= Yu implies the first);  EQ iff a bound differs.
+template <int KIND, bool IMPLICIT = false>
 __device__ __forceinline__ uint64_t fast_flag(const int2 X, const int Yl, const int Yu) {
+  if constexpr (IMPLICIT) {
+    if (KIND == PCP_NEQ) return __ballot(X.x == Yu) | __ballot(Yl == X.y);
+    if (KIND == PCP_LT) return __ballot(X.y >= Yu) | __ballot(Yl <= X.x);
+    return __ballot(X.x != Yl) | __ballot(X.y != Yu);
+  }
   if (KIND == PCP_NEQ) return __ballot(X.x >= Yu) | __ballot(Yl >= X.y);
   if (KIND == PCP_LT) return __ballot(X.y >= Yu) | __ballot(Yl <= X.x) | __ballot(X.y < Yl);
   return __ballot(X.x != Yl) | __ballot(X.y != Yu) | __ballot(X.x == X.y);
@@ -460,7 +479,7 @@ __device__ __forceinline__ uint64_t pure_entailed(const int2 X, const int Yl, co
 // one address register, all issued before the first compare so that the LDS latency is paid once per group;
 // then two or three compares per node and scalar mask logic.  (word,node) pairs with a flagged live lane are
 // returned in the bitmask for the full filter.
-template <int KIND, int B, bool PACKED, int NL>
+template <int KIND, int B, bool PACKED, int NL, bool IMPLICIT>
 __device__ __forceinline__ uint32_t fast_nodes(const typename CellOf<PACKED>::type* px, const typename CellOf<PACKED>::type* py, const int d,
                                                const uint64_t (&live)[NL], const uint32_t j) {
   // live[h]: lane (b & 15) * kChunk + j holds word j of node b = 16 h + (b & 15)   (see sweep_fast)
@@ -469,7 +488,7 @@ __device__ __forceinline__ uint32_t fast_nodes(const typename CellOf<PACKED>::ty
     const uint64_t word = readlane64(live[0], j);
     if (word) {
       const int2 X = px[0], Y = py[0];  // stored as (-lb, ub)
-      if (fast_flag<KIND>(make_int2(-X.x, X.y), d - Y.x, Y.y + d) & word) todo = 1;
+      if (fast_flag<KIND, IMPLICIT>(make_int2(-X.x, X.y), d - Y.x, Y.y + d) & word) todo = 1;
     }
     return todo;
   } else {
@@ -489,7 +508,7 @@ __device__ __forceinline__ uint32_t fast_nodes(const typename CellOf<PACKED>::ty
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
-          const uint64_t f = fast_flag<KIND>(X, Y.x + d, Y.y + d) & wd[jj];
+          const uint64_t f = fast_flag<KIND, IMPLICIT>(X, Y.x + d, Y.y + d) & wd[jj];
           todo |= f ? (1u << (g + jj)) : 0u;
         }
       } else {
@@ -502,8 +521,8 @@ __device__ __forceinline__ uint32_t fast_nodes(const typename CellOf<PACKED>::ty
 #pragma unroll
         for (int jj = 0; jj < G / 2; ++jj) {
           // LDS holds (-lb, ub)
-          const uint64_t f0 = fast_flag<KIND>(make_int2(-Xp[jj].x, Xp[jj].y), d - Yp[jj].x, Yp[jj].y + d) & wd[2 * jj];
-          const uint64_t f1 = fast_flag<KIND>(make_int2(-Xp[jj].z, Xp[jj].w), d - Yp[jj].z, Yp[jj].w + d) & wd[2 * jj + 1];
+          const uint64_t f0 = fast_flag<KIND, IMPLICIT>(make_int2(-Xp[jj].x, Xp[jj].y), d - Yp[jj].x, Yp[jj].y + d) & wd[2 * jj];
+          const uint64_t f1 = fast_flag<KIND, IMPLICIT>(make_int2(-Xp[jj].z, Xp[jj].w), d - Yp[jj].z, Yp[jj].w + d) & wd[2 * jj + 1];
           todo |= f0 ? (1u << (g + 2 * jj)) : 0u;
           todo |= f1 ? (1u << (g + 2 * jj + 1)) : 0u;
         }
@@ -530,10 +549,28 @@ __device__ __forceinline__ uint32_t slot_row(uint32_t v) {
 // and the terms of all nodes are OR-ed together (v_or3_b32): the sign bit of the result is clear iff nothing happens
 // on this lane's record in ANY node.  No scalar work, no cross-lane work: 3 VALU (NEQ) and half a ds_read_b128 per
 // (record,node).
-template <int KIND, int B>
+// IMPLICIT: XNeqY can only narrow where t1 = Yu + d + Xn or t2 = Xu + Yn - d is exactly zero (fast_flag): the running
+// UNSIGNED minimum of the terms over the nodes is zero iff some node has a zero.  XLessY: the entailment term is dropped.
+template <int KIND, int B, bool IMPLICIT = false>
 __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const int d) {
   const int c1 = d - 1, c2 = -d - 1, c3 = -d;
   int o = 0;
+  if constexpr (IMPLICIT && KIND == PCP_NEQ) {
+    uint32_t z1 = 0xffffffffu, z2 = 0xffffffffu;
+    if (B == 1) {
+      const int2 X = px[0], Y = py[0];
+      z1 = (uint32_t)(Y.y + d + X.x); z2 = (uint32_t)(X.y - d + Y.x);
+    } else {
+#pragma unroll
+      for (int g = 0; g < B; g += 2) {
+        const int4 Xp = *static_cast<const int4*>(__builtin_assume_aligned(px + g, 16));
+        const int4 Yp = *static_cast<const int4*>(__builtin_assume_aligned(py + g, 16));
+        z1 = min(min(z1, (uint32_t)(Yp.y + d + Xp.x)), (uint32_t)(Yp.w + d + Xp.z));
+        z2 = min(min(z2, (uint32_t)(Xp.y - d + Yp.x)), (uint32_t)(Xp.w - d + Yp.z));
+      }
+    }
+    return (z1 == 0u || z2 == 0u) ? -1 : 0;
+  }
   if (PCP_ABLATE & 1) {
     const int f = (int)(size_t)px ^ (int)(size_t)py;
 #pragma unroll
@@ -572,6 +609,7 @@ __device__ __forceinline__ int fast_signs(const int2* px, const int2* py, const 
   }
   if (PCP_ABLATE & 2) return o;
   if (KIND == PCP_NEQ) return (m1 + c1) | (m2 + c2);
+  if (IMPLICIT) return m1 + c1;  // XLessY narrows iff X.ub >= Yu or Yl <= X.lb; whether it is entailed does not matter
   return (m1 + c1) | (m2 + c3);
 }
 
@@ -621,6 +659,47 @@ __device__ __forceinline__ void lt4_16(uint32_t& mn, uint32_t& mx, uint32_t& mn3
       : "+v"(mn), "+v"(mx), "+v"(mn3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
       : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
 }
+// IMPLICIT XNeqY: U = X + swap(Y) + (d, -d) = (t1, t2) per node; running unsigned minimum (zero iff some node has a zero)
+__device__ __forceinline__ void neq4z_16(uint32_t& mn, const uint4 X, const uint4 Y, const uint32_t c0) {
+  uint32_t t0, t1, t2, t3;
+  asm("v_pk_add_u16 %1, %5, %9 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %2, %6, %10 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %3, %7, %11 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %4, %8, %12 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_add_u16 %1, %1, %13\n\t"
+      "v_pk_add_u16 %2, %2, %13\n\t"
+      "v_pk_add_u16 %3, %3, %13\n\t"
+      "v_pk_add_u16 %4, %4, %13\n\t"
+      "v_pk_min_u16 %1, %1, %2\n\t"
+      "v_pk_min_u16 %3, %3, %4\n\t"
+      "v_pk_min_u16 %0, %0, %1\n\t"
+      "v_pk_min_u16 %0, %0, %3"
+      : "+v"(mn), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w), "v"(c0));
+}
+// IMPLICIT XLessY: only the narrowing terms (running min of Xn - Yn and running max of Xu - Yu)
+__device__ __forceinline__ void lt4i_16(uint32_t& mn, uint32_t& mx, const uint4 X, const uint4 Y) {
+  uint32_t t0, t1, t2, t3;
+  asm("v_pk_sub_i16 %2, %6, %10\n\t"
+      "v_pk_sub_i16 %3, %7, %11\n\t"
+      "v_pk_sub_i16 %4, %8, %12\n\t"
+      "v_pk_sub_i16 %5, %9, %13\n\t"
+      "v_pk_min_i16 %0, %0, %2\n\t"
+      "v_pk_max_i16 %1, %1, %2\n\t"
+      "v_pk_min_i16 %0, %0, %3\n\t"
+      "v_pk_max_i16 %1, %1, %3\n\t"
+      "v_pk_min_i16 %0, %0, %4\n\t"
+      "v_pk_max_i16 %1, %1, %4\n\t"
+      "v_pk_min_i16 %0, %0, %5\n\t"
+      "v_pk_max_i16 %1, %1, %5"
+      : "+v"(mn), "+v"(mx), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(X.x), "v"(X.y), "v"(X.z), "v"(X.w), "v"(Y.x), "v"(Y.y), "v"(Y.z), "v"(Y.w));
+}
+// (d, -d) as two int16 halves; |d| beyond the packed range can never meet a sum of two packed bounds: any non-zero filler
+__device__ __forceinline__ uint32_t pack_c0(int d) {
+  const int dc = max(-32767, min(32767, d));
+  return ((uint32_t)dc & 0xffffu) | ((uint32_t)(-dc) << 16);
+}
 __device__ __forceinline__ uint32_t pk_min(uint32_t x, uint32_t y) {
   uint32_t r;
   asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
@@ -634,11 +713,12 @@ __device__ __forceinline__ uint32_t pk_max(uint32_t x, uint32_t y) {
 __device__ __forceinline__ int lo16(uint32_t v) { return (int)(short)(v & 0xffffu); }
 __device__ __forceinline__ int hi16(uint32_t v) { return (int)v >> 16; }
 
-template <int KIND, int B>
+template <int KIND, int B, bool IMPLICIT = false>
 __device__ __forceinline__ int fast_signs16(const uint32_t* px, const uint32_t* py, const int d) {
   static_assert(B % 4 == 0, "packed tiles hold a multiple of four nodes");
   const int c1 = d - 1, c2 = -d - 1, c3 = -d;
-  uint32_t mn = 0x7fff7fffu, mn3 = 0x7fff7fffu, mx = 0x80008000u;
+  uint32_t mn = (IMPLICIT && KIND == PCP_NEQ) ? 0xffffffffu : 0x7fff7fffu, mn3 = 0x7fff7fffu, mx = 0x80008000u;
+  const uint32_t c0 = pack_c0(d);
 #pragma unroll
   for (int g = 0; g < B; g += 4) {
     uint32_t xs[4], ys[4];
@@ -657,8 +737,17 @@ __device__ __forceinline__ int fast_signs16(const uint32_t* px, const uint32_t* 
       continue;
     }
     const uint4 X4 = make_uint4(xs[0], xs[1], xs[2], xs[3]), Y4 = make_uint4(ys[0], ys[1], ys[2], ys[3]);
-    if (KIND == PCP_NEQ) neq4_16(mn, X4, Y4);   // running min of (Xn + Yu, Xu + Yn)
-    else lt4_16(mn, mx, mn3, X4, Y4);           // mn.lo: min (Xn - Yn); mx.hi: max (Xu - Yu); mn3.hi: min (Xu + Yn)
+    if constexpr (IMPLICIT) {
+      if (KIND == PCP_NEQ) neq4z_16(mn, X4, Y4, c0);  // running unsigned min of (t1, t2)
+      else lt4i_16(mn, mx, X4, Y4);
+    } else {
+      if (KIND == PCP_NEQ) neq4_16(mn, X4, Y4);   // running min of (Xn + Yu, Xu + Yn)
+      else lt4_16(mn, mx, mn3, X4, Y4);           // mn.lo: min (Xn - Yn); mx.hi: max (Xu - Yu); mn3.hi: min (Xu + Yn)
+    }
+  }
+  if constexpr (IMPLICIT) {
+    if (KIND == PCP_NEQ) return ((mn & 0xffffu) == 0u || (mn >> 16) == 0u) ? -1 : 0;
+    return (lo16(mn) + c1) | (c1 - hi16(mx));
   }
   if (KIND == PCP_NEQ) return (lo16(mn) + c1) | (hi16(mn) + c2);
   return (lo16(mn) + c1) | (c1 - hi16(mx)) | (hi16(mn3) + c3);
@@ -682,18 +771,29 @@ __device__ __forceinline__ void load_unit(Rows& r, const typename CellOf<PACKED>
     r.y[i] = *static_cast<const uint4*>(__builtin_assume_aligned(py + g0 + kPer * i, 16));
   }
 }
-template <bool PACKED>
+template <int KIND, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ SignAcc acc_init() {
+  if (IMPLICIT && KIND == PCP_NEQ) return SignAcc{0xffffffffu, 0xffffffffu, 0u};  // running unsigned minima
   if (PACKED) return SignAcc{0x7fff7fffu, 0x80008000u, 0x7fff7fffu};
   return SignAcc{0x7fffffffu, 0x7fffffffu, 0u};
 }
-template <int KIND, bool PACKED>
-__device__ __forceinline__ void accumulate(SignAcc& s, const Rows& r) {
+template <int KIND, bool PACKED, bool IMPLICIT>
+__device__ __forceinline__ void accumulate(SignAcc& s, const Rows& r, const int d) {
 #pragma unroll
   for (int i = 0; i < kUnitRows; ++i) {
     if constexpr (PACKED) {
-      if (KIND == PCP_NEQ) neq4_16(s.a, r.x[i], r.y[i]);
-      else lt4_16(s.a, s.b, s.c, r.x[i], r.y[i]);
+      if constexpr (IMPLICIT) {
+        if (KIND == PCP_NEQ) neq4z_16(s.a, r.x[i], r.y[i], pack_c0(d));
+        else lt4i_16(s.a, s.b, r.x[i], r.y[i]);
+      } else {
+        if (KIND == PCP_NEQ) neq4_16(s.a, r.x[i], r.y[i]);
+        else lt4_16(s.a, s.b, s.c, r.x[i], r.y[i]);
+      }
+    } else if constexpr (IMPLICIT && KIND == PCP_NEQ) {
+      const int xn0 = (int)r.x[i].x, xu0 = (int)r.x[i].y, xn1 = (int)r.x[i].z, xu1 = (int)r.x[i].w;
+      const int yn0 = (int)r.y[i].x, yu0 = (int)r.y[i].y, yn1 = (int)r.y[i].z, yu1 = (int)r.y[i].w;
+      s.a = min(min(s.a, (uint32_t)(yu0 + d + xn0)), (uint32_t)(yu1 + d + xn1));
+      s.b = min(min(s.b, (uint32_t)(xu0 - d + yn0)), (uint32_t)(xu1 - d + yn1));
     } else {
       // (-lb, ub) pairs of two nodes per 16 bytes
       const int xn0 = (int)r.x[i].x, xu0 = (int)r.x[i].y, xn1 = (int)r.x[i].z, xu1 = (int)r.x[i].w;
@@ -711,9 +811,18 @@ __device__ __forceinline__ void accumulate(SignAcc& s, const Rows& r) {
     }
   }
 }
-template <int KIND, bool PACKED>
+template <int KIND, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ int acc_finish(const SignAcc& s, const int d) {
   const int c1 = d - 1, c2 = -d - 1, c3 = -d;
+  if constexpr (IMPLICIT) {
+    if constexpr (KIND == PCP_NEQ) {
+      if (PACKED) return ((s.a & 0xffffu) == 0u || (s.a >> 16) == 0u) ? -1 : 0;
+      return (s.a == 0u || s.b == 0u) ? -1 : 0;
+    } else {
+      if (PACKED) return (lo16(s.a) + c1) | (c1 - hi16(s.b));
+      return (int)s.a + c1;
+    }
+  }
   if constexpr (PACKED) {
     if (KIND == PCP_NEQ) return (lo16(s.a) + c1) | (hi16(s.a) + c2);
     return (lo16(s.a) + c1) | (c1 - hi16(s.b)) | (hi16(s.c) + c3);
@@ -723,19 +832,19 @@ __device__ __forceinline__ int acc_finish(const SignAcc& s, const int d) {
   }
 }
 // o[j] for the four words of a chunk, units double-buffered.
-template <int KIND, int B, bool PACKED>
+template <int KIND, int B, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ void chunk_signs(int (&o)[4], const typename CellOf<PACKED>::type* const (&px)[4],
                                             const typename CellOf<PACKED>::type* const (&py)[4], const int (&d)[4]) {
   constexpr int UN = UnitNodes<PACKED>::value, UPW = B / UN, U = 4 * UPW;
   static_assert(B % UN == 0 && UPW >= 1, "tile must be a whole number of units");
   Rows r[2];
-  SignAcc acc = acc_init<PACKED>();
+  SignAcc acc = acc_init<KIND, PACKED, IMPLICIT>();
   load_unit<PACKED>(r[0], px[0], py[0], 0);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (u + 1 < U) load_unit<PACKED>(r[(u + 1) & 1], px[(u + 1) / UPW], py[(u + 1) / UPW], ((u + 1) % UPW) * UN);
-    accumulate<KIND, PACKED>(acc, r[u & 1]);
-    if (u % UPW == UPW - 1) { o[u / UPW] = acc_finish<KIND, PACKED>(acc, d[u / UPW]); acc = acc_init<PACKED>(); }
+    accumulate<KIND, PACKED, IMPLICIT>(acc, r[u & 1], d[u / UPW]);
+    if (u % UPW == UPW - 1) { o[u / UPW] = acc_finish<KIND, PACKED, IMPLICIT>(acc, d[u / UPW]); acc = acc_init<KIND, PACKED, IMPLICIT>(); }
     __builtin_amdgcn_sched_barrier(0);  // keep the source order: hipcc otherwise clusters the reads of a whole word up front
   }
 }
@@ -794,12 +903,32 @@ __device__ __forceinline__ Rec expand(const Rec r) { return r; }
 // The summaries are not maintained while the domains narrow: a record that touches a variable narrowed during the
 // sweep is re-run by the wake-up rounds anyway, so a stale summary is the same race as reading the domain a moment
 // before the narrowing.
-template <int KIND, bool PACKED>
+// IMPLICIT: XNeqY narrows only where t1 = Xn + Yu + d or t2 = Xu + Yn - d is exactly zero: a term whose lower bound over the
+// tile (sum of the minima) is positive or whose upper bound (sum of the maxima) is negative has no zero in any node — this also
+// clears records that are ENTAILED in every node of the tile, which the explicit form (it must unlink them) cannot.
+__device__ __forceinline__ int neq_no_zero(const uint32_t tlo, const uint32_t thi, const int dmin, const int dmax) {
+  // tlo <= (Xn + Yu, Xu + Yn) <= thi over the nodes; offsets in [dmin, dmax].  < 0 iff a zero cannot be excluded
+  const bool z1 = (lo16(tlo) + dmin > 0) || (lo16(thi) + dmax < 0);
+  const bool z2 = (hi16(tlo) - dmax > 0) || (hi16(thi) - dmin < 0);
+  return (z1 && z2) ? 0 : -1;
+}
+template <int KIND, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, const uint32_t (&x)[4], const uint32_t (&y)[4], const int (&d)[4]) {
   if constexpr (PACKED) {
     const uint32_t* tmin = static_cast<const uint32_t*>(sp.a);
     const uint32_t* tmax = static_cast<const uint32_t*>(sp.b);
-    if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
+    if constexpr (IMPLICIT && KIND == PCP_NEQ) {
+      uint32_t xn[4], xx[4], yn[4], yx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xn[j] = tmin[x[j]]; xx[j] = tmax[x[j]]; yn[j] = tmin[y[j]]; yx[j] = tmax[y[j]]; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t tlo, thi;
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tlo) : "v"(xn[j]), "v"(yn[j]));
+        asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(thi) : "v"(xx[j]), "v"(yx[j]));
+        o[j] = neq_no_zero(tlo, thi, d[j], d[j]);
+      }
+    } else if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
       uint32_t xs[4], ys[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) { xs[j] = tmin[x[j]]; ys[j] = tmin[y[j]]; }
@@ -816,7 +945,7 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c1 = d[j] - 1, c3 = -d[j];
-        o[j] = (hi16(yn[j]) - hi16(xx[j]) + c1) | (lo16(xn[j]) - lo16(yx[j]) + c1) | (hi16(xn[j]) + lo16(yn[j]) + c3);
+        o[j] = (hi16(yn[j]) - hi16(xx[j]) + c1) | (lo16(xn[j]) - lo16(yx[j]) + c1) | (IMPLICIT ? 0 : (hi16(xn[j]) + lo16(yn[j]) + c3));
       }
     }
   } else {
@@ -827,13 +956,21 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c1 = d[j] - 1, c2 = -d[j] - 1, c3 = -d[j];
-      if (KIND == PCP_NEQ) o[j] = (X[j].x + Y[j].y + c1) | (X[j].y + Y[j].x + c2);
+      if constexpr (IMPLICIT) {
+        if (KIND == PCP_NEQ) {
+          const bool z1 = (X[j].x + Y[j].y + d[j] > 0) || (X[j].z + Y[j].w + d[j] < 0);
+          const bool z2 = (X[j].y + Y[j].x - d[j] > 0) || (X[j].w + Y[j].z - d[j] < 0);
+          o[j] = (z1 && z2) ? 0 : -1;
+        } else {
+          o[j] = (Y[j].y - X[j].w + c1) | (X[j].x - Y[j].z + c1);
+        }
+      } else if (KIND == PCP_NEQ) o[j] = (X[j].x + Y[j].y + c1) | (X[j].y + Y[j].x + c2);
       else o[j] = (Y[j].y - X[j].w + c1) | (X[j].x - Y[j].z + c1) | (X[j].y + Y[j].x + c3);
     }
   }
 }
 
-template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
+template <int B, bool GLOBAL, bool COMPACT, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& k, uint32_t w0, uint32_t w1, uint32_t node0, uint32_t nb,
                                            uint32_t* chg_next, uint32_t* remaining, uint64_t& steps2, uint64_t& steps3, Ctr& ctr,
                                            const uint64_t* hard64 = nullptr) {
@@ -850,7 +987,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the loop control scalar
   const uint32_t P = a.m.n_recs, words = (P + 63) >> 6;
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
-  const uint64_t* live_src = post_a ? a.live : a.live_in;
+  // IMPLICIT: no live rows anywhere — every record of every node is taken as live (an entailed record's filter is a no-op)
+  const uint64_t* live_src = IMPLICIT ? nullptr : (post_a ? a.live : a.live_in);
   const uint32_t bq = lane / kChunk, jq = lane % kChunk;  // this lane's (node mod 16, word-in-chunk) for the live-mask I/O
   bool io[NL];
   const uint64_t* my_in[NL];
@@ -860,7 +998,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     io[h] = bq + 16u * h < nb;
     const uint32_t my_node = node0 + (io[h] ? bq + 16u * h : 0u);
     my_in[h] = live_src ? live_src + (size_t)my_node * words : nullptr;
-    my_out[h] = a.live + (size_t)my_node * words;
+    my_out[h] = IMPLICIT ? nullptr : a.live + (size_t)my_node * words;
   }
   const uint32_t c0 = w0 / kChunk, c1 = (w1 + kChunk - 1) / kChunk;  // w0 is a multiple of kChunk
   // The stream is latency-bound, not bandwidth-bound: with one 1-KiB record load in flight per wavefront a CU moves
@@ -975,8 +1113,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           d0[j] = rec.d;
         }
         // one kind branch per chunk, and the eight summary reads of a chunk go out together
-        if (ckind == PCP_NEQ) level0_chunk<PCP_NEQ, PACKED>(o0, k.summ, sx, sy, d0);
-        else level0_chunk<PCP_LT, PACKED>(o0, k.summ, sx, sy, d0);
+        if (ckind == PCP_NEQ) level0_chunk<PCP_NEQ, PACKED, IMPLICIT>(o0, k.summ, sx, sy, d0);
+        else level0_chunk<PCP_LT, PACKED, IMPLICIT>(o0, k.summ, sx, sy, d0);
         uint64_t bal[kChunk];
         bool any0 = false;
 #pragma unroll
@@ -1010,8 +1148,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
             py[j] = kdom + slot_row<B, PACKED>(rec.y);
             dd[j] = rec.d;
           }
-          if (ckind == PCP_NEQ) chunk_signs<PCP_NEQ, B, PACKED>(o, px, py, dd);
-          else chunk_signs<PCP_LT, B, PACKED>(o, px, py, dd);
+          if (ckind == PCP_NEQ) chunk_signs<PCP_NEQ, B, PACKED, IMPLICIT>(o, px, py, dd);
+          else chunk_signs<PCP_LT, B, PACKED, IMPLICIT>(o, px, py, dd);
 #pragma unroll
           for (int j = 0; j < kChunk; ++j)
             if (__ballot(o[j] < 0) & readlane64(alive4, j)) slow |= 1u << j;
@@ -1030,8 +1168,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
           const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
           const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
           int o;
-          if constexpr (PACKED) o = (ckind == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
-          else o = (ckind == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+          if constexpr (PACKED) o = (ckind == PCP_NEQ) ? fast_signs16<PCP_NEQ, B, IMPLICIT>(px, py, rec.d) : fast_signs16<PCP_LT, B, IMPLICIT>(px, py, rec.d);
+          else o = (ckind == PCP_NEQ) ? fast_signs<PCP_NEQ, B, IMPLICIT>(px, py, rec.d) : fast_signs<PCP_LT, B, IMPLICIT>(px, py, rec.d);
           if (__ballot(o < 0) & readlane64(alive4, j)) slow |= 1u << j;
         }
       }
@@ -1056,8 +1194,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
                 int o;
                 uint64_t tw = 0;
                 if (PCP_ABLATE & 128) tw = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(rec.d) & 0);
-                if constexpr (PACKED) o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B>(px, py, rec.d) : fast_signs16<PCP_LT, B>(px, py, rec.d);
-                else o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B>(px, py, rec.d) : fast_signs<PCP_LT, B>(px, py, rec.d);
+                if constexpr (PACKED) o = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B, IMPLICIT>(px, py, rec.d) : fast_signs16<PCP_LT, B, IMPLICIT>(px, py, rec.d);
+                else o = (kind0 == PCP_NEQ) ? fast_signs<PCP_NEQ, B, IMPLICIT>(px, py, rec.d) : fast_signs<PCP_LT, B, IMPLICIT>(px, py, rec.d);
                 if (PCP_ABLATE & 128) segw += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(o) & 0) - tw;
                 if (__ballot(o < 0) & alive) slow |= 1u << j;
               }
@@ -1094,9 +1232,9 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         const Cell* px = kdom + slot_row<B, PACKED>(rec.xk & kSlotMask);
         const Cell* py = kdom + slot_row<B, PACKED>(rec.y);
         // (for NEQ / LT the hot part has already established that a record live somewhere in the tile is flagged)
-        if (kind0 == PCP_EQ) todo = fast_nodes<PCP_EQ, B, PACKED, NL>(px, py, rec.d, loaded, j);
-        else if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B, PACKED, NL>(px, py, rec.d, loaded, j);
-        else todo = fast_nodes<PCP_LT, B, PACKED, NL>(px, py, rec.d, loaded, j);
+        if (kind0 == PCP_EQ) todo = fast_nodes<PCP_EQ, B, PACKED, NL, IMPLICIT>(px, py, rec.d, loaded, j);
+        else if (kind0 == PCP_NEQ) todo = fast_nodes<PCP_NEQ, B, PACKED, NL, IMPLICIT>(px, py, rec.d, loaded, j);
+        else todo = fast_nodes<PCP_LT, B, PACKED, NL, IMPLICIT>(px, py, rec.d, loaded, j);
       } else {
         const bool tern = kind > PCP_LT;
         for (uint32_t b = 0; b < nb; ++b) {
@@ -1112,9 +1250,21 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         todo &= todo - 1;
         const uint64_t word = word_of(loaded, b, j);
         bool e = false;
-        ctr.add_full_uniform((uint32_t)__popcll(word));
         if (generic) ctr.add_ev_uniform((uint32_t)__popcll(word));  // not counted by a level-1 / level-2 test above
-        if ((word >> lane) & 1ull) {
+        bool run = (word >> lane) & 1ull;
+        if constexpr (IMPLICIT) {
+          // only the lanes on which a domain can narrow (fast_flag); an entailed or untouched record is left alone
+          if (!generic && run) {
+            const auto dmr = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
+            const int2 X = dmr.load(rec.xk & kSlotMask), Y = dmr.load(rec.y);
+            const int Yl = Y.x + rec.d, Yu = Y.y + rec.d;
+            if (kind == PCP_NEQ) run = (X.x == Yu) | (Yl == X.y);
+            else if (kind == PCP_LT) run = (X.y >= Yu) | (Yl <= X.x);
+            else run = (X.x != Yl) | (X.y != Yu);
+          }
+        }
+        ctr.add_full_uniform((uint32_t)__popcll(__ballot(run)));
+        if (run) {
           const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
           e = eval_record(rec, dm);
         }
@@ -1129,7 +1279,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
     const uint32_t wl = c * kChunk + jq;
 #pragma unroll
     for (int h = 0; h < NL; ++h) {
-      if (io[h] && wl < w1) {
+      if (!IMPLICIT && io[h] && wl < w1) {
         rem_acc[h] += post_a ? (uint32_t)(__popcll(loaded[h]) - __popcll(my_new[h])) : (uint32_t)__popcll(my_new[h]);
         if (!(PCP_ABLATE & 8) && (live_src != a.live || my_new[h] != loaded[h])) my_out[h][wl] = my_new[h];
       }
@@ -1146,7 +1296,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
   }
 #pragma unroll
   for (int h = 0; h < NL; ++h)
-    if (io[h] && rem_acc[h]) { if (post_a) atomicSub(&remaining[bq + 16u * h], rem_acc[h]); else atomicAdd(&remaining[bq + 16u * h], rem_acc[h]); }
+    if (!IMPLICIT && io[h] && rem_acc[h]) { if (post_a) atomicSub(&remaining[bq + 16u * h], rem_acc[h]); else atomicAdd(&remaining[bq + 16u * h], rem_acc[h]); }
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
   if ((PCP_ABLATE & 128) && lane == 0) {  // profiling build: per-segment ticks summed over all wavefronts
@@ -1174,7 +1324,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 // Returns false when phase A noted more than an eighth of the words (a tile deep in the search tree: many assigned
 // variables, whose words no range test clears): the caller then runs the chunked record-level sweep over the noted
 // words instead of phase B, which is organised for a few words.
-template <int B, bool COMPACT>
+template <int B, bool COMPACT, bool IMPLICIT>
 __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
                                             uint32_t* remaining, uint32_t* hardmap, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane; a node column fits one DPP row");
@@ -1211,13 +1361,17 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     const bool wv = w < words;
     const uint32_t wc = min(w, words - 1);
     const WordPart qa = qa_next;
-    uint64_t lv[B];
+    uint64_t lv[IMPLICIT ? 1 : B];
+    if constexpr (IMPLICIT) {
+      lv[0] = wv ? (wc == words - 1 ? tail_mask : ~0ull) : 0ull;  // every node: all records live
+    } else {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      const uint32_t node = node0 + ((uint32_t)b < nb ? (uint32_t)b : 0u);
-      uint64_t v = live_src ? live_src[(size_t)node * words + wc] : ~0ull;
-      if (wc == words - 1) v &= tail_mask;
-      lv[b] = (wv && (uint32_t)b < nb) ? v : 0ull;
+      for (int b = 0; b < B; ++b) {
+        const uint32_t node = node0 + ((uint32_t)b < nb ? (uint32_t)b : 0u);
+        uint64_t v = live_src ? live_src[(size_t)node * words + wc] : ~0ull;
+        if (wc == words - 1) v &= tail_mask;
+        lv[b] = (wv && (uint32_t)b < nb) ? v : 0ull;
+      }
     }
     qa_next = a.m.wdesc[min((g + nw) * 64 + lane, words - 1)].a;
     // level -1: the whole word against the range tables
@@ -1228,6 +1382,21 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       const uint32_t ya = __umul24(ky, S) + (q.y & 0xffffu), yb = __umul24(ky, S) + (q.y >> 16);
       const uint32_t Xn = pk_min(tmin[xa], tmin[xb]), Yn = pk_min(tmin[ya], tmin[yb]);  // (min -lb, min ub) over the range
       const int dmin = lo16(q.d), dmax = hi16(q.d);
+      if constexpr (IMPLICIT) {
+        // no record of the word can narrow in any node (neq_no_zero / the XLessY narrowing terms); with the maximum tables
+        // (word_level 2) this also clears words that are entailed throughout the tile
+        if (cls == 1 && a.word_level >= 2) {
+          const uint32_t Xx = pk_max(tmax[xa], tmax[xb]), Yx = pk_max(tmax[ya], tmax[yb]);
+          uint32_t tlo, thi;
+          asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tlo) : "v"(Xn), "v"(Yn));
+          asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(thi) : "v"(Xx), "v"(Yx));
+          return neq_no_zero(tlo, thi, dmin, dmax) < 0;
+        }
+        if (cls == 2 && a.word_level >= 2) {
+          const uint32_t Xx = pk_max(tmax[xa], tmax[xb]), Yx = pk_max(tmax[ya], tmax[yb]);
+          return ((hi16(Yn) - hi16(Xx) + dmin - 1) | (lo16(Xn) - lo16(Yx) + dmin - 1)) < 0;
+        }
+      }
       if (cls == 1) {
         uint32_t t;
         asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(Xn), "v"(Yn));  // (Xn + Yu, Xu + Yn)
@@ -1242,13 +1411,18 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     bool fail = part_fails(qa);
     if (!fail && ((qa.k >> 12) & 1u)) fail = part_fails(a.m.wdesc[wc].b);  // a word that straddles two x-blocks
     uint64_t alive = 0;
+    if constexpr (IMPLICIT) {
+      alive = lv[0];
+      steps_lane += nb * (uint32_t)__popcll(lv[0]);  // every record of every node runs once
+    } else {
 #pragma unroll
-    for (int b = 0; b < B; ++b) {
-      alive |= lv[b];
-      const uint32_t pc = (uint32_t)__popcll(lv[b]);
-      steps_lane += pc;                    // every live record of every node runs once
-      racc[b / 2] += pc << (16 * (b & 1));
-      if (wv && (uint32_t)b < nb && live_src != a.live) a.live[(size_t)(node0 + b) * words + w] = lv[b];
+      for (int b = 0; b < B; ++b) {
+        alive |= lv[b];
+        const uint32_t pc = (uint32_t)__popcll(lv[b]);
+        steps_lane += pc;                    // every live record of every node runs once
+        racc[b / 2] += pc << (16 * (b & 1));
+        if (wv && (uint32_t)b < nb && live_src != a.live) a.live[(size_t)(node0 + b) * words + w] = lv[b];
+      }
     }
     uint64_t hard = __ballot(alive != 0 && (fail || failm != 0));
     if (PCP_ABLATE & 16) hard = 0;
@@ -1258,11 +1432,13 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     if (lane == 0) hard64[g] = hard;
   }
   if (lane == 0 && n_hard) atomicAdd(&k.misc[M_HARD], n_hard);
+  if constexpr (!IMPLICIT) {
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
-    for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
-    if (lane == 0 && (uint32_t)b < nb && r) atomicAdd(&remaining[b], r);
+    for (int b = 0; b < B; ++b) {
+      uint32_t r = (racc[b / 2] >> (16 * (b & 1))) & 0xffffu;
+      for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o);
+      if (lane == 0 && (uint32_t)b < nb && r) atomicAdd(&remaining[b], r);
+    }
   }
   for (int o = 32; o > 0; o >>= 1) steps_lane += __shfl_down(steps_lane, o);
   steps2 += __builtin_amdgcn_readfirstlane(steps_lane);
@@ -1276,7 +1452,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
   constexpr int kBatch = 4;
   uint32_t pend[kBatch];
   uint32_t npend = 0;
-  uint64_t* const my_live = a.live + (size_t)(node0 + (lane < nb ? lane : 0u)) * words;  // lane b = node b: the word's column
+  uint64_t* const my_live = IMPLICIT ? nullptr : a.live + (size_t)(node0 + (lane < nb ? lane : 0u)) * words;  // lane b = node b: the word's column
   uint64_t tfl[2] = {0, 0};  // PCP_ABLATE & 128: ticks waiting for a batch's loads / processing it
   auto flush = [&]() {
     const uint64_t tf0 = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
@@ -1286,7 +1462,8 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     for (int t = 0; t < kBatch; ++t) {
       const uint32_t ww = pend[(uint32_t)t < npend ? t : 0];
       rb[t] = (rec_stream + (size_t)ww * 64)[lane];
-      const uint64_t v = __hip_atomic_load(my_live + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: phase A stored it
+      uint64_t v = ~0ull;
+      if constexpr (!IMPLICIT) v = __hip_atomic_load(my_live + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: phase A stored it
       cb[t] = lane < nb ? (ww == words - 1 ? v & tail_mask : v) : 0ull;
     }
     uint64_t tf1 = 0;
@@ -1317,12 +1494,23 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       if ((PCP_ABLATE & 8192) && (alive_w | failnow | kind0 | (uint64_t)(size_t)px | (uint64_t)(size_t)py) != 0x123456789ull) continue;  // profiling: preamble only
       uint32_t todo = 0;
       uint64_t ncol = col;
-      if (__all(kind == kind0) && kind0 <= PCP_LT && failnow == 0) {
+      const bool tested = __all(kind == kind0) && kind0 <= PCP_LT && failnow == 0;
+      if (tested) {
         bool run2 = true;
         if (kind0 != PCP_EQ) {
           // level 0 on the per-slot summaries, then level 1 on every node
           int o0;
-          {
+          if constexpr (IMPLICIT) {
+            const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y], xx = tmax[rec.xk & kSlotMask], yx = tmax[rec.y];
+            if (kind0 == PCP_NEQ) {
+              uint32_t tlo, thi;
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tlo) : "v"(xs), "v"(ys));
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(thi) : "v"(xx), "v"(yx));
+              o0 = neq_no_zero(tlo, thi, rec.d, rec.d);
+            } else {
+              o0 = (hi16(ys) - hi16(xx) + rec.d - 1) | (lo16(xs) - lo16(yx) + rec.d - 1);
+            }
+          } else {
             const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y];
             if (kind0 == PCP_NEQ) {
               uint32_t t2;
@@ -1349,6 +1537,8 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
             const int dc = max(-32767, min(32767, rec.d));
             const uint32_t c1 = ((uint32_t)(dc - 1) & 0xffffu) | ((uint32_t)(-dc - 1) << 16);
             const uint32_t c0 = ((uint32_t)dc & 0xffffu) | ((uint32_t)(-dc) << 16);
+            const uint32_t cz = c0;  // IMPLICIT: (d, -d)
+            (void)c1; (void)cz;
 #pragma unroll
             for (int g4 = 0; g4 < B; g4 += 4) {
               const uint4 Xq = *static_cast<const uint4*>(__builtin_assume_aligned(px + g4, 16));
@@ -1359,6 +1549,16 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
                 const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
                 if (wd == 0) continue;
                 ctr.add_ev_uniform((uint32_t)__popcll(wd));
+                if constexpr (IMPLICIT) {
+                  // (t1, t2) = X + swap(Y) + (d, -d): a lane can narrow only where one of them is zero
+                  uint32_t Uz;
+                  asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+                      "v_pk_add_u16 %0, %0, %3"
+                      : "=&v"(Uz) : "v"(xs[jj]), "v"(ys[jj]), "v"(cz));
+                  const uint64_t f = __ballot((Uz & 0xffffu) == 0u || (Uz >> 16) == 0u) & wd;
+                  todo |= f ? (1u << (g4 + jj)) : 0u;
+                  continue;
+                }
                 uint32_t F, E;
                 asm("v_pk_add_u16 %0, %2, %3 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
                     "v_pk_add_i16 %1, %0, %5 clamp\n\t"
@@ -1382,9 +1582,9 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
                 if (wd == 0) continue;
                 ctr.add_ev_uniform((uint32_t)__popcll(wd));
                 const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
-                uint64_t f, en;
-                if (kind0 == PCP_LT) { f = fast_flag<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); en = pure_entailed<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); }
-                else { f = fast_flag<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d); en = pure_entailed<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d); }
+                uint64_t f, en = 0;
+                if (kind0 == PCP_LT) { f = fast_flag<PCP_LT, IMPLICIT>(X, Y.x + rec.d, Y.y + rec.d); if (!IMPLICIT) en = pure_entailed<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); }
+                else { f = fast_flag<PCP_EQ, IMPLICIT>(X, Y.x + rec.d, Y.y + rec.d); if (!IMPLICIT) en = pure_entailed<PCP_EQ>(X, Y.x + rec.d, Y.y + rec.d); }
                 en &= wd;
                 if (en) { ncol = writelane64(ncol, wd & ~en, (uint32_t)(g4 + jj)); if (PCP_ABLATE & 128) ++n_bulk; }
                 todo |= (f & wd & ~en) ? (1u << (g4 + jj)) : 0u;
@@ -1402,15 +1602,26 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
         const uint32_t b = __builtin_ctz(todo);
         todo &= todo - 1;
         const uint64_t word = readlane64(ncol, b);  // without the lanes already unlinked in bulk
-        ctr.add_full_uniform((uint32_t)__popcll(word));
         bool e = false;
-        if ((word >> lane) & 1ull) {
+        bool run = (word >> lane) & 1ull;
+        if constexpr (IMPLICIT) {
+          if (tested && run) {  // only the lanes on which a domain can narrow (fast_flag)
+            const auto dmr = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
+            const int2 X = dmr.load(rec.xk & kSlotMask), Y = dmr.load(rec.y);
+            const int Yl = Y.x + rec.d, Yu = Y.y + rec.d;
+            if (kind0 == PCP_NEQ) run = (X.x == Yu) | (Yl == X.y);
+            else if (kind0 == PCP_LT) run = (X.y >= Yu) | (Yl <= X.x);
+            else run = (X.x != Yl) | (X.y != Yu);
+          }
+        }
+        ctr.add_full_uniform((uint32_t)__popcll(__ballot(run)));
+        if (run) {
           const auto dm = make_dom<GLOBAL, PACKED>(k, b, chg_next, &ctr);
           e = eval_record(rec, dm);
         }
         ncol = writelane64(ncol, word & ~__ballot(e), b);
       }
-      if (lane < nb && ncol != col) {  // entailed records: unlink them (store.rs:200-207)
+      if (!IMPLICIT && lane < nb && ncol != col) {  // entailed records: unlink them (store.rs:200-207)
         my_live[ww] = ncol;
         atomicSub(&remaining[lane], (uint32_t)(__popcll(col) - __popcll(ncol)));
       }
@@ -1453,7 +1664,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
 
 // Dense wake-up round: more changed variables than the LDS list holds, so stream the whole table again and run
 // the live records that touch a variable in `cur`.  Rare path, generic code.
-template <bool GLOBAL, bool PACKED>
+template <bool GLOBAL, bool PACKED, bool IMPLICIT>
 __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, const uint32_t* cur,
                                                uint32_t* chg_next, uint32_t& rem_sub, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
   const uint32_t lane = threadIdx.x & 63, nw = blockDim.x >> 6;
@@ -1465,7 +1676,10 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
     if (r < P) rec = a.m.recs[r];
     else { rec.xk = 0; rec.y = 0; rec.z = 0; rec.d = 0; }
     uint64_t my_word = 0;
-    if (lane < nb) my_word = a.live[(size_t)(node0 + lane) * words + w];
+    if (lane < nb) {
+      if constexpr (IMPLICIT) my_word = (w == words - 1 && (P & 63)) ? ((1ull << (P & 63)) - 1) : ~0ull;
+      else my_word = a.live[(size_t)(node0 + lane) * words + w];
+    }
     uint64_t my_new = my_word;
     const uint32_t failm = __hip_atomic_load(&k.misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t x = rec.xk & kSlotMask;
@@ -1489,7 +1703,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
       ctr.add_full_uniform((uint32_t)__popcll(run));
       my_new = writelane64(my_new, word & ~__ballot(e), b);
     }
-    if (lane < nb && my_new != my_word) {
+    if (!IMPLICIT && lane < nb && my_new != my_word) {
       rem_sub += __popcll(my_word) - __popcll(my_new);  // newly entailed
       a.live[(size_t)(node0 + lane) * words + w] = my_new;
     }
@@ -1499,7 +1713,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 // ------------------------------------------------------------------------------------------------
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
-template <int B, bool GLOBAL, bool COMPACT, bool PACKED>
+template <int B, bool GLOBAL, bool COMPACT, bool PACKED, bool IMPLICIT>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   static_assert(!GLOBAL || B == 1, "the global-domain variant runs one node per block");
   static_assert(!PACKED || (!GLOBAL && B >= 8 && B % 4 == 0), "packed tiles: LDS-resident, a multiple of four nodes");
@@ -1643,11 +1857,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if constexpr (PACKED && B <= 16) {
       if (a.word_level) {  // team == 1 here
         swept = true;
-        if (!sweep_words<B, COMPACT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr))
-          sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr, reinterpret_cast<const uint64_t*>(list_id));
+        if (!sweep_words<B, COMPACT, IMPLICIT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr))
+          sweep_fast<B, GLOBAL, COMPACT, PACKED, IMPLICIT>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr, reinterpret_cast<const uint64_t*>(list_id));
       }
     }
-    if (!swept && w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
+    if (!swept && w0 < w1) sweep_fast<B, GLOBAL, COMPACT, PACKED, IMPLICIT>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr);  // w0 is chunk-aligned unless the slice is empty
   }
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
@@ -1776,7 +1990,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
       // lower-numbered changed variable of the same record will run it (RelaxedFifo dedup, relaxed_fifo.rs:42-48).
       auto run_item = [&](uint32_t b, uint32_t v, uint32_t r, uint32_t lbits, const Rec rec) {
         const uint32_t bit = 1u << (r & 31);
-        if (!(lbits & bit)) return;  // unlinked (store.rs:200-207)
+        if (!IMPLICIT && !(lbits & bit)) return;  // unlinked (store.rs:200-207)
         const uint32_t* cb = cur + (size_t)b * Wv;
         const uint32_t x = rec.xk & kSlotMask;
         const bool tern = (rec.xk >> 28) > PCP_LT;
@@ -1785,10 +1999,13 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
         const auto dm = make_dom<GLOBAL, PACKED>(k, b, nxt, &ctr);
         if (tern) ++my3; else ++my2;
-        if (eval_record(rec, dm)) {
-          uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
-          const uint32_t old = atomicAnd(lw, ~bit);
-          if (old & bit) atomicSub(&remaining[b], 1u);
+        const bool entailed = eval_record(rec, dm);
+        if constexpr (!IMPLICIT) {
+          if (entailed) {
+            uint32_t* lw = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + b) * words) + (r >> 5);
+            const uint32_t old = atomicAnd(lw, ~bit);
+            if (old & bit) atomicSub(&remaining[b], 1u);
+          }
         }
       };
       if (T >= 32u * total) {
@@ -1807,7 +2024,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           const uint32_t id = list_id[e], b = id >> 26, v = id & ((1u << 26) - 1);
           const uint32_t deg = list_pre[e + 1] - list_pre[e];
           const uint32_t* ap = a.m.adj + a.m.adj_off[v];
-          const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
+          const uint32_t* lrow = IMPLICIT ? nullptr : reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
           for (uint32_t k0 = whole ? 0u : wv * 64 * U; k0 < deg; k0 += (whole ? 1u : nwv) * 64 * U) {
             uint32_t r[U], lb_[U];
             Rec rc[U];
@@ -1833,11 +2050,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
                 rc[u].d = (int32_t)q.y;
               }
 #pragma unroll
-              for (int u = 0; u < U; ++u) lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              for (int u = 0; u < U; ++u) lb_[u] = IMPLICIT ? ~0u : __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                lb_[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                lb_[u] = IMPLICIT ? ~0u : __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 rc[u] = a.m.recs[r[u]];
               }
             }
@@ -1855,8 +2072,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
           const uint32_t ai = a.m.adj_off[v] + (i - list_pre[lo]);
           const uint32_t r = a.m.adj[ai];
-          const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
-          const uint32_t lbits = __hip_atomic_load(lrow + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          uint32_t lbits = ~0u;
+          if constexpr (!IMPLICIT) {
+            const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
+            lbits = __hip_atomic_load(lrow + (r >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           Rec rec;
           if (a.m.adjp) {
             const uint2 q = a.m.adjp[ai];
@@ -1877,7 +2097,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     } else {
       __syncthreads();
       uint32_t rem_sub = 0;
-      sweep_filtered<GLOBAL, PACKED>(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
+      sweep_filtered<GLOBAL, PACKED, IMPLICIT>(a, k, node0, nb, cur, nxt, rem_sub, steps2, steps3, ctr);
       if (lane < nb && rem_sub) atomicSub(&remaining[lane], rem_sub);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1886,6 +2106,35 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     uint32_t* t = cur; cur = nxt; nxt = t;
     if (tid == 0) { misc[M_WAVES] += __popc(misc[M_ROUNDMASK]); misc[M_ROUNDMASK] = 0; }
     __syncthreads();
+  }
+
+  // ---- phase 3b (implicit `active`): is anything NOT entailed under the final domains? -------------------------
+  // Consistency::consistency returns True iff no subscription remains (store.rs:250-256), i.e. iff every propagator is
+  // entailed under the final domains (A.4).  At the fixpoint every filter is a no-op, so eval_record only reports
+  // is_subsumed(); the scan stops as soon as every node of the tile has shown one propagator that is not entailed —
+  // for an Unknown node that is its first or second word.
+  if constexpr (IMPLICIT) {
+    __syncthreads();
+    const uint32_t wv3 = __builtin_amdgcn_readfirstlane(tid >> 6), nwv3 = nth >> 6;
+    const uint32_t want = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~misc[M_FAIL];
+    for (uint32_t w = wv3; w < words; w += nwv3) {
+      uint32_t have = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[M_UNK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if ((have & want) == want) break;
+      const uint32_t r = (w << 6) + lane;
+      const bool valid = r < P;
+      const Rec rec = a.m.recs[valid ? r : P - 1];
+      uint32_t todo = want & ~have;
+      while (todo) {
+        const uint32_t b = __builtin_ctz(todo);
+        todo &= todo - 1;
+        bool open_rec = false;
+        if (valid) {
+          const auto dm = make_dom<GLOBAL, PACKED>(k, b, nxt, &ctr);
+          open_rec = !eval_record(rec, dm);
+        }
+        if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[M_UNK], 1u << b);
+      }
+    }
   }
 
   // ---- phase 4: write back domains, status, counters ---------------------------------------------------
@@ -1934,7 +2183,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     const bool failed = (misc[M_FAIL] >> tid) & 1u;
     // Consistency::consistency (store.rs:250-256): False if a propagate failed, True if no subscription
     // remains (every live propagator got entailed), else Unknown.
-    a.status[node0 + tid] = failed ? (uint8_t)PCP_FALSE : (remaining[tid] == 0 ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
+    const bool none_open = IMPLICIT ? !((misc[M_UNK] >> tid) & 1u) : remaining[tid] == 0;
+    a.status[node0 + tid] = failed ? (uint8_t)PCP_FALSE : (none_open ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
   }
   if (tid == 0) {
     unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);
@@ -1962,6 +2212,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   }
 }
 
+#if PCP_TU == 0
 // ------------------------------------------------------------------------------------------------
 // Conjunction / Distinct units (logic/conjunction.rs:77-119, propagators/distinct.rs:63-126).  The reference keeps
 // ONE active bit for the whole conjunction: it is entailed iff every member is (conjunction.rs:78-94), and a pop
@@ -2013,6 +2264,49 @@ __global__ void __launch_bounds__(256) contract_units_kernel(const uint32_t* __r
     const uint64_t word = __ballot(on);
     if (lane == 0) active_out[(size_t)node * unit_words + uw] = word;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// `active` rows on request for implicit-active nodes: bit r = record r is NOT entailed under the node's final domains
+// (a propagator is inactive iff it is entailed under the final domains).  At a fixpoint every filter is a
+// no-op, so eval_record over a read-only view of the final bounds only reports is_subsumed().
+// ------------------------------------------------------------------------------------------------
+struct ConstDom {
+  const int32_t* lb;
+  const int32_t* ub;
+  const int32_t* cval;
+  uint32_t n_vars;
+  __device__ __forceinline__ int2 load(uint32_t v) const {
+    if (v >= n_vars) { const int c = cval[v - n_vars]; return make_int2(c, c); }
+    return make_int2(lb[v], ub[v]);
+  }
+  __device__ __forceinline__ void raise_lb(uint32_t, int) const {}
+  __device__ __forceinline__ void lower_ub(uint32_t, int) const {}
+  __device__ __forceinline__ void set_fail() const {}
+};
+__global__ void __launch_bounds__(256) derive_active_kernel(const ModelDev m, const int32_t* __restrict__ lb, const int32_t* __restrict__ ub,
+                                                            uint64_t* __restrict__ live, uint32_t n_nodes) {
+  const uint32_t words = (m.n_recs + 63) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (uint64_t i = wave; i < (uint64_t)n_nodes * words; i += nwaves) {
+    const uint32_t node = (uint32_t)(i / words), w = (uint32_t)(i % words);
+    const uint32_t r = (w << 6) + lane;
+    bool on = false;
+    if (r < m.n_recs) {
+      const ConstDom dm{lb + (size_t)node * m.n_vars, ub + (size_t)node * m.n_vars, m.const_val, m.n_vars};
+      on = !eval_record(m.recs[r], dm);
+    }
+    const uint64_t word = __ballot(on);
+    if (lane == 0) live[(size_t)node * words + w] = word;
+  }
+}
+hipError_t launch_derive_active(const ModelDev& m, const int32_t* lb, const int32_t* ub, uint64_t* live, uint32_t n_nodes, hipStream_t stream) {
+  const uint64_t items = (uint64_t)n_nodes * ((m.n_recs + 63) >> 6);
+  if (items == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (items + 3) / 4), 16384);
+  hipLaunchKernelGGL(derive_active_kernel, dim3(grid), dim3(256), 0, stream, m, lb, ub, live, n_nodes);
+  return hipGetLastError();
 }
 
 hipError_t launch_expand_units(const uint32_t* rec_unit, uint32_t n_recs, uint32_t unit_words, const uint64_t* active_in, uint64_t* live,
@@ -2118,13 +2412,16 @@ hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, cons
   return hipGetLastError();
 }
 
+#endif  // PCP_TU == 0
+
 template <int B, bool GLOBAL, bool COMPACT, bool PACKED = false>
 static hipError_t launch_k(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  constexpr bool IMPLICIT = PCP_TU == 1;
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL, COMPACT, PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fixpoint_kernel<B, GLOBAL, COMPACT, PACKED, IMPLICIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL, COMPACT, PACKED>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((fixpoint_kernel<B, GLOBAL, COMPACT, PACKED, IMPLICIT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 template <int B>
@@ -2133,8 +2430,16 @@ static hipError_t launch_b(const LaunchArgs& a, const LaunchPlan& p, hipStream_t
 }
 
 // nodes_per_block must be one of the instantiated tile sizes; global_dom selects the HBM-resident-domain variant,
-// packed the 16-bit tiles (compact record stream only).
+// packed the 16-bit tiles (compact record stream only).  This translation unit serves a.live != nullptr (PCP_TU == 0:
+// explicit `active` rows) or a.live == nullptr (PCP_TU == 1: implicit).
+#if PCP_TU == 0
+hipError_t launch_fixpoint_implicit(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (a.live == nullptr) return launch_fixpoint_implicit(a, p, stream);
+#else
+hipError_t launch_fixpoint_implicit(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (a.live != nullptr) return hipErrorInvalidValue;
+#endif
   if (a.global_dom) return a.nodes_per_block == 1 ? launch_k<1, true, false>(a, p, stream) : hipErrorInvalidValue;
   if (a.packed) {
     if (!a.m.recs8) return hipErrorInvalidValue;

@@ -247,7 +247,7 @@ def balance_stacks(stack, dist) -> int:
     return delta
 
 
-def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4):
+def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None):
     """Sharded subtree search with device-resident stacks: ``search`` is a pcp_amd.search_device.DeviceSearch of this
     rank's GPU.  Rank 0 starts with the root; every ``rounds_per_exchange`` rounds the stacks are balanced GPU-to-GPU
     (X1+X2) and termination / totals agreed on (X3).  Returns the global (nodes, solutions, failures, filter steps)."""
@@ -257,17 +257,28 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
     search.reset(lb0, ub0)
     if rank != 0:
         search.size = 0
+    import time
     moved = 0
+    exchange_s, exchanges = 0.0, 0
+    world = dist.get_world_size()
     while True:
         if search.size > 0:
-            search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0)
+            # a rank's share of what is left of the node budget (the budget is global; it is checked at every exchange)
+            left = max(1, (node_limit - search.stats.num_nodes * world) // world) if node_limit else 0
+            search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0,
+                           node_limit=(search.stats.num_nodes + left) if node_limit else 0)
+        t0 = time.perf_counter()
         moved += max(balance_stacks(search, dist), 0)
         st = search.stats
         flags = torch.tensor([search.size, st.num_solution, st.num_nodes], dtype=torch.int64, device=dev)
         dist.all_reduce(flags, op=dist.ReduceOp.SUM)
         open_total, sol_total, nodes_total = (int(x) for x in flags.tolist())
+        exchange_s += time.perf_counter() - t0
+        exchanges += 1
         if open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit):
             break
+    if info is not None:
+        info.update(exchange_s=exchange_s, exchanges=exchanges)
     st = search.stats
     tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, moved], dtype=torch.int64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)

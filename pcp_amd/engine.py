@@ -188,6 +188,26 @@ class Context:
                                           C.byref(st) if want_stats else None))
         return lb, ub, active, status, st.as_dict()
 
+    def propagate_implicit(self, lb, ub, want_active: bool = True, in_place: bool = True):
+        """Implicit-active nodes through the device-resident entry: active_in = NULL (every unit active, liveness derived
+        from the domains), `active` materialised on request only.  Returns (lb, ub, active or None, status, stats)."""
+        import torch
+        lb = np.array(lb, dtype=np.int32, order="C")
+        n = lb.shape[0] if lb.ndim == 2 else 1
+        lb = lb.reshape(n, self.n_vars)
+        ub = np.array(ub, dtype=np.int32, order="C").reshape(n, self.n_vars)
+        dev = torch.device("cuda", self.device)
+        t_lb, t_ub = torch.from_numpy(lb).to(dev), torch.from_numpy(ub).to(dev)
+        o_lb, o_ub = (t_lb, t_ub) if in_place else (torch.empty_like(t_lb), torch.empty_like(t_ub))
+        t_act = torch.zeros((n, max(self.words, 1)), dtype=torch.int64, device=dev) if want_active else None
+        t_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        before = self.stats_read(stream)
+        self.propagate_device(n, t_lb, t_ub, o_lb, o_ub, None, t_act, t_st, stream)
+        after = self.stats_read(stream)
+        act = t_act.cpu().numpy().view(np.uint64)[:, : self.words] if want_active else None
+        return o_lb.cpu().numpy(), o_ub.cpu().numpy(), act, t_st.cpu().numpy(), {k: after[k] - before[k] for k in after}
+
     # ---- propagation, device-resident (pcp_propagate_device) ------------------------------------------------
     def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0):
         """All arguments are torch tensors on this context's device (or None for the optional masks); nothing is

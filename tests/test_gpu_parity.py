@@ -36,6 +36,12 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
         ctx.set_option(k, v)
     got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
     assert_parity(ref[:4], got[:4], what)
+    # the same nodes as IMPLICIT-active nodes (domains only, every unit active on entry, liveness derived from the domains;
+    # `active` rows materialised on request) under the same launch options
+    ref_i = ref if active is None else om.consistency(lb, ub, None)
+    got_i = ctx.propagate_implicit(lb, ub)
+    assert ctx.last_plan()["implicit_active"] == 1
+    assert_parity(ref_i[:4], got_i[:4], what + " [implicit]")
     return ref, got
 
 

@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/ablate
 for ab in ${ABS:-0 1 2 3 8 16 32 48}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DPCP_ABLATE=$ab pcp_amd/csrc/pcp_api.hip pcp_amd/csrc/pcp_kernels.hip -o gpurun_out/ablate/lib$ab.so 2>/dev/null
+  python tools/build_variant.py $ab gpurun_out/ablate/lib$ab.so 2>/dev/null
 done
 # the frontier is generated with the real library first and cached by bench.py? no: each run regenerates it with the ablated
 # kernel, so only compare kernel_ms (the ablated statuses are meaningless).

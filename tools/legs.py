@@ -1,0 +1,13 @@
+#!/usr/bin/env python
+"""One line per leg of a bench.py JSON line.  usage: python tools/legs.py < bench.json"""
+import json, sys
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+c = d["config"]
+print(f"headline: value={d['value']:.3e} steps/s  ms/step={d['ms_per_step']:.3f}  kernel_ms={c['kernel_ms_per_launch']}  evaluated/s={c['steps_evaluated_per_s']:.3e}  full/s={c['full_filter_evals_per_s']:.3e}  "
+      f"hbm_frac={d['roofline']['frac']:.3f}  eval/step={c['evaluated_per_step_per_gpu']:.3e} full/step={c['full_evals_per_step_per_gpu']:.3e} parity_nodes={c.get('parity_checked_nodes')}")
+for l in c.get("legs", []):
+    if "kernel_ms" in l:
+        print(f"{l['name']:45s} nodes={l['nodes']:6d} ms={l['kernel_ms']['median']:9.3f} steps/s={l['steps_per_s']:.3e} eval/s={l['evaluated_per_s']:.3e} eval={l['evaluated_per_launch']:.3e} full={l['full_evals_per_launch']:.3e} "
+              f"narrow={l['narrowings_per_launch']:.0f} waves/node={l['waves_per_node']:.2f} hbm_frac={l['hbm_frac']:.4f} status={l['status_false_true_unknown']} B={l['plan']['nodes_per_block']} wl={l['plan'].get('word_level')}")
+    else:
+        print(f"{l['name']:45s} nodes={l['nodes']:6d} us/node={l['us_per_node']:.1f} steps/s={l['steps_per_s']:.3e} kernel_us={l['last_kernel_us']:.1f} team={l['plan']['team']}")

@@ -1,32 +1,42 @@
 #!/usr/bin/env python
-"""Per-tile time of the sweep vs the wake-up rounds, from a -DPCP_ABLATE=64 profiling build (which reports the phase
-timers in the steps3 / narrowings counters).  usage: PCP_HIP_LIB=/tmp/lib64.so python tools/phase_times.py"""
+"""Per-tile time of staging / sweep / wake-up rounds, from -DPCP_ABLATE=64 and =320 profiling builds (which report the phase
+timers in the counters).  usage: PCP_HIP_LIB=.../lib64.so [PCP_ACTIVE=explicit] python tools/phase_times.py [nodes]
+Regimes: the bench frontier (near the root), and the deep end of the stack after 500 / 3000-node depth-first dives."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pcp_amd.engine as E
 from pcp_amd import model as M
-from pcp_amd.search_device import DeviceSearch
+from pcp_amd import workloads as W
 
-n = 1000; batch = 4096
-ctx = E.Context(0); ctx.set_model(n, M.nqueens_props(n))
+n = 1000; nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+implicit = os.environ.get("PCP_ACTIVE", "implicit") == "implicit"
+mode320 = "320" in os.environ.get("PCP_HIP_LIB", "")
+ctx = E.Context(0); ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
 if os.environ.get('PCP_WORD_LEVEL'): ctx.set_option('word_level', int(os.environ['PCP_WORD_LEVEL'])); print('word_level', os.environ['PCP_WORD_LEVEL'])
-ds = DeviceSearch(ctx, batch=batch, capacity=24 * batch)
+dev = torch.device("cuda:0")
 for D in (0, 500, 3000):
-    ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
-    if D:
-        ds.advance(max_rounds=D, batch=1)
-    ds.advance(max_rounds=14, batch=batch)
-    lb, ub, act = (t.clone() for t in ds.top(batch))
+    ctx.set_option("nodes_per_block", 0)
+    if D == 0:
+        L, U, A = W.nqueens_frontier(ctx, n, nodes, 0, 8, implicit=implicit)
+        lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+        act = None if A is None else torch.from_numpy(A.view(np.int64)).to(dev)
+    else:
+        lb, ub, act = W.nqueens_deep(ctx, n, D, nodes, implicit=implicit)
     N = lb.shape[0]
-    lbo, ubo, acto = torch.empty_like(lb), torch.empty_like(ub), torch.empty_like(act)
-    status = torch.zeros(N, dtype=torch.uint8, device=lb.device)
+    ctx.set_option("nodes_per_block", 16)
+    status = torch.zeros(N, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    ctx.propagate_device(N, lb, ub, lbo, ubo, act, acto, status, stream)
-    ctx.stats_reset(stream)
-    ctx.propagate_device(N, lb, ub, lbo, ubo, act, acto, status, stream)
-    s = ctx.stats_read(stream)
-    tiles = N / 16
-    print("dive %d: kernel %.3f ms; per tile: sweep avg %.1f us max %.1f us, rounds+tail avg %.1f us max %.1f us" %
-          (D, ctx.last_kernel_ms(), s["steps3"] / tiles / 100, s["failed_nodes"] / 100, s["narrowings"] / tiles / 100, s["waves"] / 100))
+    for _ in range(2):
+        l2, u2, a2 = lb.clone(), ub.clone(), None if act is None else act.clone()
+        ctx.stats_reset(stream)
+        ctx.propagate_device(N, l2, u2, l2, u2, a2, a2, status, stream)
+        s = ctx.stats_read(stream)
+    tiles = (N + 15) // 16
+    if mode320:
+        print("dive %d (%s): kernel %.3f ms, %d tiles; per tile: staging avg %.1f us, sweep avg %.1f us, rounds+tail avg %.1f us, whole block avg %.1f us" %
+              (D, "implicit" if implicit else "explicit", ctx.last_kernel_ms(), tiles, s["failed_nodes"] / tiles / 100, s["steps3"] / tiles / 100, s["narrowings"] / tiles / 100, (s["nodes"] - N) / tiles / 100))
+    else:
+        print("dive %d (%s): kernel %.3f ms, %d tiles; per tile: sweep avg %.1f us max %.1f us, rounds+tail avg %.1f us max %.1f us" %
+              (D, "implicit" if implicit else "explicit", ctx.last_kernel_ms(), tiles, s["steps3"] / tiles / 100, s["failed_nodes"] / 100, s["narrowings"] / tiles / 100, s["waves"] / 100))

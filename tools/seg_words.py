@@ -6,16 +6,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import pcp_amd.engine as E
 from pcp_amd import model as M
-from pcp_amd.search import bfs_frontier
+from pcp_amd import workloads as W
 n, N = 1000, 4096
+implicit = os.environ.get("PCP_ACTIVE", "implicit") == "implicit"
 ctx = E.Context(0); ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
-L, U, A, _ = bfs_frontier(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), N)
+L, U, A = W.nqueens_frontier(ctx, n, N, 0, 8, implicit=implicit)
 dev = torch.device("cuda:0"); stream = torch.cuda.current_stream().cuda_stream
 lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
-act = torch.from_numpy(A.view(np.int64)).to(dev)
+act = None if A is None else torch.from_numpy(A.view(np.int64)).to(dev)
 status = torch.zeros(N, dtype=torch.uint8, device=dev)
+ctx.set_option("nodes_per_block", 16)
 for _ in range(2):
-    l2, u2, a2 = lb.clone(), ub.clone(), act.clone()
+    l2, u2, a2 = lb.clone(), ub.clone(), None if act is None else act.clone()
     ctx.stats_reset(stream)
     ctx.propagate_device(N, l2, u2, l2, u2, a2, a2, status, stream)
     s = ctx.stats_read(stream)
