@@ -553,12 +553,16 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (Bp) { B = Bp; list_cap_used = cap_p; }
   plan.lds_bytes = global_dom ? lds_bytes_global(c->n_vars, S, list_cap_used) : lds_bytes_for(S, B, list_cap_used, block, Bp != 0, Bp ? wl_used : 0);
   plan.grid = team > 1 ? n_nodes * team : (n_nodes + B - 1) / B;
+  const size_t adj_cache_bytes = (((size_t)c->n_vars + 1) * 4 + 15) & ~(size_t)15;
+  const bool adj_cache = plan.lds_bytes + adj_cache_bytes <= c->lds_max;  // LDS copy of adj_off behind the carve
+  if (adj_cache) plan.lds_bytes += adj_cache_bytes;
 
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
+  a.adj_cache = adj_cache ? 1u : 0u;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
@@ -612,6 +616,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     LaunchPlan plan2;
     plan2.block = block;
     plan2.lds_bytes = lds_bytes_for(S, Bp / 2, cap_half, block);
+    a2.adj_cache = plan2.lds_bytes + adj_cache_bytes <= c->lds_max ? 1u : 0u;
+    if (a2.adj_cache) plan2.lds_bytes += adj_cache_bytes;
     plan2.grid = (n_nodes + Bp / 2 - 1) / (Bp / 2);
     HIP_TRY(c, launch_fixpoint(a2, plan2, stream));
   }

@@ -87,6 +87,7 @@ struct LaunchArgs {
                              //     2 = the same with maximum tables as well (the model has XLessY words)
   uint32_t packed;           // 1 = 16-bit packed LDS domains (every bound within +-kPackedMax); tiles that do not fit mark
                              //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
+  uint32_t adj_cache;        // 1 = (n_vars + 1) words of LDS behind the carve hold a copy of m.adj_off
   uint32_t only_marked;      // 1 = second launch of a packed call: run only tiles whose nodes carry kStatusRetry
   uint32_t epoch;            // launch stamp compared with *retry_flag
   uint32_t* retry_flag;      // device word of the context

@@ -354,7 +354,7 @@ __host__ __device__ inline uint32_t rmq_levels(uint32_t word_level, bool max_tab
   return word_level == 0 ? 1u : ((max_table && word_level < 2) ? 1u : kRangeLevels);
 }
 struct Carve {
-  size_t dom, summ, chg_a, chg_b, list_id, list_pre, tmp, remaining, misc, total;
+  size_t dom, summ, chg_a, chg_b, list_id, list_pre, list_off, tmp, remaining, misc, total;
 };
 __host__ __device__ inline uint32_t row_stride(uint32_t B) { return B == 1 ? 1u : B + 2u; }
 // packed tiles: dwords per slot; B + 4 = 12/20/36 for B = 8/16/32 keeps rows 16-byte aligned (one ds_read_b128 = four
@@ -377,6 +377,7 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
   c.list_id = o; o = up(o + (size_t)list_cap * 4);
   c.list_pre = o; o = up(o + ((size_t)list_cap + 1) * 4);
+  c.list_off = o; o = up(o + (size_t)list_cap * 4);
   c.tmp = o; o = up(o + 40 * 4);
   c.remaining = o; o = up(o + (size_t)B * 4);
   c.misc = o; o = up(o + 24 * 4);
@@ -397,7 +398,7 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 #endif  // PCP_TU == 0
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_WORDS = 24 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_TOTAL2 = 19, M_ITEMS2 = 20, M_ROUNDMASK2 = 21, M_SCAN = 22, M_WORDS = 24 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -1732,6 +1733,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
   uint32_t* list_id = reinterpret_cast<uint32_t*>(smem + cv.list_id);
   uint32_t* list_pre = reinterpret_cast<uint32_t*>(smem + cv.list_pre);
+  uint32_t* list_off = reinterpret_cast<uint32_t*>(smem + cv.list_off);
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + cv.tmp);
   uint32_t* remaining = reinterpret_cast<uint32_t*>(smem + cv.remaining);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
@@ -1748,6 +1750,14 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
+  // adjacency offsets of the variables: an LDS copy behind the carve when the launch has room for it (a round's
+  // compaction then has no global load in its dependence chain)
+  const uint32_t* adjo = a.m.adj_off;
+  if (a.adj_cache) {
+    uint32_t* adj_lds = reinterpret_cast<uint32_t*>(smem + cv.total);
+    for (uint32_t v = tid; v <= V; v += nth) adj_lds[v] = a.m.adj_off[v];
+    adjo = adj_lds;
+  }
   if (tid < (uint32_t)M_WORDS) misc[tid] = 0;
   if (tid < (uint32_t)B) remaining[tid] = 0;
   for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
@@ -1943,48 +1953,61 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   // ---- phase 3: wake-up rounds until no variable changes (IndexedDeps::react + RelaxedFifo, as waves) ------
   const unsigned long long t_sweep = (PCP_ABLATE & 64) ? wall_clock64() : 0ull;
   const uint32_t TW = nb * Wv;
-  for (;;) {
-    // (a) count changed (node,var) pairs of live nodes
+  // A round costs latency, not throughput (the tail of a cascade is one changed variable per round), so it is built from as
+  // few block-wide steps as possible: ONE pass compacts the changed (node, variable) pairs with LDS atomics (their order is
+  // irrelevant), a barrier, the incident records run, a barrier.  The counters alternate between two slots and the old
+  // `cur` mask is cleared inside the next round's pass, so nothing else needs a barrier of its own.
+  for (uint32_t round = 0;; ++round) {
+    const uint32_t m_total = (round & 1u) ? M_TOTAL2 : M_TOTAL, m_items = (round & 1u) ? M_ITEMS2 : M_ITEMS, m_mask = (round & 1u) ? M_ROUNDMASK2 : M_ROUNDMASK;
+    // (a) compact the changed pairs of the live nodes: (node, var), the variable's adjacency offset and its degree
     const uint32_t failm = misc[M_FAIL];
-    uint32_t cnt = 0;
-    for (uint32_t w = tid; w < TW; w += nth) {
-      const uint32_t b = w / Wv;
-      if (!((failm >> b) & 1u)) {
-        const uint32_t bits = cur[w];
-        cnt += __popc(bits);
-        if (bits) atomicOr(&misc[M_ROUNDMASK], 1u << b);
-      }
-    }
-    uint32_t off = block_exclusive_scan(cnt, tmp, &misc[M_TOTAL]);
-    const uint32_t total = misc[M_TOTAL];
-    if (total == 0 || (PCP_ABLATE & 32)) break;
-    if (total <= C) {
-      // (b) compact them into a list with each variable's degree, prefix-sum the degrees
+    {
+      uint32_t degsum = 0;
       for (uint32_t w = tid; w < TW; w += nth) {
+        if (round) nxt[w] = 0;  // the mask two rounds back (`cur` of the previous round): free since the last barrier
         const uint32_t b = w / Wv;
         if ((failm >> b) & 1u) continue;
         uint32_t bits = cur[w];
+        if (!bits) continue;
+        atomicOr(&misc[m_mask], 1u << b);
+        uint32_t pos = atomicAdd(&misc[m_total], (uint32_t)__popc(bits));
         const uint32_t vbase = (w - b * Wv) << 5;
         while (bits) {
           const uint32_t v = vbase + __builtin_ctz(bits);
           bits &= bits - 1;
-          list_id[off] = (b << 26) | v;
-          list_pre[off] = (v < V) ? (a.m.adj_off[v + 1] - a.m.adj_off[v]) : 0u;
-          ++off;
+          if (pos < C) {
+            const uint32_t o0 = (v < V) ? adjo[v] : 0u, o1 = (v < V) ? adjo[v + 1] : 0u;
+            list_id[pos] = (b << 26) | v;
+            list_off[pos] = o0;
+            list_pre[pos] = o1 - o0;
+            degsum += o1 - o0;
+          }
+          ++pos;
         }
       }
-      __syncthreads();
-      {
+      if (degsum) atomicAdd(&misc[m_items], degsum);
+    }
+    __syncthreads();
+    const uint32_t total = misc[m_total];
+    if (total == 0 || (PCP_ABLATE & 32)) break;
+    if (tid == 0) {  // the other slot: last read before this round's barrier
+      misc[M_WAVES] += __popc(misc[m_mask]);
+      misc[(round & 1u) ? M_TOTAL : M_TOTAL2] = 0; misc[(round & 1u) ? M_ITEMS : M_ITEMS2] = 0; misc[(round & 1u) ? M_ROUNDMASK : M_ROUNDMASK2] = 0;
+    }
+    if (total <= C) {
+      const bool high_degree = misc[m_items] >= 32u * total;
+      if (!high_degree) {
+        // low-degree path: turn the degrees into prefix sums (the flat item space below is balanced by binary search)
         const uint32_t per = (total + nth - 1) / nth;
         const uint32_t s = min(total, tid * per), e = min(total, s + per);
         uint32_t sum = 0;
         for (uint32_t i = s; i < e; ++i) sum += list_pre[i];
-        uint32_t base = block_exclusive_scan(sum, tmp, &misc[M_ITEMS]);
+        uint32_t base = block_exclusive_scan(sum, tmp, &misc[M_SCAN]);
         for (uint32_t i = s; i < e; ++i) { const uint32_t dg = list_pre[i]; list_pre[i] = base; base += dg; }
-        if (tid == 0) list_pre[total] = misc[M_ITEMS];
+        if (tid == 0) list_pre[total] = misc[M_SCAN];
+        __syncthreads();
       }
-      __syncthreads();
-      const uint32_t T = misc[M_ITEMS];
+      const uint32_t T = misc[m_items];
       uint32_t my2 = 0, my3 = 0;
       // one item = one (changed var, incident record).  Runs a live record woken from variable v of node b unless a
       // lower-numbered changed variable of the same record will run it (RelaxedFifo dedup, relaxed_fifo.rs:42-48).
@@ -2008,7 +2031,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           }
         }
       };
-      if (T >= 32u * total) {
+      if (high_degree) {
         // (c1) high-degree variables (N-queens: 2997 records each): a wavefront walks an adjacency list 4 x 64 entries at
         // a time — the index loads are coalesced, and the 4 x (live word, record) gathers that depend on them are all
         // in flight together, instead of one dependent chain per item.
@@ -2022,8 +2045,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
         const bool whole = total >= nwv;
         for (uint32_t e = whole ? wv : 0u; e < total; e += whole ? nwv : 1u) {
           const uint32_t id = list_id[e], b = id >> 26, v = id & ((1u << 26) - 1);
-          const uint32_t deg = list_pre[e + 1] - list_pre[e];
-          const uint32_t* ap = a.m.adj + a.m.adj_off[v];
+          const uint32_t deg = list_pre[e], aoff = list_off[e];
+          const uint32_t* ap = a.m.adj + aoff;
           const uint32_t* lrow = IMPLICIT ? nullptr : reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
           for (uint32_t k0 = whole ? 0u : wv * 64 * U; k0 < deg; k0 += (whole ? 1u : nwv) * 64 * U) {
             uint32_t r[U], lb_[U];
@@ -2033,12 +2056,13 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
             for (int u = 0; u < U; ++u) {
               const uint32_t idx = k0 + u * 64 + lane;
               ok[u] = idx < deg;
-              r[u] = ap[ok[u] ? idx : 0];
+              // the record id is only needed for its live bit (explicit rows) or to fetch the record (no payloads)
+              r[u] = (IMPLICIT && a.m.adjp) ? 0u : ap[ok[u] ? idx : 0];
             }
             if (a.m.adjp) {
               // binary-only model: the record is rebuilt from the adjacency payload (a coalesced 8-byte stream next
               // to the ids) — one dependent gather per entry (the live word) instead of two
-              const uint2* pp = a.m.adjp + a.m.adj_off[v];
+              const uint2* pp = a.m.adjp + aoff;
 #pragma unroll
               for (int u = 0; u < U; ++u) {
                 const uint2 q = pp[ok[u] ? k0 + u * 64 + lane : 0];
@@ -2070,7 +2094,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           uint32_t lo = 0, hi = total;
           while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (list_pre[mid] <= i) lo = mid; else hi = mid; }
           const uint32_t id = list_id[lo], b = id >> 26, v = id & ((1u << 26) - 1);
-          const uint32_t ai = a.m.adj_off[v] + (i - list_pre[lo]);
+          const uint32_t ai = list_off[lo] + (i - list_pre[lo]);
           const uint32_t r = a.m.adj[ai];
           uint32_t lbits = ~0u;
           if constexpr (!IMPLICIT) {
@@ -2102,10 +2126,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (uint32_t i = tid; i < TW; i += nth) cur[i] = 0;
-    uint32_t* t = cur; cur = nxt; nxt = t;
-    if (tid == 0) { misc[M_WAVES] += __popc(misc[M_ROUNDMASK]); misc[M_ROUNDMASK] = 0; }
-    __syncthreads();
+    uint32_t* t = cur; cur = nxt; nxt = t;  // the old `cur` is cleared by the next round's pass
   }
 
   // ---- phase 3b (implicit `active`): is anything NOT entailed under the final domains? -------------------------
