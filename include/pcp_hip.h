@@ -42,7 +42,7 @@ typedef enum {
                                (reactors/indexed_deps.rs:69-77), bound/offset out of PCP_BOUND_MAX        */
   PCP_ERR_HIP = -3,         /* a HIP runtime call failed; pcp_last_error() has the text                   */
   PCP_ERR_NOMEM = -4,
-  PCP_ERR_UNSUPPORTED = -5, /* e.g. set_words != 0 (set-mode domains are not built yet)                   */
+  PCP_ERR_UNSUPPORTED = -5, /* e.g. XEqYMulZ over set-mode domains, a set-mode store larger than one CU's LDS    */
   PCP_ERR_NODEVICE = -6     /* no HIP device: the engine never falls back to a CPU path                   */
 } pcp_err;
 
@@ -113,8 +113,13 @@ const char* pcp_strerror(int32_t err);
 uint32_t pcp_abi_version(void);
 
 /* ---- model (≡ the immutable part of Store: `propagators`) ------------------------------------------ */
-/* ≡ Store::empty() (propagation/store.rs:40-54) over a VStore of n_vars variables.  set_words must be 0
- * (Interval<i32> domains, variable/mod.rs:36 VStoreFD); bitset domains return PCP_ERR_UNSUPPORTED. */
+/* ≡ Store::empty() (propagation/store.rs:40-54) over a VStore of n_vars variables.
+ *   set_words == 0 : Interval<i32> domains (VStoreFD, variable/mod.rs:36): bounds reasoning only.
+ *   set_words  > 0 : IntervalSet<i32> domains (VStoreSet, variable/mod.rs:38 — the reference's default FDSpace,
+ *                    search/mod.rs:41-43): every domain is a SET, carried as `set_words` u64 words per variable; value v is
+ *                    bit (v - lo) where [lo, hi] is the hull declared with pcp_model_set_hull — REQUIRED in set mode, with
+ *                    hi - lo < 64 * set_words.  XNeqY removes interior values, XEqY intersects sets, `active`/True follow
+ *                    set disjointness.  XEqYMulZ is interval-mode only (PCP_ERR_UNSUPPORTED). */
 int32_t pcp_model_reset(pcp_ctx* ctx, uint32_t n_vars, uint32_t set_words);
 /* ≡ Store::alloc, append-only (propagation/store.rs:223-230). */
 int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
@@ -134,8 +139,8 @@ int32_t pcp_model_set_hull(pcp_ctx* ctx, int32_t lo, int32_t hi);
 
 /* ---- propagation (≡ Consistency::consistency, propagation/store.rs:247-257) ---------------------------- */
 /* Host-buffer form: n_nodes independent spaces sharing the model.
- *   lb, ub  : [n_nodes][n_vars] i32, node-major, in/out (Interval<i32> bounds).
- *   bits    : must be NULL (set mode).
+ *   lb, ub  : [n_nodes][n_vars] i32, node-major, in/out (Interval<i32> bounds).  Set mode: OUT only (bounds of the sets).
+ *   bits    : interval mode: must be NULL.  Set mode: [n_nodes][n_vars][set_words] u64 in/out, the domains.
  *   active  : [n_nodes][ceil(n_units/64)] u64 in/out; bit u == Store::active of unit u.  NULL = every unit
  *             active on entry, result not returned.
  *   status  : [n_nodes] out, pcp_status.
@@ -147,7 +152,12 @@ int32_t pcp_propagate(pcp_ctx* ctx, uint32_t n_nodes, int32_t* lb, int32_t* ub, 
 
 /* Device-resident form: all pointers are HIP device pointers on ctx's device; work is enqueued on
  * `hip_stream` (a hipStream_t, NULL = the null stream) and NOT synchronised.  *_out may alias *_in.
- * active_in NULL = all units active; active_out NULL = do not write the mask back. */
+ * active_in NULL = all units active; active_out NULL = do not write the mask back.
+ * IMPLICIT-ACTIVE NODES: with active_in == NULL a node is its domains only — no `active` rows are read or kept: a unit that
+ * is entailed runs as a no-op, so liveness is derived (a unit is inactive iff it is entailed under the current domains,
+ * SURVEY.md A.4); the status comes from an entailment scan of the final domains and active_out, when given, is
+ * materialised from them.  Results are identical to passing all-ones rows; a search whose root has every unit active
+ * (every driver) never needs rows at all (pcp_branch_device accepts active == child_active == NULL). */
 typedef struct {
   const int32_t* lb_in;
   const int32_t* ub_in;
@@ -156,6 +166,8 @@ typedef struct {
   const uint64_t* active_in;
   uint64_t* active_out;
   uint8_t* status;
+  const uint64_t* bits_in; /* set mode only: [n_nodes][n_vars][set_words]; lb_in/ub_in are then ignored (may be NULL) */
+  uint64_t* bits_out;      /* set mode only; may alias bits_in                                                        */
 } pcp_device_batch;
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 

@@ -43,7 +43,7 @@ class OraclePanic(Exception):
 def _src_hash() -> str:
     import hashlib
     h = hashlib.sha256()
-    for f in ("pcp_oracle.hpp", "pcp_oracle_capi.cpp", "../include/pcp_hip.h"):
+    for f in ("pcp_oracle.hpp", "pcp_oracle_engine.inc", "pcp_oracle_capi.cpp", "../include/pcp_hip.h"):
         with open(os.path.join(_HERE, f), "rb") as fh:
             h.update(fh.read() + b"\0")
     return h.hexdigest()
@@ -102,6 +102,9 @@ def lib():
         L.orc_first_smallest_var.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_first_smallest_var.restype = C.c_int64
         L.orc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+        L.orc_consistency_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_search_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+        L.orc_set_op.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -152,6 +155,50 @@ class OracleModel:
         st = OrcStats()
         _check(lib().orc_consistency(self._h, n, _ptr(lb), _ptr(ub), _ptr(active), _ptr(status), C.byref(st), int(check_dup)))
         return lb, ub, active, status, st.as_dict()
+
+    def consistency_set(self, bits: np.ndarray, base: int, active: Optional[np.ndarray] = None, check_dup: bool = False):
+        """≡ Consistency::consistency per node over IntervalSet<i32> domains (VStoreSet).  bits: [n_nodes, n_vars, set_words]
+        uint64 (copied), value v = bit (v - base).  Returns (lb, ub, bits, active, status, stats)."""
+        bits = np.array(bits, dtype=np.uint64, order="C")
+        if bits.ndim == 2:
+            bits = bits[None]
+        n, V, sw = bits.shape
+        assert V == self.n_vars
+        lb = np.zeros((n, V), np.int32)
+        ub = np.zeros((n, V), np.int32)
+        if active is None:
+            active = full_active(n, self.n_units)
+        else:
+            active = np.array(active, dtype=np.uint64, order="C").reshape(n, self.words)
+        status = np.zeros(n, dtype=np.uint8)
+        st = OrcStats()
+        _check(lib().orc_consistency_set(self._h, n, _ptr(lb), _ptr(ub), _ptr(bits), sw, int(base), _ptr(active), _ptr(status), C.byref(st), int(check_dup)))
+        return lb, ub, bits, active, status, st.as_dict()
+
+    def search_set(self, lb0, ub0, set_words: int, base: int, all_solutions=False, node_limit=0, check_dup=False, max_records=0):
+        """DFS over FDSpace (IntervalSet domains, the reference's default); returns (search_stats, prop_stats, records, first_solution)."""
+        lb0 = np.ascontiguousarray(lb0, dtype=np.int32)
+        ub0 = np.ascontiguousarray(ub0, dtype=np.int32)
+        V, W, R, sw = self.n_vars, max(self.words, 1), int(max_records), int(set_words)
+        rec = {
+            "bits_in": np.zeros((R, V, sw), np.uint64), "bits_out": np.zeros((R, V, sw), np.uint64),
+            "lb_out": np.zeros((R, V), np.int32), "ub_out": np.zeros((R, V), np.int32),
+            "active_in": np.zeros((R, W), np.uint64), "active_out": np.zeros((R, W), np.uint64),
+            "status": np.zeros(R, np.uint8),
+        }
+        nrec = C.c_uint32(0)
+        ss, ps = OrcSearchStats(), OrcStats()
+        first = np.zeros(V, np.int32)
+        _check(lib().orc_search_set(self._h, _ptr(lb0), _ptr(ub0), sw, int(base), int(all_solutions), int(node_limit), int(check_dup),
+                                    C.byref(ss), C.byref(ps), R, _ptr(rec["bits_in"]), _ptr(rec["bits_out"]), _ptr(rec["lb_out"]),
+                                    _ptr(rec["ub_out"]), _ptr(rec["active_in"]), _ptr(rec["active_out"]), _ptr(rec["status"]),
+                                    C.byref(nrec), _ptr(first)))
+        k = nrec.value
+        rec = {key: val[:k] for key, val in rec.items()}
+        if self.words == 0:
+            rec["active_in"] = rec["active_in"][:, :0]
+            rec["active_out"] = rec["active_out"][:, :0]
+        return ss.as_dict(), ps.as_dict(), rec, first
 
     def search(self, lb0, ub0, all_solutions=False, node_limit=0, check_dup=False, max_records=0):
         """DFS with the reference's default engine; returns (search_stats, prop_stats, records, first_solution)."""
@@ -214,6 +261,17 @@ def interval_op(op: str, dom, a: int, b: int = 0) -> Tuple[int, int]:
     rl, ru = C.c_int32(), C.c_int32()
     _check(lib().orc_interval_op(code, dom[0], dom[1], a, b, C.byref(rl), C.byref(ru)))
     return rl.value, ru.value
+
+
+def set_op(op: str, x: np.ndarray, base: int, a: int = 0, y: Optional[np.ndarray] = None):
+    """IntervalSet algebra on bitset words (value v = bit v - base): returns (result words, flag)."""
+    code = {"difference": 0, "shrink_left": 1, "shrink_right": 2, "intersection": 3, "shift": 4, "is_disjoint": 5, "is_subset": 6}[op]
+    x = np.ascontiguousarray(x, np.uint64)
+    y = np.ascontiguousarray(x if y is None else y, np.uint64)
+    out = np.zeros_like(x)
+    flag = C.c_int32()
+    _check(lib().orc_set_op(code, _ptr(x), _ptr(y), len(x), int(base), int(a), _ptr(out), C.byref(flag)))
+    return out, bool(flag.value)
 
 
 class Reactor:

@@ -101,366 +101,6 @@ struct Interval {
 enum FDEvent : uint8_t { Assignment = 0, Bound = 1, Inner = 2 };
 constexpr size_t kNumEvents = 3;  // EventIndex::size(), events/mod.rs:42-44
 inline FDEvent merge(FDEvent e, FDEvent f) { return std::min(e, f); }  // events/mod.rs:31-35
-inline std::optional<FDEvent> event_new(const Interval& little, const Interval& big) {  // events/mod.rs:51-69
-  if (!little.is_subset(big)) throw Panic("Events are computed on the difference between `little` and `big`.");
-  if (little.size() != big.size()) {
-    if (little.is_singleton()) return Assignment;
-    if (little.lower() != big.lower() || little.upper() != big.upper()) return Bound;
-    return Inner;
-  }
-  return std::nullopt;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// variable::Store<Memory,Event> with copy memory — variable/store.rs:28-237.  `delta` is a VecMap (drain
-// yields ascending keys); the trail (a22) is search-side and replaced by whole-store copies.
-// ---------------------------------------------------------------------------------------------------
-struct VStore {
-  std::vector<Interval> memory;
-  std::vector<int8_t> delta;  // -1 = absent, else FDEvent (VecMap<Event>)
-  std::vector<uint32_t> delta_keys;  // keys present (unsorted; drained sorted)
-  bool has_changed_ = false;
-
-  size_t size() const { return memory.size(); }
-  size_t alloc(Interval dom) {  // variable/store.rs:129-141
-    if (dom.is_empty()) throw Panic("alloc: empty domain");
-    memory.push_back(dom);
-    delta.push_back(-1);
-    return memory.size() - 1;
-  }
-  const Interval& at(size_t idx) const {  // variable/store.rs:168-182
-    if (idx >= memory.size()) throw Panic("Variable not registered in the store.");
-    return memory[idx];
-  }
-  void update_delta(size_t key, const Interval& old_dom) {  // variable/store.rs:94-106
-    if (auto ev = event_new(memory[key], old_dom)) {
-      has_changed_ = true;
-      if (delta[key] >= 0) delta[key] = (int8_t)merge((FDEvent)delta[key], *ev);
-      else { delta[key] = (int8_t)*ev; delta_keys.push_back((uint32_t)key); }
-    }
-  }
-  bool update(size_t idx, Interval dom) {  // variable/store.rs:151-166
-    if (!dom.is_subset(at(idx))) throw Panic("Domain update must be monotonic.");
-    if (dom.is_empty()) return false;
-    if (dom.size() < memory[idx].size()) {
-      Interval old = memory[idx];
-      memory[idx] = dom;  // memory.replace (trail elided)
-      update_delta(idx, old);
-    }
-    return true;
-  }
-  std::vector<std::pair<size_t, FDEvent>> drain_delta() {  // variable/store.rs:225-229 (ascending var index)
-    std::sort(delta_keys.begin(), delta_keys.end());
-    std::vector<std::pair<size_t, FDEvent>> out;
-    out.reserve(delta_keys.size());
-    for (uint32_t k : delta_keys) { out.emplace_back(k, (FDEvent)delta[k]); delta[k] = -1; }
-    delta_keys.clear();
-    return out;
-  }
-  bool has_changed() const { return has_changed_; }   // variable/store.rs:230-232
-  void reset_changed() { has_changed_ = false; }      // variable/store.rs:234-236
-};
-
-using Deps = std::vector<std::pair<size_t, FDEvent>>;
-
-// ---------------------------------------------------------------------------------------------------
-// Views — term/ops.rs:18-28 (StoreRead / StoreMonotonicUpdate / ViewDependencies), boxed like Var<VStore>.
-// ---------------------------------------------------------------------------------------------------
-struct View {
-  virtual ~View() = default;
-  virtual Interval read(const VStore&) const = 0;
-  virtual bool update(VStore&, Interval) = 0;
-  virtual Deps dependencies(FDEvent) const = 0;
-  virtual std::unique_ptr<View> bclone() const = 0;
-};
-using Var = std::unique_ptr<View>;
-
-struct Identity final : View {  // term/identity.rs:47-70
-  size_t idx;
-  explicit Identity(size_t i) : idx(i) {}
-  Interval read(const VStore& s) const override { return s.at(idx); }
-  bool update(VStore& s, Interval v) override { return s.update(idx, v); }
-  Deps dependencies(FDEvent e) const override { return Deps{{idx, e}}; }
-  Var bclone() const override { return std::make_unique<Identity>(idx); }
-};
-struct Addition final : View {  // term/addition.rs:80-110
-  Var x; int32_t v;
-  Addition(Var x_, int32_t v_) : x(std::move(x_)), v(v_) {}
-  Interval read(const VStore& s) const override { return x->read(s).add(v); }
-  bool update(VStore& s, Interval value) override { return x->update(s, value.sub(v)); }
-  Deps dependencies(FDEvent e) const override { return x->dependencies(e); }
-  Var bclone() const override { return std::make_unique<Addition>(x->bclone(), v); }
-};
-struct Constant final : View {  // term/constant.rs:43-68
-  int32_t value;
-  explicit Constant(int32_t v) : value(v) {}
-  Interval read(const VStore&) const override { return Interval::singleton(value); }
-  bool update(VStore&, Interval v) override { return !v.is_empty() && v.contains(value); }
-  Deps dependencies(FDEvent) const override { return Deps{}; }
-  Var bclone() const override { return std::make_unique<Constant>(value); }
-};
-struct Sum final : View {  // term/sum.rs:56-92
-  std::vector<Var> vars;
-  explicit Sum(std::vector<Var> v) : vars(std::move(v)) {}
-  Interval read(const VStore& s) const override {
-    if (vars.empty()) throw Panic("At least one variable in sum.");
-    Interval a = vars[0]->read(s);
-    for (size_t i = 1; i < vars.size(); ++i) a = a.add(vars[i]->read(s));
-    return a;
-  }
-  bool update(VStore& s, Interval value) override {
-    if (vars.size() == 1) return vars[0]->update(s, value);
-    return read(s).overlap(value);
-  }
-  Deps dependencies(FDEvent e) const override {
-    Deps d;
-    for (auto& v : vars) { Deps x = v->dependencies(e); d.insert(d.end(), x.begin(), x.end()); }
-    return d;
-  }
-  Var bclone() const override {
-    std::vector<Var> c;
-    for (auto& v : vars) c.push_back(v->bclone());
-    return std::make_unique<Sum>(std::move(c));
-  }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// Propagators — propagation/ops.rs:17-29 (Propagator / Subsumption / PropagatorDependencies), boxed like
-// Box<dyn PropagatorConcept> (propagation/concept.rs:21-53).
-// ---------------------------------------------------------------------------------------------------
-struct Propagator {
-  virtual ~Propagator() = default;
-  virtual bool propagate(VStore&) = 0;
-  virtual SKleene is_subsumed(const VStore&) const = 0;
-  virtual Deps dependencies() const = 0;
-  virtual std::unique_ptr<Propagator> bclone() const = 0;
-  virtual uint64_t num_elementary() const { return 1; }  // children evaluated per pop (metric unit)
-};
-using Formula = std::unique_ptr<Propagator>;
-
-struct XEqY final : Propagator {  // propagators/cmp/x_eq_y.rs:67-116
-  Var x, y;
-  XEqY(Var x_, Var y_) : x(std::move(x_)), y(std::move(y_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :73-94
-    Interval a = x->read(s), b = y->read(s);
-    if (a.lower() == b.upper() && a.upper() == b.lower()) return SKleene::True;
-    if (a.is_disjoint(b)) return SKleene::False;
-    return SKleene::Unknown;
-  }
-  bool propagate(VStore& s) override {  // :102-107
-    Interval a = x->read(s), b = y->read(s);
-    Interval n = a.intersection(b);
-    return x->update(s, n) && y->update(s, n);
-  }
-  Deps dependencies() const override {  // :110-115
-    Deps d = x->dependencies(Inner), e = y->dependencies(Inner);
-    d.insert(d.end(), e.begin(), e.end());
-    return d;
-  }
-  Formula bclone() const override { return std::make_unique<XEqY>(x->bclone(), y->bclone()); }
-};
-
-struct XNeqY final : Propagator {  // propagators/cmp/x_neq_y.rs:66-104
-  Var x, y;
-  XNeqY(Var x_, Var y_) : x(std::move(x_)), y(std::move(y_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :71-73 — builds a temporary XEqY from bclones
-    return knot(XEqY(x->bclone(), y->bclone()).is_subsumed(s));
-  }
-  bool propagate(VStore& s) override {  // :82-93
-    Interval a = x->read(s), b = y->read(s);
-    if (a.is_singleton()) return y->update(s, b.difference(a.lower()));
-    if (b.is_singleton()) return x->update(s, a.difference(b.lower()));
-    return true;
-  }
-  Deps dependencies() const override {  // :101-103
-    return XEqY(x->bclone(), y->bclone()).dependencies();
-  }
-  Formula bclone() const override { return std::make_unique<XNeqY>(x->bclone(), y->bclone()); }
-};
-
-struct XLessY final : Propagator {  // propagators/cmp/x_less_y.rs:67-117
-  Var x, y;
-  XLessY(Var x_, Var y_) : x(std::move(x_)), y(std::move(y_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :73-96
-    Interval a = x->read(s), b = y->read(s);
-    if (a.lower() >= b.upper()) return SKleene::False;
-    if (a.upper() < b.lower()) return SKleene::True;
-    return SKleene::Unknown;
-  }
-  bool propagate(VStore& s) override {  // :104-109 (both updates computed from the pre-read values)
-    Interval a = x->read(s), b = y->read(s);
-    return x->update(s, a.strict_shrink_right(b.upper())) && y->update(s, b.strict_shrink_left(a.lower()));
-  }
-  Deps dependencies() const override {  // :112-117
-    Deps d = x->dependencies(Bound), e = y->dependencies(Bound);
-    d.insert(d.end(), e.begin(), e.end());
-    return d;
-  }
-  Formula bclone() const override { return std::make_unique<XLessY>(x->bclone(), y->bclone()); }
-};
-
-struct XLessYPlusZ final : Propagator {  // propagators/cmp/x_less_y_plus_z.rs:75-128
-  Var x, y, z;
-  XLessYPlusZ(Var x_, Var y_, Var z_) : x(std::move(x_)), y(std::move(y_)), z(std::move(z_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :81-97
-    Interval a = x->read(s), b = y->read(s), c = z->read(s);
-    if ((int64_t)a.lower() >= (int64_t)b.upper() + c.upper()) return SKleene::False;
-    if ((int64_t)a.upper() < (int64_t)b.lower() + c.lower()) return SKleene::True;
-    return SKleene::Unknown;
-  }
-  bool propagate(VStore& s) override {  // :105-119
-    Interval a = x->read(s), b = y->read(s), c = z->read(s);
-    return x->update(s, a.strict_shrink_right((int64_t)b.upper() + c.upper())) &&
-           y->update(s, b.strict_shrink_left((int64_t)a.lower() - c.upper())) &&
-           z->update(s, c.strict_shrink_left((int64_t)a.lower() - b.upper()));
-  }
-  Deps dependencies() const override {  // :122-128
-    Deps d = x->dependencies(Bound), e = y->dependencies(Bound), f = z->dependencies(Bound);
-    d.insert(d.end(), e.begin(), e.end());
-    d.insert(d.end(), f.begin(), f.end());
-    return d;
-  }
-  Formula bclone() const override { return std::make_unique<XLessYPlusZ>(x->bclone(), y->bclone(), z->bclone()); }
-};
-
-struct XGreaterYPlusZ final : Propagator {  // propagators/cmp/x_greater_y_plus_z.rs:75-128
-  Var x, y, z;
-  XGreaterYPlusZ(Var x_, Var y_, Var z_) : x(std::move(x_)), y(std::move(y_)), z(std::move(z_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :81-98
-    Interval a = x->read(s), b = y->read(s), c = z->read(s);
-    if ((int64_t)a.upper() <= (int64_t)b.lower() + c.lower()) return SKleene::False;
-    if ((int64_t)a.lower() > (int64_t)b.upper() + c.upper()) return SKleene::True;
-    return SKleene::Unknown;
-  }
-  bool propagate(VStore& s) override {  // :106-118
-    Interval a = x->read(s), b = y->read(s), c = z->read(s);
-    return x->update(s, a.strict_shrink_left((int64_t)b.lower() + c.lower())) &&
-           y->update(s, b.strict_shrink_right((int64_t)a.upper() - c.lower())) &&
-           z->update(s, c.strict_shrink_right((int64_t)a.upper() - b.lower()));
-  }
-  Deps dependencies() const override {  // :121-128
-    Deps d = x->dependencies(Bound), e = y->dependencies(Bound), f = z->dependencies(Bound);
-    d.insert(d.end(), e.begin(), e.end());
-    d.insert(d.end(), f.begin(), f.end());
-    return d;
-  }
-  Formula bclone() const override { return std::make_unique<XGreaterYPlusZ>(x->bclone(), y->bclone(), z->bclone()); }
-};
-
-// cmp/mod.rs:34-86 — constructor sugar.
-inline std::unique_ptr<XLessY> x_greater_y(Var x, Var y) { return std::make_unique<XLessY>(std::move(y), std::move(x)); }
-inline std::unique_ptr<XLessY> x_geq_y(Var x, Var y) { return x_greater_y(std::make_unique<Addition>(std::move(x), 1), std::move(y)); }
-inline std::unique_ptr<XLessY> x_leq_y(Var x, Var y) { return std::make_unique<XLessY>(std::move(x), std::make_unique<Addition>(std::move(y), 1)); }
-inline std::unique_ptr<XGreaterYPlusZ> x_geq_y_plus_z(Var x, Var y, Var z) {
-  return std::make_unique<XGreaterYPlusZ>(std::make_unique<Addition>(std::move(x), 1), std::move(y), std::move(z));
-}
-inline std::unique_ptr<XLessYPlusZ> x_leq_y_plus_z(Var x, Var y, Var z) {
-  return std::make_unique<XLessYPlusZ>(std::make_unique<Addition>(std::move(x), -1), std::move(y), std::move(z));
-}
-
-struct XEqYPlusZ final : Propagator {  // propagators/cmp/x_eq_y_plus_z.rs:26-105
-  std::unique_ptr<XGreaterYPlusZ> geq;
-  std::unique_ptr<XLessYPlusZ> leq;
-  XEqYPlusZ(Var x, Var y, Var z) {  // :36-41
-    geq = x_geq_y_plus_z(x->bclone(), y->bclone(), z->bclone());
-    leq = x_leq_y_plus_z(std::move(x), std::move(y), std::move(z));
-  }
-  XEqYPlusZ(std::unique_ptr<XGreaterYPlusZ> g, std::unique_ptr<XLessYPlusZ> l) : geq(std::move(g)), leq(std::move(l)) {}
-  SKleene is_subsumed(const VStore& s) const override { return kand(geq->is_subsumed(s), leq->is_subsumed(s)); }  // :65-67
-  bool propagate(VStore& s) override { return geq->propagate(s) && leq->propagate(s); }                        // :85-87
-  Deps dependencies() const override {  // :96-104
-    Deps g = geq->dependencies(), l = leq->dependencies();
-    if (g != l) throw Panic("This function assumed both dependencies of X >= Y + Z and X <= Y + Z are equals.");
-    return g;
-  }
-  Formula bclone() const override {
-    auto g = std::unique_ptr<XGreaterYPlusZ>(static_cast<XGreaterYPlusZ*>(geq->bclone().release()));
-    auto l = std::unique_ptr<XLessYPlusZ>(static_cast<XLessYPlusZ*>(leq->bclone().release()));
-    return std::make_unique<XEqYPlusZ>(std::move(g), std::move(l));
-  }
-};
-
-struct XEqYMulZ final : Propagator {  // propagators/cmp/x_eq_y_mul_z.rs:68-115
-  Var x, y, z;
-  XEqYMulZ(Var x_, Var y_, Var z_) : x(std::move(x_)), y(std::move(y_)), z(std::move(z_)) {}
-  SKleene is_subsumed(const VStore& s) const override {  // :73-91
-    Interval a = x->read(s), yz = y->read(s).mul(z->read(s));
-    if (yz.overlap(a)) return (yz.is_singleton() && a.is_singleton()) ? SKleene::True : SKleene::Unknown;
-    return SKleene::False;
-  }
-  bool propagate(VStore& s) override {  // :99-105
-    Interval a = x->read(s), yz = y->read(s).mul(z->read(s));
-    return x->update(s, a.intersection(yz));
-  }
-  Deps dependencies() const override {  // :108-114
-    Deps d = x->dependencies(Bound), e = y->dependencies(Bound), f = z->dependencies(Bound);
-    d.insert(d.end(), e.begin(), e.end());
-    d.insert(d.end(), f.begin(), f.end());
-    return d;
-  }
-  Formula bclone() const override { return std::make_unique<XEqYMulZ>(x->bclone(), y->bclone(), z->bclone()); }
-};
-
-struct Conjunction final : Propagator {  // logic/conjunction.rs:77-119
-  std::vector<Formula> fs;
-  explicit Conjunction(std::vector<Formula> f) : fs(std::move(f)) {}
-  mutable uint64_t last_children = 0;
-  SKleene is_subsumed(const VStore& s) const override {  // :78-94
-    bool all_entailed = true;
-    for (auto& f : fs) {
-      SKleene k = f->is_subsumed(s);
-      if (k == SKleene::False) return SKleene::False;
-      if (k == SKleene::Unknown) all_entailed = false;
-    }
-    return all_entailed ? SKleene::True : SKleene::Unknown;
-  }
-  bool propagate(VStore& s) override {  // :97-104
-    last_children = 0;
-    for (auto& f : fs) { ++last_children; if (!f->propagate(s)) return false; }
-    return true;
-  }
-  Deps dependencies() const override {  // :107-118 (sorted + dedup union)
-    Deps d;
-    for (auto& f : fs) { Deps x = f->dependencies(); d.insert(d.end(), x.begin(), x.end()); }
-    std::sort(d.begin(), d.end());
-    d.erase(std::unique(d.begin(), d.end()), d.end());
-    return d;
-  }
-  Formula bclone() const override {
-    std::vector<Formula> c;
-    for (auto& f : fs) c.push_back(f->bclone());
-    return std::make_unique<Conjunction>(std::move(c));
-  }
-  uint64_t num_elementary() const override { return last_children; }
-};
-
-struct Distinct final : Propagator {  // propagators/distinct.rs:47-126
-  std::unique_ptr<Conjunction> conj;
-  std::vector<Var> vars;
-  explicit Distinct(std::vector<Var> v) : vars(std::move(v)) {  // :63-83
-    if (vars.empty()) throw Panic("Variable array in `Distinct` must be non-empty.");
-    std::vector<Formula> props;
-    for (size_t i = 0; i + 1 < vars.size(); ++i)
-      for (size_t j = i + 1; j < vars.size(); ++j)
-        props.push_back(std::make_unique<XNeqY>(vars[i]->bclone(), vars[j]->bclone()));
-    conj = std::make_unique<Conjunction>(std::move(props));
-  }
-  Distinct(std::unique_ptr<Conjunction> c, std::vector<Var> v) : conj(std::move(c)), vars(std::move(v)) {}
-  SKleene is_subsumed(const VStore& s) const override { return conj->is_subsumed(s); }  // :105-107
-  bool propagate(VStore& s) override { return conj->propagate(s); }                      // :111-113
-  Deps dependencies() const override {  // :117-124 (Inner on each var, NO dedup)
-    Deps d;
-    for (auto& v : vars) { Deps x = v->dependencies(Inner); d.insert(d.end(), x.begin(), x.end()); }
-    return d;
-  }
-  Formula bclone() const override {
-    std::vector<Var> c;
-    for (auto& v : vars) c.push_back(v->bclone());
-    auto cj = std::unique_ptr<Conjunction>(static_cast<Conjunction*>(conj->bclone().release()));
-    return std::make_unique<Distinct>(std::move(cj), std::move(c));
-  }
-  uint64_t num_elementary() const override { return conj->num_elementary(); }
-};
 
 // ---------------------------------------------------------------------------------------------------
 // Growable bitset — crate bit-set ^0.5.3 (iter yields ascending indices).
@@ -562,188 +202,100 @@ struct Stats {
   uint64_t subscriptions = 0; // Σ subscribe() calls in prepare()
 };
 
-// ---------------------------------------------------------------------------------------------------
-// propagation::store::Store — propagation/store.rs:32-324.
-// ---------------------------------------------------------------------------------------------------
-struct CStore {
-  std::vector<Formula> propagators;
-  BitSet active;
-  IndexedDeps reactor;
-  RelaxedFifo scheduler;
-  bool check_dup = true;  // false = the `restatement-noassert` baseline
-  Stats* stats = nullptr;
-
-  size_t alloc(Formula p) {  // :223-230
-    size_t idx = propagators.size();
-    propagators.push_back(std::move(p));
-    active.insert(idx);
-    return idx;
-  }
-  size_t size() const { return propagators.size(); }
-
-  void init_reactor(const VStore& vs) {  // :130-142
-    reactor = IndexedDeps(vs.size(), kNumEvents, check_dup);
-    active.for_each([&](size_t p) {
-      Deps d = propagators[p]->dependencies();
-      for (auto& [v, ev] : d) {
-        reactor.subscribe(v, ev, p);
-        if (stats) ++stats->subscriptions;
-      }
-    });
-  }
-  void init_scheduler() {  // :144-149
-    scheduler = RelaxedFifo(propagators.size());
-    active.for_each([&](size_t p) { scheduler.schedule(p); });
-  }
-  void prepare(const VStore& vs) { init_reactor(vs); init_scheduler(); }  // :125-128
-
-  SKleene propagator_consistency(size_t p, VStore& vs) {  // :177-183
-    if (propagators[p]->propagate(vs)) return propagators[p]->is_subsumed(vs);
-    return SKleene::False;
-  }
-  void unlink_prop(size_t p) {  // :200-207
-    active.remove(p);
-    scheduler.unschedule(p);
-    Deps d = propagators[p]->dependencies();
-    for (auto& [v, ev] : d) reactor.unsubscribe(v, ev, p);
-  }
-  void reschedule_prop(size_t p, VStore& vs) {  // :185-189
-    if (vs.has_changed()) scheduler.schedule(p);
-  }
-  bool propagate_one(size_t p, VStore& vs) {  // :166-175
-    vs.reset_changed();
-    SKleene s = propagator_consistency(p, vs);
-    if (stats) {
-      ++stats->pops;
-      stats->steps += propagators[p]->num_elementary();
-      if (vs.has_changed()) ++stats->narrowings;
-    }
-    if (s == SKleene::False) return false;
-    if (s == SKleene::True) unlink_prop(p); else reschedule_prop(p, vs);
-    return true;
-  }
-  void react(VStore& vs) {  // :191-198
-    for (auto& [v, ev] : vs.drain_delta()) {
-      std::vector<size_t> reactions = reactor.react(v, ev);
-      for (size_t p : reactions) scheduler.schedule(p);
-    }
-  }
-  bool propagation_loop(VStore& vs) {  // :151-164
-    bool consistent = true;
-    while (!scheduler.is_empty() && consistent) {
-      while (auto p = scheduler.pop()) {
-        if (!propagate_one(*p, vs)) { consistent = false; break; }
-        react(vs);
-      }
-    }
-    return consistent;
-  }
-  SKleene consistency(VStore& vs) {  // :247-257
-    prepare(vs);
-    bool consistent = propagation_loop(vs);
-    if (stats) { ++stats->nodes; if (!consistent) ++stats->failed_nodes; }
-    if (!consistent) return SKleene::False;
-    if (reactor.is_empty()) return SKleene::True;
-    return SKleene::Unknown;
-  }
-  SKleene is_subsumed(const VStore& vs) const {  // :232-238
-    SKleene x = SKleene::True;
-    for (auto& p : propagators) x = kand(x, p->is_subsumed(vs));
-    return x;
-  }
-  // Snapshot label/restore — :306-324
-  using Label = std::pair<size_t, BitSet>;
-  Label label() const { return {propagators.size(), active}; }
-  void restore(const Label& l) { propagators.resize(l.first); active = l.second; }
-};
-
-// ---------------------------------------------------------------------------------------------------
-// Search (caller side of the path): search/space.rs:21-44, search/propagation.rs:42-55,
-// search/branching/{first_smallest_var.rs:30-39, middle_val.rs:25-27, binary_split.rs:33-60, brancher.rs:52-71,
-// branch.rs:36-55}, search/engine/one_solution.rs:46-105, all_solution.rs:37-47, stop_node.rs:47-62,
-// statistics via monitor.rs:19-68.  Restoration = whole-store copies (CopyMemory semantics,
-// variable/memory/copy_memory.rs:125-151) — the trail is an optimisation with identical observable state.
-// ---------------------------------------------------------------------------------------------------
-struct Space {
-  VStore vstore;
-  CStore cstore;
-  SKleene consistency() { return cstore.consistency(vstore); }  // search/space.rs:41-43
-};
-
-inline size_t first_smallest_var(const VStore& vs) {  // first_smallest_var.rs:30-39 (min_by_key keeps the FIRST minimum)
-  size_t best = SIZE_MAX; uint32_t best_size = 0;
-  for (size_t i = 0; i < vs.size(); ++i) {
-    uint32_t sz = vs.memory[i].size();
-    if (sz > 1 && (best == SIZE_MAX || sz < best_size)) { best = i; best_size = sz; }
-  }
-  if (best == SIZE_MAX) throw Panic("Cannot select a variable in a space where all variables are assigned.");
-  return best;
-}
-inline int32_t middle_val(const Interval& d) {  // middle_val.rs:25-27 (Rust `/` truncates toward zero, as C++)
-  return (int32_t)(((int64_t)d.lower() + d.upper()) / 2);
-}
-
 struct SearchStats { uint64_t num_solution = 0, num_failed_node = 0, num_prune = 0, num_nodes = 0; bool end_of_search = false; };
 
-// One DFS over `root` with OneSolution<Propagation<Brancher<FirstSmallestVar,MiddleVal,BinarySplit>>, VectorStack>
-// wrapped in AllSolution when `all_solutions` and StopNode(node_limit) when node_limit > 0 (search/mod.rs:45-52).
-// `on_node(space_before_domains, space_after, status)` is called once per explored node.
-struct Branch {
-  std::vector<Interval> vlabel;  // vstore label (copy)
-  CStore::Label clabel;          // cstore label (len, active)
-  size_t var; int32_t val; bool left;
+// ---------------------------------------------------------------------------------------------------
+// IntervalSet<i32> — crate intervallum (interval_set.rs; not in the tree, "^1.2.0", no lockfile): a set of integers kept as
+// sorted, pairwise disjoint, NON-ADJACENT intervals plus its cardinality.  Restated from the crate's published behaviour
+// [3P-unverified]: every operation below is the SET-theoretic one — in particular `difference(&v)` removes an interior
+// value (splitting an interval), which is what makes XNeqY raise `Inner` events on VStoreSet (the FDSpace default,
+// variable/mod.rs:38, search/mod.rs:41-43; example/src/nqueens.rs:34 allocates IntervalSet::new(1, n)).
+// PARITY: unpinned beyond the search-level answers the reference's tests hold on FDSpace (solution counts
+// all_solution.rs:70, first-solution statuses one_solution.rs:121-128, StopNode stop_node.rs:83-104): no reference test
+// observes an IntervalSet domain after propagation.
+// ---------------------------------------------------------------------------------------------------
+struct IntervalSet {
+  std::vector<Interval> iv;  // sorted by lb; iv[i].ub + 1 < iv[i+1].lb
+  static IntervalSet empty() { return IntervalSet{}; }
+  static IntervalSet singleton(int32_t v) { return from_interval(v, v); }
+  static IntervalSet from_interval(int64_t l, int64_t u) {
+    IntervalSet s;
+    if (l <= u) s.iv.push_back(Interval::make(l, u));
+    return s;
+  }
+  static IntervalSet make(int64_t l, int64_t u) { return from_interval(l, u); }
+  bool is_empty() const { return iv.empty(); }
+  uint32_t size() const { uint64_t n = 0; for (auto& i : iv) n += i.size(); return (uint32_t)n; }
+  bool is_singleton() const { return iv.size() == 1 && iv[0].is_singleton(); }
+  int32_t lower() const { if (iv.empty()) throw Panic("lower() of an empty IntervalSet"); return iv.front().lb; }
+  int32_t upper() const { if (iv.empty()) throw Panic("upper() of an empty IntervalSet"); return iv.back().ub; }
+  bool contains(int32_t v) const { for (auto& i : iv) if (i.contains(v)) return true; return false; }
+  IntervalSet intersection(const IntervalSet& b) const {
+    IntervalSet r;
+    size_t i = 0, j = 0;
+    while (i < iv.size() && j < b.iv.size()) {
+      Interval x = iv[i].intersection(b.iv[j]);
+      if (!x.is_empty()) r.iv.push_back(x);
+      if (iv[i].ub < b.iv[j].ub) ++i; else ++j;
+    }
+    return r;
+  }
+  bool is_subset(const IntervalSet& b) const { return intersection(b).size() == size(); }
+  bool is_disjoint(const IntervalSet& b) const { return intersection(b).is_empty(); }
+  bool overlap(const IntervalSet& b) const { return !is_disjoint(b); }
+  IntervalSet difference(int32_t v) const {  // Difference<Bound>: remove ONE value, wherever it sits
+    IntervalSet r;
+    for (auto& i : iv) {
+      if (!i.contains(v)) { r.iv.push_back(i); continue; }
+      if (i.lb < v) r.iv.push_back(Interval{i.lb, v - 1});
+      if (v < i.ub) r.iv.push_back(Interval{v + 1, i.ub});
+    }
+    return r;
+  }
+  IntervalSet shrink_left(int64_t b) const {  // keep the values >= b
+    IntervalSet r;
+    for (auto& i : iv) { if (i.ub < b) continue; r.iv.push_back(i.lb >= b ? i : Interval::make(b, i.ub)); }
+    return r;
+  }
+  IntervalSet shrink_right(int64_t b) const {  // keep the values <= b
+    IntervalSet r;
+    for (auto& i : iv) { if (i.lb > b) break; r.iv.push_back(i.ub <= b ? i : Interval::make(i.lb, b)); }
+    return r;
+  }
+  IntervalSet strict_shrink_left(int64_t b) const { return shrink_left(b + 1); }
+  IntervalSet strict_shrink_right(int64_t b) const { return shrink_right(b - 1); }
+  IntervalSet add(int32_t v) const { IntervalSet r; for (auto& i : iv) r.iv.push_back(i.add(v)); return r; }
+  IntervalSet sub(int32_t v) const { IntervalSet r; for (auto& i : iv) r.iv.push_back(i.sub(v)); return r; }
+  IntervalSet add(const IntervalSet& b) const {  // { x + y }: union of the pairwise interval sums, normalised
+    std::vector<Interval> all;
+    for (auto& i : iv) for (auto& j : b.iv) all.push_back(i.add(j));
+    std::sort(all.begin(), all.end(), [](const Interval& p, const Interval& q) { return p.lb < q.lb; });
+    IntervalSet r;
+    for (auto& x : all) {
+      if (!r.iv.empty() && (int64_t)x.lb <= (int64_t)r.iv.back().ub + 1) r.iv.back().ub = std::max(r.iv.back().ub, x.ub);
+      else r.iv.push_back(x);
+    }
+    return r;
+  }
+  IntervalSet mul(const IntervalSet&) const { throw Panic("IntervalSet * IntervalSet is not restated (XEqYMulZ is interval-mode only)"); }
+  bool operator==(const IntervalSet& o) const {
+    if (iv.size() != o.iv.size()) return false;
+    for (size_t k = 0; k < iv.size(); ++k) if (!(iv[k].lb == o.iv[k].lb && iv[k].ub == o.iv[k].ub)) return false;
+    return true;
+  }
 };
 
-template <class OnNode>
-inline SearchStats dfs(Space& root, bool all_solutions, uint64_t node_limit, OnNode&& on_node) {
-  SearchStats st;
-  std::vector<Branch> stack;  // VectorStack: LIFO
-  bool first = true;
-  // frozen "immutable_state" = current space contents; commit = restore label + run the alternative
-  while (true) {
-    if (!first) {
-      if (stack.empty()) break;
-      Branch b = std::move(stack.back());
-      stack.pop_back();
-      // Branch::commit (branch.rs:51-55): restore, then add the branch propagator.
-      root.vstore.memory = b.vlabel;
-      root.vstore.delta.assign(root.vstore.memory.size(), -1);  // Store::from_memory: fresh delta (variable/store.rs:68-76)
-      root.vstore.delta_keys.clear();
-      root.vstore.has_changed_ = false;
-      root.cstore.restore(b.clabel);
-      Var x = std::make_unique<Identity>(b.var);
-      Var v = std::make_unique<Constant>(b.val);
-      if (b.left) root.cstore.alloc(x_leq_y(std::move(x), std::move(v)));      // binary_split.rs:46-51
-      else root.cstore.alloc(x_greater_y(std::move(x), std::move(v)));         // binary_split.rs:52-57
-    }
-    first = false;
-    std::vector<Interval> before = root.vstore.memory;
-    BitSet active_before = root.cstore.active;
-    SKleene k = root.consistency();  // Propagation::enter, search/propagation.rs:49
-    ++st.num_nodes;
-    on_node(before, active_before, root, k);
-    // StopNode replaces the status by EndOfSearch once the limit is reached (stop_node.rs:57-62), so the
-    // monitor dispatches on_end_of_search for that node and neither a solution nor a failure is counted.
-    if (node_limit && st.num_nodes >= node_limit) { st.end_of_search = true; return st; }
-    if (k == SKleene::True) {
-      ++st.num_solution;
-      if (!all_solutions) return st;  // OneSolution::enter returns Satisfiable (one_solution.rs:98-103)
-    } else if (k == SKleene::False) {
-      ++st.num_failed_node;
-    } else {
-      // Brancher::enter (brancher.rs:52-71) + BinarySplit::distribute + Branch::distribute (label AFTER consistency).
-      size_t var = first_smallest_var(root.vstore);
-      Interval dom = root.vstore.memory[var];
-      if (dom.is_singleton() || dom.is_empty()) throw Panic("Can not distribute over assigned or failed variables.");
-      int32_t val = middle_val(dom);
-      CStore::Label cl = root.cstore.label();
-      // push_branches reversed so that the left branch is explored first (one_solution.rs:46-51)
-      stack.push_back(Branch{root.vstore.memory, cl, var, val, false});
-      stack.push_back(Branch{root.vstore.memory, cl, var, val, true});
-    }
-  }
-  st.end_of_search = true;
-  return st;
-}
+// The domain-generic engine (events, variable store, views, propagators, constraint store, search), once per domain type.
+#define ORC_DOM Interval
+namespace fd {
+#include "pcp_oracle_engine.inc"
+}  // namespace fd
+#undef ORC_DOM
+#define ORC_DOM IntervalSet
+namespace fdset {
+#include "pcp_oracle_engine.inc"
+}  // namespace fdset
+#undef ORC_DOM
+using namespace fd;  // the unqualified names are the Interval<i32> engine (VStoreFD)
 
 }  // namespace orc

@@ -14,75 +14,96 @@ namespace {
 
 thread_local std::string g_err;
 
-Var make_view(uint32_t var, int32_t off, uint32_t n_vars) {
-  if (var == PCP_CONST) return std::make_unique<Constant>(off);
+// Everything below is written once over a `Types` (orc::fd::Types: Interval<i32> domains, VStoreFD; orc::fdset::Types:
+// IntervalSet<i32> domains, VStoreSet — variable/mod.rs:35-38) and instantiated for both.
+template <class T>
+typename T::VarT make_view(uint32_t var, int32_t off, uint32_t n_vars) {
+  if (var == PCP_CONST) return std::make_unique<typename T::ConstantT>(off);
   if (var >= n_vars) throw Panic("variable index out of range");
-  Var id = std::make_unique<Identity>(var);
-  if (off != 0) return std::make_unique<Addition>(std::move(id), off);
+  typename T::VarT id = std::make_unique<typename T::IdentityT>(var);
+  if (off != 0) return std::make_unique<typename T::AdditionT>(std::move(id), off);
   return id;
 }
 
-Formula make_elementary(const pcp_prop& p, uint32_t n_vars) {
-  auto v = [&](int i) { return make_view(p.var[i], p.off[i], n_vars); };
+template <class T>
+typename T::FormulaT make_elementary(const pcp_prop& p, uint32_t n_vars) {
+  auto v = [&](int i) { return make_view<T>(p.var[i], p.off[i], n_vars); };
   switch (p.kind) {
-    case PCP_NEQ: return std::make_unique<XNeqY>(v(0), v(1));
-    case PCP_EQ: return std::make_unique<XEqY>(v(0), v(1));
-    case PCP_LT: return std::make_unique<XLessY>(v(0), v(1));
-    case PCP_LT3: return std::make_unique<XLessYPlusZ>(v(0), v(1), v(2));
-    case PCP_GT3: return std::make_unique<XGreaterYPlusZ>(v(0), v(1), v(2));
-    case PCP_EQ3: return std::make_unique<XEqYPlusZ>(v(0), v(1), v(2));
-    case PCP_MUL3: return std::make_unique<XEqYMulZ>(v(0), v(1), v(2));
+    case PCP_NEQ: return std::make_unique<typename T::XNeqYT>(v(0), v(1));
+    case PCP_EQ: return std::make_unique<typename T::XEqYT>(v(0), v(1));
+    case PCP_LT: return std::make_unique<typename T::XLessYT>(v(0), v(1));
+    case PCP_LT3: return std::make_unique<typename T::XLessYPlusZT>(v(0), v(1), v(2));
+    case PCP_GT3: return std::make_unique<typename T::XGreaterYPlusZT>(v(0), v(1), v(2));
+    case PCP_EQ3: return std::make_unique<typename T::XEqYPlusZT>(v(0), v(1), v(2));
+    case PCP_MUL3: return std::make_unique<typename T::XEqYMulZT>(v(0), v(1), v(2));
     default: throw Panic("unknown propagator kind");
   }
 }
 
 // A Distinct-ordered conjunction: Conjunction semantics, Distinct's dependency order (distinct.rs:117-124).
-struct DistinctGroup final : Propagator {
-  std::unique_ptr<Conjunction> conj;
-  Deps deps;  // Inner on each var, order of first appearance, no dedup beyond first appearance
-  DistinctGroup(std::unique_ptr<Conjunction> c, Deps d) : conj(std::move(c)), deps(std::move(d)) {}
-  bool propagate(VStore& s) override { return conj->propagate(s); }
-  SKleene is_subsumed(const VStore& s) const override { return conj->is_subsumed(s); }
-  Deps dependencies() const override { return deps; }
-  Formula bclone() const override {
-    auto cj = std::unique_ptr<Conjunction>(static_cast<Conjunction*>(conj->bclone().release()));
-    return std::make_unique<DistinctGroup>(std::move(cj), deps);
+template <class T>
+struct DistinctGroup final : T::PropagatorT {
+  using VStoreT = typename T::VStoreT;
+  std::unique_ptr<typename T::ConjunctionT> conj;
+  typename T::DepsT deps;  // Inner on each var, order of first appearance, no dedup beyond first appearance
+  DistinctGroup(std::unique_ptr<typename T::ConjunctionT> c, typename T::DepsT d) : conj(std::move(c)), deps(std::move(d)) {}
+  bool propagate(VStoreT& s) override { return conj->propagate(s); }
+  SKleene is_subsumed(const VStoreT& s) const override { return conj->is_subsumed(s); }
+  typename T::DepsT dependencies() const override { return deps; }
+  typename T::FormulaT bclone() const override {
+    auto cj = std::unique_ptr<typename T::ConjunctionT>(static_cast<typename T::ConjunctionT*>(conj->bclone().release()));
+    return std::make_unique<DistinctGroup<T>>(std::move(cj), deps);
   }
   uint64_t num_elementary() const override { return conj->num_elementary(); }
 };
 
+template <class T>
+std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props, uint32_t n_vars) {
+  std::vector<typename T::FormulaT> units;
+  size_t i = 0;
+  while (i < props.size()) {
+    const pcp_prop& p = props[i];
+    if (p.group_kind == 0) { units.push_back(make_elementary<T>(p, n_vars)); ++i; continue; }
+    size_t j = i;
+    std::vector<typename T::FormulaT> fs;
+    typename T::DepsT ddeps;
+    while (j < props.size() && props[j].group_kind == p.group_kind && props[j].group == p.group) {
+      fs.push_back(make_elementary<T>(props[j], n_vars));
+      for (int k = 0; k < 3; ++k) {
+        uint32_t v = props[j].var[k];
+        if (v == PCP_CONST || v == PCP_NOVAR) continue;
+        bool seen = false;
+        for (auto& d : ddeps) if (d.first == v) { seen = true; break; }
+        if (!seen) ddeps.emplace_back(v, Inner);
+      }
+      ++j;
+    }
+    auto conj = std::make_unique<typename T::ConjunctionT>(std::move(fs));
+    if (p.group_kind == 2) units.push_back(std::make_unique<DistinctGroup<T>>(std::move(conj), std::move(ddeps)));
+    else units.push_back(std::move(conj));
+    i = j;
+  }
+  return units;
+}
+
 struct Model {
   uint32_t n_vars = 0;
   std::vector<pcp_prop> props;
-  std::vector<Formula> units;  // one per reference-level propagator
-  // pending group
+  std::vector<fd::Formula> units;       // one per reference-level propagator, over Interval<i32>
+  std::vector<fdset::Formula> units_s;  // the same model over IntervalSet<i32>
+  bool units_s_valid = false;           // built on the first set-mode call
   void rebuild() {
-    units.clear();
-    size_t i = 0;
-    while (i < props.size()) {
-      const pcp_prop& p = props[i];
-      if (p.group_kind == 0) { units.push_back(make_elementary(p, n_vars)); ++i; continue; }
-      size_t j = i;
-      std::vector<Formula> fs;
-      Deps ddeps;
-      while (j < props.size() && props[j].group_kind == p.group_kind && props[j].group == p.group) {
-        fs.push_back(make_elementary(props[j], n_vars));
-        for (int k = 0; k < 3; ++k) {
-          uint32_t v = props[j].var[k];
-          if (v == PCP_CONST || v == PCP_NOVAR) continue;
-          bool seen = false;
-          for (auto& d : ddeps) if (d.first == v) { seen = true; break; }
-          if (!seen) ddeps.emplace_back(v, Inner);
-        }
-        ++j;
-      }
-      auto conj = std::make_unique<Conjunction>(std::move(fs));
-      if (p.group_kind == 2) units.push_back(std::make_unique<DistinctGroup>(std::move(conj), std::move(ddeps)));
-      else units.push_back(std::move(conj));
-      i = j;
-    }
+    units = build_units<fd::Types>(props, n_vars);
+    units_s.clear();
+    units_s_valid = false;
   }
+  template <class T> const std::vector<typename T::FormulaT>& units_of();
 };
+template <> const std::vector<fd::Formula>& Model::units_of<fd::Types>() { return units; }
+template <> const std::vector<fdset::Formula>& Model::units_of<fdset::Types>() {
+  if (!units_s_valid) { units_s = build_units<fdset::Types>(props, n_vars); units_s_valid = true; }
+  return units_s;
+}
 
 template <class F>
 int guard(F&& f) {
@@ -91,21 +112,46 @@ int guard(F&& f) {
   catch (const std::exception& e) { g_err = e.what(); return PCP_ERR_ARG; }
 }
 
-void fill_cstore(CStore& cs, const Model& m) {
+template <class T>
+void fill_cstore(typename T::CStoreT& cs, Model& m) {
   cs.propagators.clear();
-  for (auto& u : m.units) cs.propagators.push_back(u->bclone());
+  for (auto& u : m.units_of<T>()) cs.propagators.push_back(u->bclone());
 }
 
-void set_active(CStore& cs, const uint64_t* row, size_t n_units) {
+template <class CS>
+void set_active(CS& cs, const uint64_t* row, size_t n_units) {
   cs.active = BitSet();
   for (size_t u = 0; u < n_units; ++u)
     if (!row || ((row[u >> 6] >> (u & 63)) & 1)) cs.active.insert(u);
 }
-void get_active(const CStore& cs, uint64_t* row, size_t n_units) {
+template <class CS>
+void get_active(const CS& cs, uint64_t* row, size_t n_units) {
   size_t words = (n_units + 63) / 64;
   for (size_t w = 0; w < words; ++w) row[w] = 0;
   for (size_t u = 0; u < n_units; ++u)
     if (cs.active.contains(u)) row[u >> 6] |= 1ull << (u & 63);
+}
+
+// IntervalSet <-> the bitset words of the C ABI: value v is bit (v - base) of the variable's set_words u64 words.
+IntervalSet set_from_bits(const uint64_t* w, uint32_t set_words, int32_t base) {
+  IntervalSet s;
+  int64_t run_lo = 0; bool in_run = false;
+  const int64_t nbits = (int64_t)set_words * 64;
+  for (int64_t b = 0; b <= nbits; ++b) {
+    const bool on = b < nbits && ((w[b >> 6] >> (b & 63)) & 1);
+    if (on && !in_run) { in_run = true; run_lo = b; }
+    if (!on && in_run) { in_run = false; s.iv.push_back(Interval::make(base + run_lo, base + b - 1)); }
+  }
+  return s;
+}
+void set_to_bits(const IntervalSet& s, uint64_t* w, uint32_t set_words, int32_t base) {
+  for (uint32_t k = 0; k < set_words; ++k) w[k] = 0;
+  for (auto& i : s.iv)
+    for (int64_t v = i.lb; v <= i.ub; ++v) {
+      const int64_t b = v - base;
+      if (b < 0 || b >= (int64_t)set_words * 64) throw Panic("IntervalSet value outside the bitset universe");
+      w[b >> 6] |= 1ull << (b & 63);
+    }
 }
 
 }  // namespace
@@ -138,7 +184,7 @@ int orc_consistency(void* h, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_
     CStore cs;
     cs.check_dup = check_dup != 0;
     cs.stats = &st;
-    fill_cstore(cs, *m);
+    fill_cstore<fd::Types>(cs, *m);
     size_t nu = m->units.size(), words = (nu + 63) / 64;
     for (uint32_t n = 0; n < n_nodes; ++n) {
       VStore vs;
@@ -264,7 +310,7 @@ int orc_search(void* h, const int32_t* lb0, const int32_t* ub0, int all_solution
     size_t nu = m->units.size(), words = (nu + 63) / 64, V = m->n_vars;
     uint32_t nrec = 0;
     bool have_solution = false;
-    SearchStats ss = dfs(sp, all_solutions != 0, node_limit,
+    SearchStats ss = fd::dfs(sp, all_solutions != 0, node_limit,
                          [&](const std::vector<Interval>& before, const BitSet& active_before, Space& s, SKleene k) {
       if (k == SKleene::True && !have_solution && first_solution) {
         have_solution = true;
@@ -302,6 +348,118 @@ int orc_search(void* h, const int32_t* lb0, const int32_t* ub0, int all_solution
     if (n_recorded) *n_recorded = nrec;
     if (out) *out = orc_search_stats_c{ss.num_solution, ss.num_failed_node, ss.num_prune, ss.num_nodes, ss.end_of_search ? 1u : 0u};
     if (pstats) *pstats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
+  });
+}
+
+// ---- set mode: the same two entry points over IntervalSet<i32> domains (VStoreSet, the FDSpace default) ----------------
+// bits: [n_nodes][n_vars][set_words] u64 in/out, value v = bit (v - base); lb/ub: [n_nodes][n_vars] out (bounds of the sets).
+int orc_consistency_set(void* h, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* bits, uint32_t set_words, int32_t base,
+                        uint64_t* active, uint8_t* status, orc_stats_c* stats, int check_dup) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    using T = fdset::Types;
+    Stats st;
+    fdset::CStore cs;
+    cs.check_dup = check_dup != 0;
+    cs.stats = &st;
+    fill_cstore<T>(cs, *m);
+    const size_t nu = m->units.size(), words = (nu + 63) / 64, V = m->n_vars;
+    for (uint32_t n = 0; n < n_nodes; ++n) {
+      fdset::VStore vs;
+      for (size_t v = 0; v < V; ++v) vs.alloc(set_from_bits(bits + ((size_t)n * V + v) * set_words, set_words, base));
+      set_active(cs, active ? active + (size_t)n * words : nullptr, nu);
+      SKleene k = cs.consistency(vs);
+      status[n] = (uint8_t)k;
+      for (size_t v = 0; v < V; ++v) {
+        const IntervalSet& d = vs.memory[v];
+        set_to_bits(d, bits + ((size_t)n * V + v) * set_words, set_words, base);
+        lb[(size_t)n * V + v] = d.is_empty() ? 1 : d.lower();
+        ub[(size_t)n * V + v] = d.is_empty() ? 0 : d.upper();
+      }
+      if (active) get_active(cs, active + (size_t)n * words, nu);
+    }
+    if (stats) *stats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
+  });
+}
+
+// DFS over FDSpace (search/mod.rs:41-52): variables allocated as IntervalSet::new(lb0, ub0) (example/src/nqueens.rs:32-35).
+// Records as orc_search, plus the sets: rec_bits_in is the FOLDED input (the branch propagator x <= v / x > v applied to the
+// set), rec_bits_out the fixpoint.
+int orc_search_set(void* h, const int32_t* lb0, const int32_t* ub0, uint32_t set_words, int32_t base, int all_solutions, uint64_t node_limit,
+                   int check_dup, orc_search_stats_c* out, orc_stats_c* pstats, uint32_t max_records, uint64_t* rec_bits_in,
+                   uint64_t* rec_bits_out, int32_t* rec_lb_out, int32_t* rec_ub_out, uint64_t* rec_active_in, uint64_t* rec_active_out,
+                   uint8_t* rec_status, uint32_t* n_recorded, int32_t* first_solution) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    using T = fdset::Types;
+    Stats st;
+    fdset::Space sp;
+    sp.cstore.check_dup = check_dup != 0;
+    sp.cstore.stats = &st;
+    for (uint32_t v = 0; v < m->n_vars; ++v) sp.vstore.alloc(IntervalSet::from_interval(lb0[v], ub0[v]));
+    for (auto& u : m->units_of<T>()) sp.cstore.alloc(u->bclone());
+    const size_t nu = m->units.size(), words = (nu + 63) / 64, V = m->n_vars;
+    uint32_t nrec = 0;
+    bool have_solution = false;
+    SearchStats ss = T::run_dfs(sp, all_solutions != 0, node_limit,
+                                [&](const std::vector<IntervalSet>& before, const BitSet& active_before, fdset::Space& s, SKleene k) {
+      if (k == SKleene::True && !have_solution && first_solution) {
+        have_solution = true;
+        for (size_t v = 0; v < V; ++v) first_solution[v] = s.vstore.memory[v].lower();
+      }
+      if (nrec >= max_records) return;
+      const size_t r = nrec++;
+      std::vector<IntervalSet> in = before;
+      if (s.cstore.propagators.size() > nu) {  // fold the newest branch propagator into the input set
+        auto* br = dynamic_cast<fdset::XLessY*>(s.cstore.propagators.back().get());
+        if (!br) throw Panic("branch propagator is not XLessY");
+        if (auto* idx = dynamic_cast<fdset::Identity*>(br->x.get())) {
+          IntervalSet y = br->y->read(s.vstore);  // {v+1}
+          in[idx->idx] = in[idx->idx].strict_shrink_right(y.upper());
+        } else {
+          auto* idy = dynamic_cast<fdset::Identity*>(br->y.get());
+          if (!idy) throw Panic("unexpected branch propagator shape");
+          IntervalSet c = br->x->read(s.vstore);  // {v}
+          in[idy->idx] = in[idy->idx].strict_shrink_left(c.lower());
+        }
+      }
+      for (size_t v = 0; v < V; ++v) {
+        set_to_bits(in[v], rec_bits_in + (r * V + v) * set_words, set_words, base);
+        const IntervalSet& d = s.vstore.memory[v];
+        set_to_bits(d, rec_bits_out + (r * V + v) * set_words, set_words, base);
+        rec_lb_out[r * V + v] = d.is_empty() ? 1 : d.lower();
+        rec_ub_out[r * V + v] = d.is_empty() ? 0 : d.upper();
+      }
+      for (size_t w = 0; w < words; ++w) { rec_active_in[r * words + w] = 0; rec_active_out[r * words + w] = 0; }
+      for (size_t u = 0; u < nu; ++u) {
+        if (active_before.contains(u)) rec_active_in[r * words + (u >> 6)] |= 1ull << (u & 63);
+        if (s.cstore.active.contains(u)) rec_active_out[r * words + (u >> 6)] |= 1ull << (u & 63);
+      }
+      rec_status[r] = (uint8_t)k;
+    });
+    if (n_recorded) *n_recorded = nrec;
+    if (out) *out = orc_search_stats_c{ss.num_solution, ss.num_failed_node, ss.num_prune, ss.num_nodes, ss.end_of_search ? 1u : 0u};
+    if (pstats) *pstats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
+  });
+}
+
+// IntervalSet algebra for the table tests: op 0 difference(a), 1 shrink_left(a), 2 shrink_right(a), 3 intersection with the second
+// set, 4 shift by a, 5 is_disjoint (result in *flag), 6 is_subset.  Sets as bitset words over [base, base + 64 set_words).
+int orc_set_op(int op, const uint64_t* x, const uint64_t* y, uint32_t set_words, int32_t base, int32_t a, uint64_t* out, int32_t* flag) {
+  return guard([&] {
+    IntervalSet s = set_from_bits(x, set_words, base), r;
+    *flag = 0;
+    switch (op) {
+      case 0: r = s.difference(a); break;
+      case 1: r = s.shrink_left(a); break;
+      case 2: r = s.shrink_right(a); break;
+      case 3: r = s.intersection(set_from_bits(y, set_words, base)); break;
+      case 4: r = s.add(a); break;
+      case 5: *flag = s.is_disjoint(set_from_bits(y, set_words, base)); r = s; break;
+      case 6: *flag = s.is_subset(set_from_bits(y, set_words, base)); r = s; break;
+      default: throw Panic("bad op");
+    }
+    set_to_bits(r, out, set_words, base);
   });
 }
 

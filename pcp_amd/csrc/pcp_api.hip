@@ -19,6 +19,7 @@ struct pcp_ctx {
 
   // host model
   uint32_t n_vars = 0;
+  uint32_t set_words = 0;   // > 0: IntervalSet<i32> domains as bitsets (pcp_model_reset)
   std::vector<pcp_prop> props;          // as pushed
   std::vector<uint32_t> unit_of_prop;   // unit index of each prop
   uint32_t n_units = 0;
@@ -115,6 +116,8 @@ int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
       if (p.var[i] != PCP_CONST && p.var[i] == p.var[j])
         return fail(c, PCP_ERR_CONTRACT, "propagator already subscribed to this variable (reactors/indexed_deps.rs:69-77)");
   }
+  if (p.kind == PCP_MUL3 && c->set_words)
+    return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ over IntervalSet domains is not supported (interval mode only)");
   if (p.kind == PCP_MUL3)
     for (int i = 1; i < 3; ++i)
       if (p.var[i] != PCP_CONST && p.off[i] != 0)
@@ -288,6 +291,52 @@ int32_t finalize_model(pcp_ctx* c) {
   return PCP_OK;
 }
 
+// Set mode (IntervalSet<i32> domains): one workgroup per node, the sets in LDS (pcp_set.hip).
+int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batch* bt, hipStream_t stream) {
+  if (!c->hull_set) return fail(c, PCP_ERR_CONTRACT, "set mode needs the hull of the initial domains (pcp_model_set_hull): value v is bit v - lo");
+  if ((int64_t)c->hull_hi - c->hull_lo >= (int64_t)c->set_words * 64) return fail(c, PCP_ERR_CONTRACT, "the declared hull does not fit set_words * 64 values");
+  if (c->n_vars && (!bt->bits_in || !bt->bits_out || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "set mode: bits_in, bits_out, lb_out and ub_out must not be null");
+  const uint32_t P = (uint32_t)c->props.size(), words = (P + 63) / 64, S = c->n_slots;
+  uint32_t cap = (uint32_t)std::min<int64_t>(c->opt_list_cap, 1024);
+  while (cap > 64 && !lds_bytes_set(c->n_vars, S, c->set_words, cap)) cap /= 2;
+  const size_t lds = lds_bytes_set(c->n_vars, S, c->set_words, cap);
+  if (!lds || lds > c->lds_max) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode variable store does not fit one CU's LDS (n_vars * (set_words + 1) * 8 bytes)");
+  ModelDev m;
+  memset(&m, 0, sizeof(m));
+  m.recs = c->d_recs; m.adj_off = c->d_adj_off; m.adj = c->d_adj; m.const_val = c->d_const;
+  m.n_recs = P; m.n_vars = c->n_vars; m.n_slots = S; m.has_ternary = c->has_ternary; m.uniform_kind = c->uniform_kind;
+  const bool implicit = bt->active_in == nullptr && c->opt_implicit;
+  const uint32_t unit_words = (c->n_units + 63) / 64;
+  const uint64_t* live_in = nullptr;
+  uint64_t* live = nullptr;
+  uint64_t* derive = nullptr;
+  int32_t rc;
+  if (implicit) {
+    if (bt->active_out && P) {
+      if (c->has_groups) { if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc; derive = c->d_live; }
+      else derive = bt->active_out;
+    }
+  } else if (c->has_groups) {
+    if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+    HIP_TRY(c, launch_expand_units(c->d_rec_unit, P, unit_words, bt->active_in, c->d_live, n_nodes, stream));
+    live_in = c->d_live; live = c->d_live;
+  } else if (bt->active_out) {
+    live_in = bt->active_in; live = bt->active_out;
+  } else {
+    if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+    live_in = bt->active_in; live = c->d_live;
+  }
+  c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, implicit ? 1u : 0u, 1u, n_nodes, 1024u, (uint32_t)lds, cap};
+  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  HIP_TRY(c, launch_setfix(m, n_nodes, c->set_words, c->hull_lo, cap, bt->bits_in, bt->bits_out, bt->lb_out, bt->ub_out, live_in, live, bt->status,
+                           c->d_stats, derive, stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (c->has_groups && bt->active_out && P)
+    HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
+  c->ev_valid = true;
+  return PCP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -349,9 +398,10 @@ void pcp_ctx_destroy(pcp_ctx* c) {
 
 int32_t pcp_model_reset(pcp_ctx* c, uint32_t n_vars, uint32_t set_words) {
   if (!c) return PCP_ERR_ARG;
-  if (set_words != 0) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode (bitset) domains are not built yet");
+  if (set_words > 4096) return fail(c, PCP_ERR_ARG, "set_words too large");
   if (n_vars >= kMaxSlots) return fail(c, PCP_ERR_UNSUPPORTED, "too many variables");
   c->n_vars = n_vars;
+  c->set_words = set_words;
   c->props.clear();
   c->unit_of_prop.clear();
   c->n_units = 0;
@@ -460,8 +510,9 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   c->ev_valid = false;
   if (n_nodes == 0) return PCP_OK;
   if (!bt->status) return fail(c, PCP_ERR_ARG, "status must not be null");
-  if (c->n_vars && (!bt->lb_in || !bt->ub_in || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "domain pointers must not be null");
+  if (c->n_vars && !c->set_words && (!bt->lb_in || !bt->ub_in || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "domain pointers must not be null");
 
+  if (c->set_words) return propagate_set_device(c, n_nodes, bt, stream);
   const uint32_t P = (uint32_t)c->props.size();
   const uint32_t words = (P + 63) / 64;
   const uint32_t S = c->n_slots, Wv = (S + 31) / 32;
@@ -692,7 +743,7 @@ int32_t pcp_last_kernel_ms(pcp_ctx* c, float* ms) {
 int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* bits, uint64_t* active,
                       uint8_t* status, pcp_stats* stats) {
   if (!c) return PCP_ERR_ARG;
-  if (bits) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode (bitset) domains are not built yet");
+  if ((bits != nullptr) != (c->set_words != 0)) return fail(c, PCP_ERR_ARG, "`bits` must be given exactly when the model was reset with set_words > 0");
   if (n_nodes && (!status || (c->n_vars && (!lb || !ub)))) return fail(c, PCP_ERR_ARG, "null buffer");
   HIP_TRY(c, hipSetDevice(c->device));
   int32_t rc = finalize_model(c);
@@ -702,7 +753,16 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   // The reference panics on an empty initial domain (variable/store.rs:136) and the build rejects bounds
   // outside +-PCP_BOUND_MAX.
   const size_t nv = (size_t)n_nodes * c->n_vars;
-  for (size_t i = 0; i < nv; ++i) {
+  const size_t sw = c->set_words;
+  if (sw) {
+    // set mode: the domains are the bitsets; an empty initial domain is the reference's alloc panic (variable/store.rs:136)
+    for (size_t i = 0; i < nv; ++i) {
+      bool any = false;
+      for (size_t k = 0; k < sw && !any; ++k) any = bits[i * sw + k] != 0;
+      if (!any) return fail(c, PCP_ERR_CONTRACT, "empty initial domain (variable/store.rs:136)");
+    }
+  }
+  for (size_t i = 0; i < nv && !sw; ++i) {
     if (lb[i] > ub[i]) return fail(c, PCP_ERR_CONTRACT, "empty initial domain (variable/store.rs:136)");
     if (lb[i] < -PCP_BOUND_MAX || ub[i] > PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "bound outside +-PCP_BOUND_MAX");
     if (c->hull_set && (lb[i] < c->hull_lo || ub[i] > c->hull_hi)) return fail(c, PCP_ERR_CONTRACT, "bound outside the hull declared with pcp_model_set_hull");
@@ -710,7 +770,8 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   const uint32_t words = ((uint32_t)c->n_units + 63) / 64;
   const size_t dom_bytes = nv * 4, act_bytes = (size_t)n_nodes * words * 8;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  const size_t o_lb = 0, o_ub = up(o_lb + dom_bytes), o_act = up(o_ub + dom_bytes), o_st = up(o_act + act_bytes), total = up(o_st + n_nodes);
+  const size_t bits_bytes = nv * sw * 8;
+  const size_t o_lb = 0, o_ub = up(o_lb + dom_bytes), o_act = up(o_ub + dom_bytes), o_st = up(o_act + act_bytes), o_bits = up(o_st + n_nodes), total = up(o_bits + bits_bytes);
   {
     unsigned char* p = static_cast<unsigned char*>(c->d_stage);
     size_t cap = c->cap_stage;
@@ -719,14 +780,17 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   }
   unsigned char* base = static_cast<unsigned char*>(c->d_stage);
   hipStream_t stream = nullptr;
-  if (dom_bytes) {
+  if (dom_bytes && !sw) {
     HIP_TRY(c, hipMemcpyAsync(base + o_lb, lb, dom_bytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(base + o_ub, ub, dom_bytes, hipMemcpyHostToDevice, stream));
   }
+  if (bits_bytes) HIP_TRY(c, hipMemcpyAsync(base + o_bits, bits, bits_bytes, hipMemcpyHostToDevice, stream));
   if (active && act_bytes) HIP_TRY(c, hipMemcpyAsync(base + o_act, active, act_bytes, hipMemcpyHostToDevice, stream));
   pcp_stats before;
   if (stats) { rc = pcp_stats_read(c, &before, stream); if (rc) return rc; }
   pcp_device_batch bt;
+  memset(&bt, 0, sizeof(bt));
+  if (sw) { bt.bits_in = reinterpret_cast<uint64_t*>(base + o_bits); bt.bits_out = reinterpret_cast<uint64_t*>(base + o_bits); }
   bt.lb_in = reinterpret_cast<int32_t*>(base + o_lb); bt.ub_in = reinterpret_cast<int32_t*>(base + o_ub);
   bt.lb_out = reinterpret_cast<int32_t*>(base + o_lb); bt.ub_out = reinterpret_cast<int32_t*>(base + o_ub);
   bt.active_in = active ? reinterpret_cast<uint64_t*>(base + o_act) : nullptr;
@@ -739,6 +803,7 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
     HIP_TRY(c, hipMemcpyAsync(ub, base + o_ub, dom_bytes, hipMemcpyDeviceToHost, stream));
   }
   if (active && act_bytes) HIP_TRY(c, hipMemcpyAsync(active, base + o_act, act_bytes, hipMemcpyDeviceToHost, stream));
+  if (bits_bytes) HIP_TRY(c, hipMemcpyAsync(bits, base + o_bits, bits_bytes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(c, hipMemcpyAsync(status, base + o_st, n_nodes, hipMemcpyDeviceToHost, stream));
   HIP_TRY(c, hipStreamSynchronize(stream));
   if (stats) {

@@ -133,6 +133,13 @@ hipError_t launch_contract_units(const uint32_t* unit_first, uint32_t n_units, u
 // Implicit-active nodes: record-level live rows from the final domains (live bit = the record is not entailed).
 hipError_t launch_derive_active(const ModelDev& m, const int32_t* lb, const int32_t* ub, uint64_t* live, uint32_t n_nodes, hipStream_t stream);
 
+// Set mode (pcp_set.hip): IntervalSet<i32> domains as bitsets, one workgroup per node.  live == nullptr: implicit-active nodes;
+// derive_into != nullptr: record-level live rows materialised from the final sets afterwards.
+size_t lds_bytes_set(uint32_t n_vars, uint32_t n_slots, uint32_t set_words, uint32_t list_cap);
+hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words, int32_t base, uint32_t list_cap, const uint64_t* bits_in,
+                         uint64_t* bits_out, int32_t* lb_out, int32_t* ub_out, const uint64_t* live_in, uint64_t* live, uint8_t* status,
+                         pcp_stats* stats, uint64_t* derive_into, hipStream_t stream);
+
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,

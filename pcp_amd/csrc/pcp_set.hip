@@ -1,0 +1,482 @@
+// pcp_set.hip — the propagation fixpoint over IntervalSet<i32> domains (set mode), gfx950.
+//
+// The reference's default space is FDSpace = Space<VStoreSet, ...> with VStoreSet = VStoreTrail<IntervalSet<i32>>
+// (variable/mod.rs:38, search/mod.rs:41-43; example/src/nqueens.rs:34 allocates IntervalSet::new(1, n)): domains are SETS, so
+// XNeqY removes interior values (x_neq_y.rs:82-93 with IntervalSet::difference), variable::Store::update raises `Inner` events
+// (events/mod.rs:57-64) and XEqY intersects sets (x_eq_y.rs:102-107).  Same engine semantics as the interval kernels
+// (Store::consistency, propagation/store.rs:125-258): every live propagator once, then wake-up rounds until nothing changes.
+//
+// MI355X design: ONE workgroup (1024 threads, one CU) owns a node.  Its domains live in LDS for the whole fixpoint:
+//   bits[V][set_words] u64   value v of variable x <-> bit (v - base) of bits[x]        (N-queens-1000: 1000 x 16 words = 125 KB)
+//   bnd[V] (lb, ub)          the sets' bounds, exact at the start of every round
+// A filter narrows a set with ds_and_b64 on the words it touches and marks the variable changed; it never writes the bounds.
+// The first step of the next round re-derives the exact bounds of every changed variable from its words (ffs / clz) — between
+// two such steps a filter may read bounds that are wider than the set, i.e. a superset of the current domain, which is the same
+// benign race as in the interval kernels (monotone, contracting filters: the greatest fixpoint is unique).
+// Wake-up rule: any change of a variable wakes all its propagators.  The reference wakes Bound-subscribers (XLessY and the
+// ternary kinds) only on Bound/Assignment events, not on Inner ones (indexed_deps.rs:99-113) — but those filters read and
+// write bounds only, so running them after an interior removal is a no-op: same fixpoint, a few more steps.
+// Entailment (`active`, status True): XNeqY is entailed iff the two SETS are disjoint (x_eq_y.rs:87-93 through
+// IntervalSet::is_disjoint), decided on the words (shifted intersection).
+#include <algorithm>
+
+#include "pcp_internal.h"
+
+namespace pcp {
+
+namespace {
+
+constexpr uint32_t kSetThreads = 1024;
+
+struct SetCarve {
+  size_t bits, bnd, chg_a, chg_b, list_id, list_off, list_deg, misc, total;
+};
+__host__ __device__ inline SetCarve set_carve(uint32_t V, uint32_t S, uint32_t sw, uint32_t cap) {
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t Wv = (S + 31) / 32;
+  SetCarve c;
+  size_t o = 0;
+  c.bits = o; o = up(o + (size_t)V * sw * 8);
+  c.bnd = o; o = up(o + (size_t)V * 8);
+  c.chg_a = o; o = up(o + Wv * 4);
+  c.chg_b = o; o = up(o + Wv * 4);
+  c.list_id = o; o = up(o + (size_t)cap * 4);
+  c.list_off = o; o = up(o + (size_t)cap * 4);
+  c.list_deg = o; o = up(o + (size_t)cap * 4);
+  c.misc = o; o = up(o + 32 * 4);
+  c.total = o;
+  return c;
+}
+
+enum { S_FAIL = 0, S_TOTAL = 1, S_ITEMS = 2, S_TOTAL2 = 3, S_ITEMS2 = 4, S_WAVES = 5, S_OPEN = 6, S_NARROW = 7, S_STEPS2 = 8, S_STEPS3 = 10, S_EVAL = 12, S_LIVE = 14 };
+
+// One node's domains in LDS.
+struct SetDom {
+  unsigned long long* bits;  // [V][sw]
+  int2* bnd;                 // [V] (lb, ub)
+  const int32_t* cval;       // constants, slots >= V
+  uint32_t V, sw;
+  int32_t base;
+  uint32_t* chg;             // changed mask to mark
+  uint32_t* misc;
+  uint32_t* narrow;          // per-thread counter
+
+  __device__ __forceinline__ bool is_const(uint32_t s) const { return s >= V; }
+  __device__ __forceinline__ int2 bounds(uint32_t s) const {
+    if (s >= V) { const int c = cval[s - V]; return make_int2(c, c); }
+    return bnd[s];
+  }
+  __device__ __forceinline__ void fail() const { atomicOr(&misc[S_FAIL], 1u); }
+  __device__ __forceinline__ void mark(uint32_t s) const { atomicOr(&chg[s >> 5], 1u << (s & 31)); ++*narrow; }
+  __device__ __forceinline__ bool test(uint32_t s, int v) const {  // v in the set of slot s?
+    if (s >= V) return cval[s - V] == v;
+    const long long b = (long long)v - base;
+    if (b < 0 || b >= (long long)sw * 64) return false;
+    return (bits[(size_t)s * sw + (b >> 6)] >> (b & 63)) & 1ull;
+  }
+  // IntervalSet::difference(&v): remove ONE value (x_neq_y.rs:86-89).  Removing the value of a Constant empties it:
+  // Constant::update returns false (term/constant.rs:49-52).
+  __device__ __forceinline__ void remove(uint32_t s, int v) const {
+    if (s >= V) { if (cval[s - V] == v) fail(); return; }
+    const long long b = (long long)v - base;
+    if (b < 0 || b >= (long long)sw * 64) return;
+    const unsigned long long m = 1ull << (b & 63);
+    unsigned long long* w = &bits[(size_t)s * sw + (b >> 6)];
+    if (!(*w & m)) return;
+    if (atomicAnd(w, ~m) & m) mark(s);
+  }
+  // keep only the values <= t  (shrink_right) / >= t (shrink_left), within the cached bounds [lo, hi] of slot s
+  __device__ __forceinline__ void keep_le(uint32_t s, long long t, const int2 cur) const {
+    if (t >= cur.y) return;
+    if (s >= V) { fail(); return; }  // a constant above t
+    clear_range(s, t + 1, cur.y);
+  }
+  __device__ __forceinline__ void keep_ge(uint32_t s, long long t, const int2 cur) const {
+    if (t <= cur.x) return;
+    if (s >= V) { fail(); return; }
+    clear_range(s, cur.x, t - 1);
+  }
+  __device__ __forceinline__ void clear_range(uint32_t s, long long lo, long long hi) const {  // values lo..hi inclusive
+    long long b0 = lo - base, b1 = hi - base;
+    if (b0 < 0) b0 = 0;
+    if (b1 >= (long long)sw * 64) b1 = (long long)sw * 64 - 1;
+    if (b0 > b1) return;
+    bool changed = false;
+    for (long long k = b0 >> 6; k <= (b1 >> 6); ++k) {
+      unsigned long long m = ~0ull;
+      if (k == (b0 >> 6)) m &= ~0ull << (b0 & 63);
+      if (k == (b1 >> 6)) m &= ~0ull >> (63 - (b1 & 63));
+      unsigned long long* w = &bits[(size_t)s * sw + k];
+      if (*w & m) changed |= (atomicAnd(w, ~m) & m) != 0;
+    }
+    if (changed) mark(s);
+  }
+  // 64 bits of slot s starting at bit position pos (positions outside the universe read as 0)
+  __device__ __forceinline__ unsigned long long window(uint32_t s, long long pos) const {
+    const long long nb = (long long)sw * 64;
+    if (pos <= -64 || pos >= nb) return 0ull;
+    const long long k = pos >> 6;  // floor
+    const int sh = (int)(pos & 63);
+    const unsigned long long lo = (k >= 0 && k < (long long)sw) ? bits[(size_t)s * sw + k] : 0ull;
+    if (sh == 0) return lo;
+    const unsigned long long hi = (k + 1 >= 0 && k + 1 < (long long)sw) ? bits[(size_t)s * sw + k + 1] : 0ull;
+    return (lo >> sh) | (hi << (64 - sh));
+  }
+  // x := x ∩ (y + d) on the words of x
+  __device__ __forceinline__ void intersect_shifted(uint32_t x, uint32_t y, long long d) const {
+    if (x >= V) return;
+    bool changed = false;
+    for (uint32_t k = 0; k < sw; ++k) {
+      unsigned long long* w = &bits[(size_t)x * sw + k];
+      const unsigned long long cur = *w;
+      if (!cur) continue;
+      unsigned long long other;
+      if (y >= V) {
+        const long long b = (long long)cval[y - V] + d - base - (long long)k * 64;
+        other = (b >= 0 && b < 64) ? (1ull << b) : 0ull;
+      } else {
+        other = window(y, (long long)k * 64 - d);  // value v of x  <->  value v - d of y
+      }
+      if (cur & ~other) changed |= (atomicAnd(w, other) & ~other) != 0;
+    }
+    if (changed) mark(x);
+  }
+  // is x ∩ (y + d) empty?
+  __device__ __forceinline__ bool disjoint_shifted(uint32_t x, uint32_t y, long long d) const {
+    for (uint32_t k = 0; k < sw; ++k) {
+      const unsigned long long cur = bits[(size_t)x * sw + k];
+      if (cur && (cur & window(y, (long long)k * 64 - d))) return false;
+    }
+    return true;
+  }
+};
+
+// One filter step on sets: propagate() + is_subsumed().  `want_entailed` = false skips the (possibly expensive) subsumption
+// test — implicit-active nodes need it only in the final scan.  Returns whether the propagator is entailed.
+__device__ __forceinline__ bool eval_set(const Rec& rec, const SetDom& dm, const bool want_entailed) {
+  const uint32_t kind = rec.xk >> 28, x = rec.xk & kSlotMask, y = rec.y;
+  const long long d = rec.d;
+  const int2 X = dm.bounds(x), Y = dm.bounds(y);
+  if (X.x > X.y || Y.x > Y.y) return false;  // an emptied set: the node has failed (found by the next bounds step)
+  if (kind == PCP_NEQ) {
+    // XNeqY::propagate (x_neq_y.rs:82-93): a singleton side is removed from the other SET, wherever the value sits
+    if (X.x == X.y) dm.remove(y, (int)(X.x - d));
+    else if (Y.x == Y.y) dm.remove(x, (int)(Y.x + d));
+    if (!want_entailed) return false;
+    // !XEqY::is_subsumed (x_neq_y.rs:71-73, x_eq_y.rs:87-93): True iff the sets are disjoint
+    if (X.x > Y.y + d || Y.x + d > X.y) return true;
+    if (X.x == X.y) return !dm.test(y, (int)(X.x - d));
+    if (Y.x == Y.y) return !dm.test(x, (int)(Y.x + d));
+    if (dm.is_const(x) || dm.is_const(y)) return false;
+    return dm.disjoint_shifted(x, y, d);
+  }
+  if (kind == PCP_EQ) {
+    // XEqY::propagate (x_eq_y.rs:102-107): both become the intersection of the sets
+    dm.intersect_shifted(x, y, d);
+    dm.intersect_shifted(y, x, -d);
+    if (dm.is_const(x) && dm.is_const(y) && X.x != Y.x + d) dm.fail();
+    return want_entailed && X.x == X.y && Y.x == Y.y && X.x == Y.x + d;  // x_eq_y.rs:87-88
+  }
+  if (kind == PCP_LT) {
+    // XLessY::propagate (x_less_y.rs:104-109): x.strict_shrink_right(y.upper()), y.strict_shrink_left(x.lower())
+    dm.keep_le(x, (long long)Y.y + d - 1, X);
+    dm.keep_ge(y, (long long)X.x - d + 1, Y);
+    return (long long)X.y < (long long)Y.x + d;  // x_less_y.rs:90-91 (on the bounds read; re-evaluated while anything changes)
+  }
+  const uint32_t z = rec.z;
+  const int2 Z = dm.bounds(z);
+  if (Z.x > Z.y) return false;
+  auto lt3 = [&](long long dd) {  // x < y + z + dd   (x_less_y_plus_z.rs:105-119)
+    dm.keep_le(x, (long long)Y.y + Z.y + dd - 1, X);
+    dm.keep_ge(y, (long long)X.x - Z.y - dd + 1, Y);
+    dm.keep_ge(z, (long long)X.x - Y.y - dd + 1, Z);
+  };
+  auto gt3 = [&](long long dd) {  // x > y + z + dd   (x_greater_y_plus_z.rs:106-118)
+    dm.keep_ge(x, (long long)Y.x + Z.x + dd + 1, X);
+    dm.keep_le(y, (long long)X.y - Z.x - dd - 1, Y);
+    dm.keep_le(z, (long long)X.y - Y.x - dd - 1, Z);
+  };
+  if (kind == PCP_LT3) { lt3(d); return (long long)X.y < (long long)Y.x + Z.x + d; }
+  if (kind == PCP_GT3) { gt3(d); return (long long)X.x > (long long)Y.y + Z.y + d; }
+  if (kind == PCP_EQ3) {  // geq && leq (x_eq_y_plus_z.rs:85-87; cmp/mod.rs:62-86)
+    gt3(d - 1);
+    lt3(d + 1);
+    return (long long)X.x > (long long)Y.y + Z.y + d - 1 && (long long)X.y < (long long)Y.x + Z.x + d + 1;
+  }
+  dm.fail();  // XEqYMulZ on sets is rejected on the host (pcp_model_push_props)
+  return false;
+}
+
+__device__ __forceinline__ int2 scan_bounds(const unsigned long long* w, uint32_t sw, int32_t base) {
+  int lo = 1, hi = 0;
+  for (uint32_t k = 0; k < sw; ++k)
+    if (w[k]) { lo = base + (int)k * 64 + (int)__builtin_ctzll(w[k]); break; }
+  for (uint32_t k = sw; k-- > 0;)
+    if (w[k]) { hi = base + (int)k * 64 + 63 - (int)__builtin_clzll(w[k]); break; }
+  return make_int2(lo, hi);
+}
+
+}  // namespace
+
+size_t lds_bytes_set(uint32_t n_vars, uint32_t n_slots, uint32_t set_words, uint32_t list_cap) {
+  const SetCarve c = set_carve(n_vars, n_slots, set_words, list_cap);
+  return c.total <= 160 * 1024 ? c.total : 0;
+}
+
+struct SetArgs {
+  ModelDev m;
+  uint32_t n_nodes, set_words, list_cap;
+  int32_t base;
+  const uint64_t* bits_in;
+  uint64_t* bits_out;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  const uint64_t* live_in;  // record-level rows or null
+  uint64_t* live;           // null = implicit
+  uint8_t* status;
+  pcp_stats* stats;
+};
+
+template <bool IMPLICIT>
+__global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, sw = a.set_words, C = a.list_cap, P = a.m.n_recs, words = (P + 63) >> 6;
+  const uint32_t Wv = (S + 31) >> 5;
+  const SetCarve cv = set_carve(V, S, sw, C);
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem + cv.bits);
+  int2* bnd = reinterpret_cast<int2*>(smem + cv.bnd);
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
+  uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
+  uint32_t* list_id = reinterpret_cast<uint32_t*>(smem + cv.list_id);
+  uint32_t* list_off = reinterpret_cast<uint32_t*>(smem + cv.list_off);
+  uint32_t* list_deg = reinterpret_cast<uint32_t*>(smem + cv.list_deg);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+  const uint32_t node = blockIdx.x;
+  const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
+
+  // ---- phase 0: stage the sets, derive their bounds ---------------------------------------------------------------------
+  if (tid < 32) misc[tid] = 0;
+  for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
+  {
+    const uint64_t* src = a.bits_in + (size_t)node * V * sw;
+    for (size_t i = tid; i < (size_t)V * sw; i += nth) bits[i] = src[i];
+  }
+  __syncthreads();
+  for (uint32_t v = tid; v < V; v += nth) {
+    const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+    bnd[v] = b;
+    if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);  // empty input domain
+  }
+  __syncthreads();
+
+  uint32_t narrow = 0;
+  uint64_t steps2 = 0, steps3 = 0;
+  uint64_t* live_row = IMPLICIT ? nullptr : a.live + (size_t)node * words;
+
+  // ---- phase 1: every live propagator once (init_scheduler, store.rs:144-149) --------------------------------------------
+  if (!misc[S_FAIL]) {
+    const uint64_t* in_row = (IMPLICIT || !a.live_in) ? nullptr : a.live_in + (size_t)node * words;
+    const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow};
+    for (uint32_t w = wv; w < words; w += nwv) {
+      uint64_t word = in_row ? in_row[w] : ~0ull;
+      if (w == words - 1) word &= tail_mask;
+      const uint32_t r = (w << 6) + lane;
+      bool e = false;
+      if ((word >> lane) & 1ull) {
+        const Rec rec = a.m.recs[r];
+        e = eval_set(rec, dm, !IMPLICIT);
+        if ((rec.xk >> 28) > PCP_LT) ++steps3; else ++steps2;
+      }
+      if constexpr (!IMPLICIT) {
+        const uint64_t nw = word & ~__ballot(e);
+        if (lane == 0 && (in_row != live_row || nw != word)) live_row[w] = nw;
+      }
+    }
+  } else if constexpr (!IMPLICIT) {
+    if (a.live_in && a.live_in != a.live)
+      for (uint32_t w = tid; w < words; w += nth) live_row[w] = a.live_in[(size_t)node * words + w];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- phase 2: wake-up rounds (react + schedule as waves, store.rs:191-198) --------------------------------------------
+  for (uint32_t round = 0;; ++round) {
+    const uint32_t m_total = (round & 1u) ? S_TOTAL2 : S_TOTAL, m_items = (round & 1u) ? S_ITEMS2 : S_ITEMS;
+    {
+      uint32_t degsum = 0;
+      for (uint32_t w = tid; w < Wv; w += nth) {
+        if (round) nxt[w] = 0;
+        uint32_t bitsw = cur[w];
+        if (!bitsw) continue;
+        uint32_t pos = atomicAdd(&misc[m_total], (uint32_t)__popc(bitsw));
+        while (bitsw) {
+          const uint32_t v = (w << 5) + __builtin_ctz(bitsw);
+          bitsw &= bitsw - 1;
+          if (v < V) {
+            // the exact bounds of a changed variable, from its words (an emptied set: the node has failed)
+            const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+            bnd[v] = b;
+            if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+          }
+          if (pos < C) {
+            const uint32_t o0 = (v < V) ? a.m.adj_off[v] : 0u, o1 = (v < V) ? a.m.adj_off[v + 1] : 0u;
+            list_id[pos] = v; list_off[pos] = o0; list_deg[pos] = o1 - o0;
+            degsum += o1 - o0;
+          }
+          ++pos;
+        }
+      }
+      if (degsum) atomicAdd(&misc[m_items], degsum);
+    }
+    __syncthreads();
+    const uint32_t total = misc[m_total];
+    if (total == 0 || misc[S_FAIL]) break;
+    if (tid == 0) { misc[S_WAVES] += 1; misc[(round & 1u) ? S_TOTAL : S_TOTAL2] = 0; misc[(round & 1u) ? S_ITEMS : S_ITEMS2] = 0; }
+    const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow};
+    auto run = [&](uint32_t v, uint32_t r) {
+      // a record woken from variable v runs unless a lower-numbered changed variable of the same record runs it (FIFO dedup)
+      if constexpr (!IMPLICIT) {
+        if (!((live_row[r >> 6] >> (r & 63)) & 1ull)) return;  // unlinked (store.rs:200-207)
+      }
+      const Rec rec = a.m.recs[r];
+      const uint32_t x = rec.xk & kSlotMask;
+      const bool tern = (rec.xk >> 28) > PCP_LT;
+      if (x < v && ((cur[x >> 5] >> (x & 31)) & 1u)) return;
+      if (rec.y < v && ((cur[rec.y >> 5] >> (rec.y & 31)) & 1u)) return;
+      if (tern && rec.z < v && ((cur[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
+      if (tern) ++steps3; else ++steps2;
+      const bool e = eval_set(rec, dm, !IMPLICIT);
+      if constexpr (!IMPLICIT) {
+        if (e) atomicAnd(reinterpret_cast<unsigned long long*>(&live_row[r >> 6]), ~(1ull << (r & 63)));
+      }
+    };
+    if (total <= C) {
+      // every (changed variable, incident record) pair: flat over the block, one list entry at a time per wavefront group
+      for (uint32_t e = 0; e < total; ++e) {
+        const uint32_t v = list_id[e], deg = list_deg[e], off = list_off[e];
+        for (uint32_t i = tid; i < deg; i += nth) run(v, a.m.adj[off + i]);
+      }
+    } else {
+      // more changed variables than the list holds: every record that touches a changed variable
+      for (uint32_t r = tid; r < P; r += nth) {
+        const Rec rec = a.m.recs[r];
+        const uint32_t x = rec.xk & kSlotMask;
+        const bool tern = (rec.xk >> 28) > PCP_LT;
+        uint32_t vmin = 0xFFFFFFFFu;
+        if ((cur[x >> 5] >> (x & 31)) & 1u) vmin = x;
+        if (((cur[rec.y >> 5] >> (rec.y & 31)) & 1u) && rec.y < vmin) vmin = rec.y;
+        if (tern && ((cur[rec.z >> 5] >> (rec.z & 31)) & 1u) && rec.z < vmin) vmin = rec.z;
+        if (vmin != 0xFFFFFFFFu) run(vmin, r);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* t = cur; cur = nxt; nxt = t;
+  }
+  __syncthreads();
+
+  // ---- phase 3: status.  True iff no propagator is left that is not entailed (store.rs:250-256) -------------------------------
+  const bool failed = misc[S_FAIL] != 0;
+  if (!failed) {
+    if constexpr (IMPLICIT) {
+      const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow};
+      for (uint32_t w = wv; w < words; w += nwv) {
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+        const uint32_t r = (w << 6) + lane;
+        bool open_rec = false;
+        if (r < P) open_rec = !eval_set(a.m.recs[r], dm, true);  // at the fixpoint the filters are no-ops: only is_subsumed()
+        if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
+      }
+    } else {
+      uint32_t cnt = 0;
+      for (uint32_t w = tid; w < words; w += nth) cnt += (uint32_t)__popcll(live_row[w]);
+      if (cnt) atomicOr(&misc[S_OPEN], 1u);
+    }
+  }
+  // counters
+  for (int o = 32; o > 0; o >>= 1) { narrow += __shfl_down(narrow, o); steps2 += __shfl_down(steps2, o); steps3 += __shfl_down(steps3, o); }
+  if (lane == 0) {
+    if (narrow) atomicAdd(&misc[S_NARROW], narrow);
+    if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]), (unsigned long long)steps2);
+    if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[S_STEPS3]), (unsigned long long)steps3);
+  }
+  __syncthreads();
+
+  // ---- phase 4: write back ------------------------------------------------------------------------------------------------
+  {
+    uint64_t* dst = a.bits_out + (size_t)node * V * sw;
+    for (size_t i = tid; i < (size_t)V * sw; i += nth) dst[i] = bits[i];
+    for (uint32_t v = tid; v < V; v += nth) {
+      const int2 b = bnd[v];
+      a.lb_out[(size_t)node * V + v] = b.x;
+      a.ub_out[(size_t)node * V + v] = b.y;
+    }
+  }
+  if (tid == 0) {
+    a.status[node] = failed ? (uint8_t)PCP_FALSE : (misc[S_OPEN] ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
+    const unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]);
+    const unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[S_STEPS3]);
+    if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
+    if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
+    if (s2 + s3) { atomicAdd((unsigned long long*)&a.stats->evaluated, s2 + s3); atomicAdd((unsigned long long*)&a.stats->full_evals, s2 + s3); }
+    if (misc[S_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[S_NARROW]);
+    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(1 + misc[S_WAVES]));
+    atomicAdd((unsigned long long*)&a.stats->nodes, 1ull);
+    if (failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, 1ull);
+  }
+}
+
+// `active` rows of implicit set-mode nodes on request: bit r = record r is not entailed under the final sets.
+__global__ void __launch_bounds__(kSetThreads) set_derive_active_kernel(const SetArgs a, uint64_t* live) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  const uint32_t wv = tid >> 6, nwv = nth >> 6;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, sw = a.set_words, P = a.m.n_recs, words = (P + 63) >> 6;
+  const SetCarve cv = set_carve(V, S, sw, a.list_cap);
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem + cv.bits);
+  int2* bnd = reinterpret_cast<int2*>(smem + cv.bnd);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+  uint32_t* scratch = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
+  const uint32_t node = blockIdx.x;
+  if (tid < 32) misc[tid] = 0;
+  const uint64_t* src = a.bits_out + (size_t)node * V * sw;
+  for (size_t i = tid; i < (size_t)V * sw; i += nth) bits[i] = src[i];
+  __syncthreads();
+  for (uint32_t v = tid; v < V; v += nth) bnd[v] = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+  __syncthreads();
+  uint32_t narrow = 0;
+  const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, scratch, misc, &narrow};
+  for (uint32_t w = wv; w < words; w += nwv) {
+    const uint32_t r = (w << 6) + lane;
+    bool on = false;
+    if (r < P) on = !eval_set(a.m.recs[r], dm, true);
+    const uint64_t word = __ballot(on);
+    if (lane == 0) live[(size_t)node * words + w] = word;
+  }
+}
+
+hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words, int32_t base, uint32_t list_cap, const uint64_t* bits_in,
+                         uint64_t* bits_out, int32_t* lb_out, int32_t* ub_out, const uint64_t* live_in, uint64_t* live, uint8_t* status,
+                         pcp_stats* stats, uint64_t* derive_into, hipStream_t stream) {
+  SetArgs a{m, n_nodes, set_words, list_cap, base, bits_in, bits_out, lb_out, ub_out, live_in, live, status, stats};
+  const size_t lds = set_carve(m.n_vars, m.n_slots, set_words, list_cap).total;
+  hipError_t e;
+  if (live) {
+    if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(setfix_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(setfix_kernel<false>, dim3(n_nodes), dim3(kSetThreads), lds, stream, a);
+  } else {
+    if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(setfix_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(setfix_kernel<true>, dim3(n_nodes), dim3(kSetThreads), lds, stream, a);
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (derive_into) {
+    if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(set_derive_active_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(set_derive_active_kernel, dim3(n_nodes), dim3(kSetThreads), lds, stream, a, derive_into);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace pcp

@@ -46,7 +46,7 @@ class PcpPlan(C.Structure):
 
 class DeviceBatch(C.Structure):
     _fields_ = [("lb_in", C.c_void_p), ("ub_in", C.c_void_p), ("lb_out", C.c_void_p), ("ub_out", C.c_void_p),
-                ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p)]
+                ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p), ("bits_in", C.c_void_p), ("bits_out", C.c_void_p)]
 
 
 class EngineUnavailable(RuntimeError):
@@ -128,6 +128,7 @@ class Context:
         self.device = device
         self.n_vars = 0
         self.n_units = 0
+        self.set_words = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -142,11 +143,13 @@ class Context:
             raise PcpError(rc, self._L.pcp_last_error(self._h).decode())
 
     # ---- model ------------------------------------------------------------------------------------------
-    def set_model(self, n_vars: int, props: np.ndarray):
-        """pcp_model_reset + pcp_model_push_props."""
+    def set_model(self, n_vars: int, props: np.ndarray, set_words: int = 0):
+        """pcp_model_reset + pcp_model_push_props.  set_words > 0: IntervalSet<i32> domains (VStoreSet, the reference's default
+        FDSpace) carried as bitsets — declare the hull with set_hull(lo, hi) before propagating (value v = bit v - lo)."""
         props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
-        self._check(self._L.pcp_model_reset(self._h, n_vars, 0))
+        self._check(self._L.pcp_model_reset(self._h, n_vars, int(set_words)))
         self.n_vars = int(n_vars)
+        self.set_words = int(set_words)
         self.push_props(props)
 
     def push_props(self, props: np.ndarray):
@@ -173,6 +176,24 @@ class Context:
         self._check(self._L.pcp_set_option(self._h, key.encode(), int(value)))
 
     # ---- propagation, host buffers (pcp_propagate) ----------------------------------------------------------
+    def propagate_set(self, bits, active: Optional[np.ndarray] = None, want_stats: bool = True):
+        """Set mode: ≡ Consistency::consistency on each node's IntervalSet domains.  bits: [n, n_vars, set_words] uint64.
+        Returns (lb, ub, bits, active, status, stats) as fresh arrays (lb/ub = the bounds of the fixpoint sets)."""
+        bits = np.array(bits, dtype=np.uint64, order="C")
+        if bits.ndim == 2:
+            bits = bits[None]
+        n = bits.shape[0]
+        assert bits.shape[1:] == (self.n_vars, self.set_words), bits.shape
+        lb = np.zeros((n, self.n_vars), np.int32)
+        ub = np.zeros((n, self.n_vars), np.int32)
+        if active is not None:
+            active = np.array(active, dtype=np.uint64, order="C").reshape(n, self.words)
+        status = np.zeros(n, dtype=np.uint8)
+        st = PcpStats()
+        self._check(self._L.pcp_propagate(self._h, n, _np_ptr(lb), _np_ptr(ub), _np_ptr(bits), _np_ptr(active), _np_ptr(status),
+                                          C.byref(st) if want_stats else None))
+        return lb, ub, bits, active, status, st.as_dict()
+
     def propagate(self, lb, ub, active: Optional[np.ndarray] = None, want_stats: bool = True):
         """≡ Consistency::consistency on each row.  Returns (lb, ub, active, status, stats) as fresh arrays."""
         lb = np.array(lb, dtype=np.int32, order="C")
@@ -209,12 +230,14 @@ class Context:
         return o_lb.cpu().numpy(), o_ub.cpu().numpy(), act, t_st.cpu().numpy(), {k: after[k] - before[k] for k in after}
 
     # ---- propagation, device-resident (pcp_propagate_device) ------------------------------------------------
-    def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0):
+    def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0,
+                         bits_in=None, bits_out=None):
         """All arguments are torch tensors on this context's device (or None for the optional masks); nothing is
-        synchronised.  Tensors: lb/ub int32 [n,V]; active int64/uint64 [n,words]; status uint8 [n]."""
+        synchronised.  Tensors: lb/ub int32 [n,V]; active int64/uint64 [n,words]; status uint8 [n]; set mode: bits int64
+        [n,V,set_words] (lb_in/ub_in ignored)."""
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
-        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status))
+        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out))
         self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
 
     def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0):

@@ -185,6 +185,40 @@ class VStore:
         return np.array(self.lb, dtype=np.int32), np.array(self.ub, dtype=np.int32)
 
 
+def interval_bits(lb, ub, set_words: int, base: int) -> np.ndarray:
+    """Bitset words of IntervalSet::new(lb, ub) per entry (the C ABI's set-mode domains, include/pcp_hip.h): value v is bit
+    (v - base) of the entry's `set_words` uint64 words.  lb/ub: arrays of any shape; result shape + (set_words,)."""
+    lb = np.asarray(lb, np.int64)
+    ub = np.asarray(ub, np.int64)
+    if ((lb <= ub) & ((lb < base) | (ub >= base + 64 * set_words))).any():
+        raise ContractViolation("domain outside the bitset universe [base, base + 64 * set_words)")
+    w = np.arange(set_words, dtype=np.int64) * 64 + base  # first value of each word
+    lo = np.clip(lb[..., None] - w, 0, 64)                # bits below lo are clear
+    hi = np.clip(ub[..., None] - w + 1, 0, 64)            # bits from hi up are clear
+    ones = np.uint64(0xFFFFFFFFFFFFFFFF)
+    def below(k):  # mask of the bits [0, k)
+        k = k.astype(np.uint64)
+        return np.where(k >= 64, ones, (np.uint64(1) << np.minimum(k, np.uint64(63))) - np.uint64(1))
+    return np.where(hi > lo, below(hi) & ~below(lo), np.uint64(0)).astype(np.uint64)
+
+
+def bits_bounds(bits: np.ndarray, base: int):
+    """(lb, ub) of bitset domains [..., set_words]; an empty set gives (1, 0)."""
+    bits = np.asarray(bits, np.uint64)
+    sw = bits.shape[-1]
+    flat = bits.reshape(-1, sw)
+    lb = np.ones(flat.shape[0], np.int64)
+    ub = np.zeros(flat.shape[0], np.int64)
+    for i, row in enumerate(flat):
+        nz = np.nonzero(row)[0]
+        if len(nz):
+            lo_w, hi_w = int(nz[0]), int(nz[-1])
+            lo_b = (int(row[lo_w]) & -int(row[lo_w])).bit_length() - 1
+            hi_b = int(row[hi_w]).bit_length() - 1
+            lb[i], ub[i] = base + 64 * lo_w + lo_b, base + 64 * hi_w + hi_b
+    return lb.reshape(bits.shape[:-1]).astype(np.int32), ub.reshape(bits.shape[:-1]).astype(np.int32)
+
+
 class CStore:
     """The model part of propagation::store::Store: an append-only list of units."""
 

@@ -147,3 +147,90 @@ def dfs(ctx, lb0: np.ndarray, ub0: np.ndarray, all_solutions: bool = False, node
                 stack.append((cl[2 * k + 1], cu[2 * k + 1], ca[2 * k + 1]))
                 stack.append((cl[2 * k], cu[2 * k], ca[2 * k]))
     return st
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Set mode (IntervalSet<i32> domains as bitsets — the reference's default FDSpace, search/mod.rs:41-43).  The same engine,
+# with the selectors the reference applies to sets: FirstSmallestVar compares CARDINALITIES (first_smallest_var.rs:30-39:
+# `v.size()`), MiddleVal is (lower + upper) / 2 (middle_val.rs:25-27), BinarySplit keeps the values <= v resp. > v.
+# ---------------------------------------------------------------------------------------------------------------------
+def _popcount64(a: np.ndarray) -> np.ndarray:
+    a = a.astype(np.uint64)
+    m1, m2, m4 = np.uint64(0x5555555555555555), np.uint64(0x3333333333333333), np.uint64(0x0F0F0F0F0F0F0F0F)
+    a = a - ((a >> np.uint64(1)) & m1)
+    a = (a & m2) + ((a >> np.uint64(2)) & m2)
+    a = (a + (a >> np.uint64(4))) & m4
+    return ((a * np.uint64(0x0101010101010101)) >> np.uint64(56)).astype(np.int64)
+
+
+def branch_set(bits: np.ndarray, lb: np.ndarray, ub: np.ndarray, base: int, active: Optional[np.ndarray]):
+    """BinarySplit children of each (Unknown) set-mode row, folded into the sets: returns (bits2, active2), 2 rows per input
+    row (left `x <= v`, then right `x > v`).  bits: [n, V, set_words]; lb/ub: the sets' bounds."""
+    from .model import interval_bits
+    n, V, sw = bits.shape
+    size = _popcount64(bits).sum(axis=2)
+    big = np.iinfo(np.int64).max
+    key = np.where(size > 1, size, big)
+    var = key.argmin(axis=1)
+    rows = np.arange(n)
+    if (key[rows, var] == big).any():
+        raise RuntimeError("Cannot select a variable in a space where all variables are assigned.")
+    v = middle_val(lb[rows, var], ub[rows, var]).astype(np.int64)
+    B = np.repeat(bits, 2, axis=0)
+    lo_mask = interval_bits(np.full(n, base, np.int64), v, sw, base)                      # values <= v
+    hi_mask = interval_bits(v + 1, np.full(n, base + 64 * sw - 1, np.int64), sw, base)    # values > v
+    B[2 * rows, var] &= lo_mask
+    B[2 * rows + 1, var] &= hi_mask
+    A = None if active is None else np.repeat(active, 2, axis=0)
+    return B, A
+
+
+def dfs_set(ctx, lb0: np.ndarray, ub0: np.ndarray, base: int, all_solutions: bool = False, node_limit: int = 0, batch: int = 1,
+            implicit: bool = True) -> SearchStats:
+    """Depth-first search over set-mode nodes (FDSpace): the variables are allocated as IntervalSet::new(lb0, ub0)
+    (example/src/nqueens.rs:32-35); with batch = 1 the node order is the reference's left-first DFS."""
+    from .engine import full_active
+    from .model import interval_bits
+    st = SearchStats()
+    sw = ctx.set_words
+    root = interval_bits(np.asarray(lb0), np.asarray(ub0), sw, base)
+    stack: List[Tuple[np.ndarray, Optional[np.ndarray]]] = [(root, None if implicit else full_active(1, ctx.n_units)[0])]
+    while stack:
+        take = stack[-batch:][::-1]
+        del stack[-batch:]
+        if node_limit:
+            take = take[: max(0, node_limit - st.num_nodes)]
+            if not take:
+                break
+        Bt = np.stack([t[0] for t in take])
+        A = None if implicit else np.stack([t[1] for t in take])
+        ok = Bt.any(axis=2).all(axis=1)  # a folded branch can empty a set: that child is failed without a launch
+        status = np.zeros(Bt.shape[0], np.uint8)
+        lb = np.ones(Bt.shape[:2], np.int32); ub = np.zeros(Bt.shape[:2], np.int32)
+        act = None if A is None else A.copy()
+        if ok.any():
+            plb, pub, pbits, pact, pst, s = ctx.propagate_set(Bt[ok], None if A is None else A[ok])
+            Bt[ok], lb[ok], ub[ok], status[ok] = pbits, plb, pub, pst
+            if act is not None:
+                act[ok] = pact
+            st.launches += 1
+            st.filter_steps += s["steps"] + s["steps3"]
+        st.num_nodes += Bt.shape[0]
+        st.num_failed_node += int((status == FALSE).sum())
+        if node_limit and st.num_nodes >= node_limit:
+            break
+        done = False
+        for r in np.nonzero(status == TRUE)[0]:
+            st.num_solution += 1
+            st.solutions.append(lb[r].copy())
+            if not all_solutions:
+                done = True
+        if done:
+            break
+        unk = np.nonzero(status == UNKNOWN)[0]
+        if len(unk):
+            cb, ca = branch_set(Bt[unk], lb[unk], ub[unk], base, None if act is None else act[unk])
+            for k in range(len(unk) - 1, -1, -1):
+                stack.append((cb[2 * k + 1], None if ca is None else ca[2 * k + 1]))
+                stack.append((cb[2 * k], None if ca is None else ca[2 * k]))
+    return st
