@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,c3,c4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,c3,c4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -377,7 +377,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "explicit,c2,deep500,deep3000,c3,c4" if world == 1 else "none"
+            legs_req = "explicit,c2,deep500,deep3000,set,c3,c4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -450,6 +450,43 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                       f"4096 open nodes {dive} nodes down a left-first DFS dive ({assigned:.0f} queens assigned on average)")
             legs.append(leg.run(launches=5, warmup=1))
             del leg, lb, ub
+    if "set" in want:
+        # the same model over IntervalSet<i32> domains — the reference's default FDSpace, in which XNeqY removes interior values
+        reset_opts()
+        sw = (n + 63) // 64
+        ctx.set_model(n, props, set_words=sw)
+        ctx.set_hull(1, n)
+        Bs, exp_nodes, exp_failed = W.nqueens_frontier_set(ctx, n, min(n, 1024))  # depth ~10: the first queen has just been assigned in every node
+        Ns = Bs.shape[0]
+        t_bits = torch.from_numpy(Bs.view(np.int64)).to(dev)
+        t_lb = torch.zeros((Ns, n), dtype=torch.int32, device=dev)
+        t_ub = torch.zeros_like(t_lb)
+        t_st = torch.zeros(Ns, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        ms = []
+        copies = [t_bits.clone() for _ in range(4)]
+        ctx.propagate_device(Ns, None, None, t_lb, t_ub, None, None, t_st, stream, bits_in=copies[0], bits_out=copies[0])
+        torch.cuda.synchronize()
+        ctx.stats_reset(stream)
+        for c_ in copies[1:]:
+            ctx.propagate_device(Ns, None, None, t_lb, t_ub, None, None, t_st, stream, bits_in=c_, bits_out=c_)
+            ms.append(ctx.last_kernel_ms())
+        stt = ctx.stats_read(stream)
+        med = float(np.median(ms))
+        cbytes = Ns * (2 * n * sw * 8 + 2 * n * 4)  # the sets in and out, the bounds out
+        removed = int((Bs != copies[1].cpu().numpy().view(np.uint64)).sum())
+        legs.append({"name": "C2-set-mode-IntervalSet-frontier", "nodes": Ns, "launches": len(ms), "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
+                     "steps_per_launch": (stt["steps"] + stt["steps3"]) / len(ms), "evaluated_per_launch": stt["evaluated"] / len(ms), "full_evals_per_launch": stt["full_evals"] / len(ms),
+                     "narrowings_per_launch": stt["narrowings"] / len(ms), "waves_per_node": stt["waves"] / len(ms) / Ns,
+                     "steps_per_s": (stt["steps"] + stt["steps3"]) / len(ms) / (med * 1e-3), "evaluated_per_s": stt["evaluated"] / len(ms) / (med * 1e-3), "nodes_per_s": Ns / (med * 1e-3),
+                     "compulsory_bytes_per_launch": cbytes, "hbm_frac": cbytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "status_false_true_unknown": np.bincount(t_st.cpu().numpy(), minlength=3)[:3].tolist(),
+                     "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "implicit_active", "set_mode", "grid")},
+                     "note": f"N-queens n={n} over IntervalSet<i32> domains ({sw} u64 words per variable, 125 KB of sets per node in LDS), {Ns} open nodes of the breadth-first "
+                             f"frontier of the FDSpace tree ({exp_nodes} nodes expanded, {exp_failed} failed); one workgroup per node; {removed} set words changed by the launch"})
+        del t_bits, copies
+        ctx.set_model(n, props)
+        ctx.set_hull(1, n)
     if "c3" in want:
         reset_opts()
         V3, P3, N3 = 50_000, 500_000, 4096

@@ -29,6 +29,9 @@ extern "C" {
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
 #define PCP_NOVAR 0xFFFFFFFEu /* operand slot unused (var[2] of the binary kinds)                          */
+#define PCP_SUM 0xC0000000u   /* var[i] = PCP_SUM | t: the operand is the term::Sum view number t (term/sum.rs:56-92,
+                                 registered with pcp_model_push_sum); off[i] adds a constant (Addition over the Sum, and
+                                 the constants / Addition offsets of its members folded together)                    */
 
 /* Interval bounds and offsets must stay inside [-PCP_BOUND_MAX, PCP_BOUND_MAX] so that no filter can
  * overflow i32 (the reference wraps in release and panics in debug; SURVEY.md §7 "i32 overflow"). */
@@ -66,7 +69,7 @@ typedef enum { PCP_FALSE = 0, PCP_TRUE = 1, PCP_UNKNOWN = 2 } pcp_status;
 /* One elementary filter.  A *unit* is what the reference stores as ONE Box<dyn PropagatorConcept>
  * (one index in Store::propagators, one bit of Store::active, propagation/store.rs:33-38):
  *   group_kind == 0 : the prop is a unit by itself;
- *   group_kind == 1 : consecutive props carrying the same `group` value form ONE unit — a
+ *   group_kind == 1 : consecutive props OF ONE pcp_model_push_props CALL carrying the same `group` value form ONE unit — a
  *                     logic::Conjunction (logic/conjunction.rs:77-119);
  *   group_kind == 2 : the same, built by Distinct::new (propagators/distinct.rs:63-83); it differs from
  *                     1 only in the ORDER of its reactor subscriptions (distinct.rs:117-124), which no
@@ -123,6 +126,13 @@ uint32_t pcp_abi_version(void);
 int32_t pcp_model_reset(pcp_ctx* ctx, uint32_t n_vars, uint32_t set_words);
 /* ≡ Store::alloc, append-only (propagation/store.rs:223-230). */
 int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
+/* Registers a term::Sum view over n_members variables (term/sum.rs:30-32) and returns its number in *term; a prop refers to
+ * it as var[i] = PCP_SUM | term.  read = the interval sum of the members (sum.rs:76-81); an update through a Sum of several
+ * variables never narrows anything — it fails iff the new domain does not overlap the sum (sum.rs:66-69); a Sum of ONE
+ * variable forwards to it (sum.rs:63-64).  The propagator depends on every member (sum.rs:85-91), so naming a variable twice
+ * in one propagator — directly or through its Sums — is PCP_ERR_CONTRACT like the reference's reactor panic.  Interval mode
+ * only.  pcp_model_reset forgets the terms. */
+int32_t pcp_model_push_sum(pcp_ctx* ctx, uint32_t n_members, const uint32_t* vars, uint32_t* term);
 /* ≡ FrozenStore::restore's `propagators.truncate(label.0)` (propagation/store.rs:319-323); n_units counts
  * units, not elementary props. */
 int32_t pcp_model_truncate(pcp_ctx* ctx, uint32_t n_units);
@@ -132,8 +142,9 @@ int32_t pcp_model_n_units(const pcp_ctx* ctx, uint32_t* n_units, uint32_t* n_pro
  * search lies inside it.  With a hull within +-16383 the engine keeps the domains as 16-bit cells (twice the nodes per
  * workgroup) without the second, 32-bit launch it otherwise queues behind every such call for nodes that do not fit.
  * A node whose bounds leave the declared hull is a contract violation: pcp_propagate returns PCP_ERR_CONTRACT;
- * pcp_propagate_device leaves that node's outputs untouched, sets its status to PCP_STATUS_HULL and the next
- * pcp_stats_read returns PCP_ERR_CONTRACT.  pcp_model_reset forgets the hull. */
+ * pcp_propagate_device leaves that node's outputs untouched, sets its status to PCP_STATUS_HULL and raises a sticky device
+ * flag: the next pcp_stats_read returns PCP_ERR_CONTRACT however many launches happened in between (pcp_branch_device counts
+ * such nodes in counts[4]).  pcp_model_reset forgets the hull. */
 int32_t pcp_model_set_hull(pcp_ctx* ctx, int32_t lo, int32_t hi);
 #define PCP_STATUS_HULL 0xFE
 
@@ -181,7 +192,8 @@ int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_ba
  * Children are written in tree order, two per Unknown node, each with a copy of its parent's `active` row — the
  * cstore label (len, active.clone()) of propagation/store.rs:315-317.  All pointers are device pointers.
  *   child_lb/child_ub : [2*n_nodes][n_vars] (capacity);  child_active : [2*n_nodes][ceil(n_units/64)]
- *   counts            : device uint32[4] out = { n_children, n_true, n_false, n_unknown }
+ *   counts            : device uint32[5] out = { n_children, n_true, n_false, n_unknown, n_other } — n_other counts nodes whose
+ *                       status is none of the three (PCP_STATUS_HULL: a node the engine refused); a driver should stop on it
  * Nothing is synchronised; read `counts` after synchronising hip_stream. */
 int32_t pcp_branch_device(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                           const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,

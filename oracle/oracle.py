@@ -76,6 +76,7 @@ def lib():
         L.orc_model_new.argtypes = [C.c_uint32]
         L.orc_model_free.argtypes = [C.c_void_p]
         L.orc_model_push_props.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_model_push_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_model_n_units.argtypes = [C.c_void_p]
         L.orc_model_n_units.restype = C.c_uint32
         L.orc_consistency.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -121,11 +122,15 @@ def _ptr(a: Optional[np.ndarray]):
 class OracleModel:
     """A model held by the oracle: n_vars + pcp_prop rows (same rows as fed to the HIP engine)."""
 
-    def __init__(self, n_vars: int, props: np.ndarray):
+    def __init__(self, n_vars: int, props: np.ndarray, sums=None):
         props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
         self.n_vars = int(n_vars)
         self._h = lib().orc_model_new(self.n_vars)
         try:
+            for members in (sums or []):  # term::Sum views, numbered in order
+                mv = np.ascontiguousarray(members, np.uint32)
+                t = C.c_uint32()
+                _check(lib().orc_model_push_sum(self._h, len(mv), _ptr(mv), C.byref(t)))
             _check(lib().orc_model_push_props(self._h, len(props), _ptr(props)))
         except Exception:
             lib().orc_model_free(self._h)

@@ -17,8 +17,20 @@ thread_local std::string g_err;
 // Everything below is written once over a `Types` (orc::fd::Types: Interval<i32> domains, VStoreFD; orc::fdset::Types:
 // IntervalSet<i32> domains, VStoreSet — variable/mod.rs:35-38) and instantiated for both.
 template <class T>
-typename T::VarT make_view(uint32_t var, int32_t off, uint32_t n_vars) {
+typename T::VarT make_view(uint32_t var, int32_t off, uint32_t n_vars, const std::vector<std::vector<uint32_t>>& sums) {
   if (var == PCP_CONST) return std::make_unique<typename T::ConstantT>(off);
+  if (var >= PCP_SUM && var < PCP_NOVAR) {  // term::Sum over Identity members (+ a constant through Addition)
+    const uint32_t t = var & ~PCP_SUM;
+    if (t >= sums.size()) throw Panic("unknown Sum term");
+    std::vector<typename T::VarT> mem;
+    for (uint32_t m : sums[t]) {
+      if (m >= n_vars) throw Panic("variable index out of range");
+      mem.push_back(std::make_unique<typename T::IdentityT>(m));
+    }
+    typename T::VarT sv = std::make_unique<typename T::SumT>(std::move(mem));
+    if (off != 0) return std::make_unique<typename T::AdditionT>(std::move(sv), off);
+    return sv;
+  }
   if (var >= n_vars) throw Panic("variable index out of range");
   typename T::VarT id = std::make_unique<typename T::IdentityT>(var);
   if (off != 0) return std::make_unique<typename T::AdditionT>(std::move(id), off);
@@ -26,8 +38,8 @@ typename T::VarT make_view(uint32_t var, int32_t off, uint32_t n_vars) {
 }
 
 template <class T>
-typename T::FormulaT make_elementary(const pcp_prop& p, uint32_t n_vars) {
-  auto v = [&](int i) { return make_view<T>(p.var[i], p.off[i], n_vars); };
+typename T::FormulaT make_elementary(const pcp_prop& p, uint32_t n_vars, const std::vector<std::vector<uint32_t>>& sums) {
+  auto v = [&](int i) { return make_view<T>(p.var[i], p.off[i], n_vars, sums); };
   switch (p.kind) {
     case PCP_NEQ: return std::make_unique<typename T::XNeqYT>(v(0), v(1));
     case PCP_EQ: return std::make_unique<typename T::XEqYT>(v(0), v(1));
@@ -58,17 +70,17 @@ struct DistinctGroup final : T::PropagatorT {
 };
 
 template <class T>
-std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props, uint32_t n_vars) {
+std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props, uint32_t n_vars, const std::vector<std::vector<uint32_t>>& sums) {
   std::vector<typename T::FormulaT> units;
   size_t i = 0;
   while (i < props.size()) {
     const pcp_prop& p = props[i];
-    if (p.group_kind == 0) { units.push_back(make_elementary<T>(p, n_vars)); ++i; continue; }
+    if (p.group_kind == 0) { units.push_back(make_elementary<T>(p, n_vars, sums)); ++i; continue; }
     size_t j = i;
     std::vector<typename T::FormulaT> fs;
     typename T::DepsT ddeps;
     while (j < props.size() && props[j].group_kind == p.group_kind && props[j].group == p.group) {
-      fs.push_back(make_elementary<T>(props[j], n_vars));
+      fs.push_back(make_elementary<T>(props[j], n_vars, sums));
       for (int k = 0; k < 3; ++k) {
         uint32_t v = props[j].var[k];
         if (v == PCP_CONST || v == PCP_NOVAR) continue;
@@ -89,11 +101,12 @@ std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props
 struct Model {
   uint32_t n_vars = 0;
   std::vector<pcp_prop> props;
+  std::vector<std::vector<uint32_t>> sums;  // term::Sum views (pcp_model_push_sum)
   std::vector<fd::Formula> units;       // one per reference-level propagator, over Interval<i32>
   std::vector<fdset::Formula> units_s;  // the same model over IntervalSet<i32>
   bool units_s_valid = false;           // built on the first set-mode call
   void rebuild() {
-    units = build_units<fd::Types>(props, n_vars);
+    units = build_units<fd::Types>(props, n_vars, sums);
     units_s.clear();
     units_s_valid = false;
   }
@@ -101,7 +114,7 @@ struct Model {
 };
 template <> const std::vector<fd::Formula>& Model::units_of<fd::Types>() { return units; }
 template <> const std::vector<fdset::Formula>& Model::units_of<fdset::Types>() {
-  if (!units_s_valid) { units_s = build_units<fdset::Types>(props, n_vars); units_s_valid = true; }
+  if (!units_s_valid) { units_s = build_units<fdset::Types>(props, n_vars, sums); units_s_valid = true; }
   return units_s;
 }
 
@@ -171,6 +184,14 @@ int orc_model_push_props(void* h, uint32_t n, const pcp_prop* props) {
     size_t old = m->props.size();
     m->props.insert(m->props.end(), props, props + n);
     try { m->rebuild(); } catch (...) { m->props.resize(old); m->rebuild(); throw; }
+  });
+}
+int orc_model_push_sum(void* h, uint32_t n, const uint32_t* vars, uint32_t* term) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    if (n == 0) throw Panic("At least one variable in sum.");
+    m->sums.emplace_back(vars, vars + n);
+    *term = (uint32_t)m->sums.size() - 1;
   });
 }
 uint32_t orc_model_n_units(void* h) { return (uint32_t)static_cast<Model*>(h)->units.size(); }

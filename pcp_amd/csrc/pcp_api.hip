@@ -23,6 +23,9 @@ struct pcp_ctx {
   std::vector<pcp_prop> props;          // as pushed
   std::vector<uint32_t> unit_of_prop;   // unit index of each prop
   uint32_t n_units = 0;
+  std::vector<std::vector<uint32_t>> sums;  // term::Sum views: member variables of each term (pcp_model_push_sum)
+  uint32_t* d_sum_off = nullptr; uint32_t* d_sum_mem = nullptr; size_t cap_sum_off = 0, cap_sum_mem = 0;
+  uint32_t n_sum_slots = 0;             // Sum terms with more than one member (those have a pseudo-slot)
   bool has_groups = false;
   bool dirty = true;
 
@@ -101,21 +104,32 @@ int32_t ensure(pcp_ctx* c, T*& p, size_t& cap, size_t n) {
 }
 
 int arity(uint8_t kind) { return kind <= PCP_LT ? 2 : 3; }
+bool is_sum_operand(uint32_t var) { return var >= PCP_SUM && var < PCP_NOVAR; }
 
 // Reference-panic checks on one prop (SURVEY.md §8b "Error conventions").
 int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
   if (p.kind > PCP_MUL3) return fail(c, PCP_ERR_ARG, "unknown propagator kind");
   if (p.group_kind > 2 || p.reserved != 0) return fail(c, PCP_ERR_ARG, "bad group_kind/reserved");
   const int n = arity(p.kind);
+  std::vector<uint32_t> seen;  // every variable the propagator subscribes to, Sum members included
   for (int i = 0; i < n; ++i) {
     if (p.var[i] == PCP_NOVAR) return fail(c, PCP_ERR_ARG, "missing operand");
-    if (p.var[i] != PCP_CONST && p.var[i] >= c->n_vars)
-      return fail(c, PCP_ERR_CONTRACT, "variable index out of range (variable/store.rs:176-179)");
     if (p.off[i] > PCP_BOUND_MAX || p.off[i] < -PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "offset outside +-PCP_BOUND_MAX");
-    for (int j = 0; j < i; ++j)
-      if (p.var[i] != PCP_CONST && p.var[i] == p.var[j])
-        return fail(c, PCP_ERR_CONTRACT, "propagator already subscribed to this variable (reactors/indexed_deps.rs:69-77)");
+    if (p.var[i] == PCP_CONST) continue;
+    if (is_sum_operand(p.var[i])) {
+      const uint32_t t = p.var[i] & ~PCP_SUM;
+      if (t >= c->sums.size()) return fail(c, PCP_ERR_ARG, "unknown Sum term (pcp_model_push_sum)");
+      if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "Sum views over IntervalSet domains are not supported (interval mode only)");
+      if (p.kind == PCP_MUL3) return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ over a Sum view is not supported");
+      for (uint32_t m : c->sums[t]) seen.push_back(m);
+      continue;
+    }
+    if (p.var[i] >= c->n_vars) return fail(c, PCP_ERR_CONTRACT, "variable index out of range (variable/store.rs:176-179)");
+    seen.push_back(p.var[i]);
   }
+  std::sort(seen.begin(), seen.end());
+  if (std::adjacent_find(seen.begin(), seen.end()) != seen.end())
+    return fail(c, PCP_ERR_CONTRACT, "propagator already subscribed to this variable (reactors/indexed_deps.rs:69-77)");
   if (p.kind == PCP_MUL3 && c->set_words)
     return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ over IntervalSet domains is not supported (interval mode only)");
   if (p.kind == PCP_MUL3)
@@ -130,8 +144,20 @@ int32_t finalize_model(pcp_ctx* c) {
   if (!c->dirty) return PCP_OK;
   const size_t P = c->props.size();
   std::map<int32_t, uint32_t> const_slot;
-  std::vector<int32_t> consts;
+  // slots: [0, n_vars) variables, [n_vars, n_vars + n_sum) Sum views of several members, then the interned constants.
+  // `consts` covers every slot >= n_vars (the Sum slots hold 0: their domain is computed from the members on demand).
+  std::vector<uint32_t> sum_slot(c->sums.size(), 0), sum_off(1, 0), sum_mem;
+  uint32_t n_sum = 0;
+  for (size_t t = 0; t < c->sums.size(); ++t) {
+    if (c->sums[t].size() == 1) { sum_slot[t] = c->sums[t][0]; continue; }  // a Sum of one variable forwards to it (sum.rs:63-64)
+    sum_slot[t] = c->n_vars + n_sum++;
+    sum_mem.insert(sum_mem.end(), c->sums[t].begin(), c->sums[t].end());
+    sum_off.push_back((uint32_t)sum_mem.size());
+  }
+  c->n_sum_slots = n_sum;
+  std::vector<int32_t> consts(n_sum, 0);
   auto slot_of = [&](uint32_t var, int32_t value) -> uint32_t {
+    if (is_sum_operand(var)) return sum_slot[var & ~PCP_SUM];
     if (var != PCP_CONST) return var;
     auto it = const_slot.find(value);
     if (it != const_slot.end()) return it->second;
@@ -139,6 +165,12 @@ int32_t finalize_model(pcp_ctx* c) {
     const_slot.emplace(value, s);
     consts.push_back(value);
     return s;
+  };
+  // every variable an operand makes the propagator depend on (ViewDependencies: identity.rs:66-69, sum.rs:85-91)
+  auto for_each_dep = [&](uint32_t var, auto&& f) {
+    if (var == PCP_CONST) return;
+    if (is_sum_operand(var)) { for (uint32_t m : c->sums[var & ~PCP_SUM]) f(m); return; }
+    f(var);
   };
   std::vector<Rec> recs(P);
   std::vector<uint32_t> deg(c->n_vars + 1, 0);
@@ -163,9 +195,9 @@ int32_t finalize_model(pcp_ctx* c) {
     recs[r].z = (n == 3) ? s[2] : 0;
     recs[r].d = (int32_t)d;
     tern |= (n == 3);
-    for (int i = 0; i < n; ++i)
-      if (p.var[i] != PCP_CONST) ++deg[p.var[i]];
+    for (int i = 0; i < n; ++i) for_each_dep(p.var[i], [&](uint32_t v) { ++deg[v]; });
   }
+  tern |= n_sum != 0;  // Sum views: generic path only (no compact stream, no adjacency payloads, no word descriptors)
   const uint32_t n_slots = c->n_vars + (uint32_t)consts.size();
   if (n_slots >= kMaxSlots) return fail(c, PCP_ERR_UNSUPPORTED, "too many variables");
   std::vector<uint32_t> adj_off(c->n_vars + 1, 0);
@@ -175,8 +207,7 @@ int32_t finalize_model(pcp_ctx* c) {
     std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1);
     for (size_t r = 0; r < P; ++r) {
       const pcp_prop& p = c->props[r];
-      for (int i = 0; i < arity(p.kind); ++i)
-        if (p.var[i] != PCP_CONST) adj[fill[p.var[i]]++] = (uint32_t)r;
+      for (int i = 0; i < arity(p.kind); ++i) for_each_dep(p.var[i], [&](uint32_t v) { adj[fill[v]++] = (uint32_t)r; });
     }
   }
   HIP_TRY(c, hipSetDevice(c->device));
@@ -189,7 +220,7 @@ int32_t finalize_model(pcp_ctx* c) {
   if ((rc = ensure(c, c->d_const, c->cap_const, consts.size()))) return rc;
   if (P) HIP_TRY(c, hipMemcpy(c->d_recs, recs.data(), Ppad * sizeof(Rec), hipMemcpyHostToDevice));
   c->uniform_kind = 0xFFFFFFFFu;
-  if (P) {
+  if (P && !n_sum) {
     const uint32_t k0 = recs[0].xk >> 28;
     bool same = (k0 == PCP_NEQ || k0 == PCP_LT);
     for (size_t r = 1; r < P && same; ++r) same = (recs[r].xk >> 28) == k0;
@@ -211,6 +242,12 @@ int32_t finalize_model(pcp_ctx* c) {
     c->have_adjp = true;
   }
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  if (n_sum) {
+    if ((rc = ensure(c, c->d_sum_off, c->cap_sum_off, sum_off.size()))) return rc;
+    if ((rc = ensure(c, c->d_sum_mem, c->cap_sum_mem, sum_mem.size()))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_sum_off, sum_off.data(), sum_off.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_sum_mem, sum_mem.data(), sum_mem.size() * 4, hipMemcpyHostToDevice));
+  }
   c->compact = !tern && n_slots <= kCompactSlots && P > 0;
   c->consts_fit16 = true;
   for (int32_t v : consts) c->consts_fit16 &= (v >= -kPackedMax && v <= kPackedMax);
@@ -375,7 +412,7 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
   }
   if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(pcp_stats)) != hipSuccess ||
       hipMemset(c->d_stats, 0, sizeof(pcp_stats)) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void**>(&c->d_retry), 4) != hipSuccess || hipMemset(c->d_retry, 0, 4) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_retry), 8) != hipSuccess || hipMemset(c->d_retry, 0, 8) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
     delete c;
     return PCP_ERR_HIP;
@@ -388,7 +425,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -405,6 +442,7 @@ int32_t pcp_model_reset(pcp_ctx* c, uint32_t n_vars, uint32_t set_words) {
   c->props.clear();
   c->unit_of_prop.clear();
   c->n_units = 0;
+  c->sums.clear();
   c->has_groups = false;
   c->hull_set = false;
   c->dirty = true;
@@ -419,9 +457,11 @@ int32_t pcp_model_push_props(pcp_ctx* c, uint32_t n, const pcp_prop* props) {
   }
   for (uint32_t i = 0; i < n; ++i) {
     const pcp_prop& p = props[i];
+    // a unit is a run of members WITHIN ONE CALL: props pushed by an earlier call (or kept by pcp_model_truncate) never
+    // join a later call's group, whatever their `group` value
     bool same_unit = false;
-    if (p.group_kind != 0 && !c->props.empty()) {
-      const pcp_prop& q = c->props.back();
+    if (p.group_kind != 0 && i > 0) {
+      const pcp_prop& q = props[i - 1];
       same_unit = q.group_kind == p.group_kind && q.group == p.group;
     }
     if (!same_unit) ++c->n_units;
@@ -429,6 +469,18 @@ int32_t pcp_model_push_props(pcp_ctx* c, uint32_t n, const pcp_prop* props) {
     c->props.push_back(p);
     c->unit_of_prop.push_back(c->n_units - 1);
   }
+  c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_push_sum(pcp_ctx* c, uint32_t n_members, const uint32_t* vars, uint32_t* term) {
+  if (!c || !vars || !term) return PCP_ERR_ARG;
+  if (n_members == 0) return fail(c, PCP_ERR_CONTRACT, "At least one variable in sum. (term/sum.rs:78)");
+  if (c->sums.size() >= 0x3FFFFFF0u) return fail(c, PCP_ERR_UNSUPPORTED, "too many Sum terms");
+  for (uint32_t i = 0; i < n_members; ++i)
+    if (vars[i] >= c->n_vars) return fail(c, PCP_ERR_CONTRACT, "variable index out of range (variable/store.rs:176-179)");
+  c->sums.emplace_back(vars, vars + n_members);
+  *term = (uint32_t)c->sums.size() - 1;
   c->dirty = true;
   return PCP_OK;
 }
@@ -612,9 +664,13 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
+  a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots};
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
+  // with a declared hull there is no retry launch: a tile outside the hull raises the STICKY violation word (d_retry[1]),
+  // which stays set until pcp_stats_read has reported it — whatever is launched in between
+  if (Bp && c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax) a.retry_flag = c->d_retry + 1;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -659,7 +715,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
-  if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation
+  if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation (d_retry[1])
   if (Bp && !hull_fits16) {
     // the tiles the packed kernel handed back (normally none: every block of this launch returns at once)
     LaunchArgs a2 = a;
@@ -700,7 +756,7 @@ int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const
     return fail(c, PCP_ERR_ARG, "null buffer");
   int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
   if (rc) return rc;
-  if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 16, stream)); return PCP_OK; }
+  if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 20, stream)); return PCP_OK; }
   HIP_TRY(c, launch_branch(n_nodes, c->n_vars, active ? words : 0u, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
   return PCP_OK;
 }
@@ -717,9 +773,10 @@ int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof(pcp_stats), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   uint32_t flag = 0;
-  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_retry, 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
+  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_retry + 1, 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   HIP_TRY(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
-  if (c->trusted_epoch && flag == c->trusted_epoch) {
+  if (flag) {  // some launch since the last read met a node outside the declared hull
+    HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));
     c->trusted_epoch = 0;
     return fail(c, PCP_ERR_CONTRACT, "a node's bounds lie outside the hull declared with pcp_model_set_hull (status PCP_STATUS_HULL)");
   }
@@ -768,6 +825,12 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
     if (c->hull_set && (lb[i] < c->hull_lo || ub[i] > c->hull_hi)) return fail(c, PCP_ERR_CONTRACT, "bound outside the hull declared with pcp_model_set_hull");
   }
   const uint32_t words = ((uint32_t)c->n_units + 63) / 64;
+  if (active && words && (c->n_units & 63)) {
+    // bits at or above n_units name no unit: they would count as "still active" and keep a node from ever being True
+    const uint64_t tail = ~0ull << (c->n_units & 63);
+    for (uint32_t n = 0; n < n_nodes; ++n)
+      if (active[(size_t)n * words + words - 1] & tail) return fail(c, PCP_ERR_ARG, "`active` row has bits set at or above n_units");
+  }
   const size_t dom_bytes = nv * 4, act_bytes = (size_t)n_nodes * words * 8;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t bits_bytes = nv * sw * 8;

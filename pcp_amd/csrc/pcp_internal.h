@@ -54,6 +54,15 @@ static_assert(sizeof(WordDesc) == 32, "WordDesc must be 32 bytes");
 constexpr uint32_t kRangeMax = 64;    // longest slot range a descriptor may cover
 constexpr uint32_t kRangeLevels = 7;  // table levels 2^0 .. 2^6
 
+// term::Sum views (term/sum.rs:56-92): pseudo-slots [first, first + count) whose domain is the interval sum of their member
+// variables, computed on demand; an update through a Sum of several variables never narrows, it only has to overlap.
+struct SumTab {
+  const uint32_t* off;  // [count + 1] into mem
+  const uint32_t* mem;  // member variable indices
+  uint32_t first;       // first sum slot (= n_vars)
+  uint32_t count;       // 0 = the model has no Sum view
+};
+
 struct ModelDev {
   const Rec* recs;          // [n_recs]
   const Rec8* recs8;        // [n_recs] or null when the model is not compactable
@@ -69,6 +78,7 @@ struct ModelDev {
   uint32_t n_slots;  // n_vars + number of interned constants
   uint32_t has_ternary;
   uint32_t uniform_kind;  // the kind shared by ALL records when that is NEQ or LT, else 0xFFFFFFFF (the sweep then classifies each chunk)
+  SumTab sums;            // Sum views; with count > 0 every record takes the generic path (no compact stream, no payloads)
 };
 
 // Both record tables are padded with copies of their last record up to a multiple of 256 records plus kStreamPadRecs, so

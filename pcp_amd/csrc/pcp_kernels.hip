@@ -62,6 +62,19 @@ struct Ctr {  // per-thread counters, reduced once per block
 // ------------------------------------------------------------------------------------------------
 // Domain access policy: node-local (lb,ub) pairs in LDS.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clamp_sum(long long v) {
+  const long long lo = -2147483647LL, hi = 2147483647LL;
+  return (int)(v < lo ? lo : (v > hi ? hi : v));
+}
+// Sum::read (term/sum.rs:76-81): the interval sum of the members' domains, through the policy's own variable load.
+template <class D>
+__device__ __forceinline__ int2 sum_read(const D& dm, const SumTab& t, uint32_t slot) {
+  long long lo = 0, hi = 0;
+  const uint32_t i0 = t.off[slot - t.first], i1 = t.off[slot - t.first + 1];
+  for (uint32_t i = i0; i < i1; ++i) { const int2 d = dm.load_var(t.mem[i]); lo += d.x; hi += d.y; }
+  return make_int2(clamp_sum(lo), clamp_sum(hi));
+}
+
 struct LdsDom {
   int2* dom;        // &dom[0*BP + b]: this node's column of the [slot][BP] array; element = (-lb, ub)
   uint32_t bp;      // row stride in int2 (nodes per block + padding)
@@ -69,14 +82,20 @@ struct LdsDom {
   uint32_t* fail;   // block fail mask
   uint32_t fbit;    // this node's bit in *fail
   Ctr* c;
+  SumTab sums;
 
   // LDS holds (-lb, ub): both narrowings are ds_min, and the sweep's no-op test becomes one v_add3_u32 per bound
   // (see fast_signs).  Bounds are below 2^29 in magnitude, so the negation cannot overflow.
-  __device__ __forceinline__ int2 load(uint32_t v) const { const int2 d = dom[(size_t)v * bp]; return make_int2(-d.x, d.y); }
+  __device__ __forceinline__ int2 load_var(uint32_t v) const { const int2 d = dom[(size_t)v * bp]; return make_int2(-d.x, d.y); }
+  __device__ __forceinline__ bool is_sum(uint32_t v) const { return v - sums.first < sums.count; }
+  __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
+  __device__ __forceinline__ int2 load(uint32_t v) const { return is_sum(v) ? sum_read(*this, sums, v) : load_var(v); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
   // lb := max(lb, nlb).  Called only when nlb exceeds the lb this thread read.
   __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    // Sum::update with several members (term/sum.rs:66-69): no pruning, the new domain only has to overlap the sum
+    if (is_sum(v)) { if (nlb > sum_read(*this, sums, v).y) set_fail(); return; }
     int2* p = dom + (size_t)v * bp;
     const int old = atomicMin(&p->x, -nlb);
     if (old > -nlb) {
@@ -87,6 +106,7 @@ struct LdsDom {
     }
   }
   __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    if (is_sum(v)) { if (nub < sum_read(*this, sums, v).x) set_fail(); return; }
     int2* p = dom + (size_t)v * bp;
     const int old = atomicMin(&p->y, nub);
     if (old > nub) {
@@ -116,6 +136,8 @@ struct LdsDom16 {
   uint32_t fbit;
   Ctr* c;
 
+  // (packed tiles are binary-only models without Sum views: the compact record stream excludes them)
+  __device__ __forceinline__ bool any_sums() const { return false; }
   __device__ __forceinline__ int2 load(uint32_t v) const { return unpack16(dom[(size_t)v * bp]); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
@@ -173,8 +195,18 @@ struct GlobalDom {
   uint32_t* fail;
   uint32_t fbit;
   Ctr* c;
+  SumTab sums;
 
+  __device__ __forceinline__ bool is_sum(uint32_t v) const { return v - sums.first < sums.count; }
+  __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
+  __device__ __forceinline__ int2 load_var(uint32_t v) const {
+    int2 d;
+    d.x = __hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    d.y = __hip_atomic_load(&ub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return d;
+  }
   __device__ __forceinline__ int2 load(uint32_t v) const {
+    if (is_sum(v)) return sum_read(*this, sums, v);
     if (v >= n_vars) return cdom[v - n_vars];
     int2 d;
     d.x = __hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -184,6 +216,7 @@ struct GlobalDom {
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
   __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    if (is_sum(v)) { if (nlb > sum_read(*this, sums, v).y) set_fail(); return; }
     if (v >= n_vars) { if (nlb > cdom[v - n_vars].y) set_fail(); return; }  // Constant::update (term/constant.rs:49-52)
     const int old = atomicMax(&lb[v], nlb);
     if (old < nlb) {
@@ -193,6 +226,7 @@ struct GlobalDom {
     }
   }
   __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    if (is_sum(v)) { if (nub < sum_read(*this, sums, v).x) set_fail(); return; }
     if (v >= n_vars) { if (nub < cdom[v - n_vars].x) set_fail(); return; }
     const int old = atomicMin(&ub[v], nub);
     if (old > nub) {
@@ -253,6 +287,9 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
         else if (v == X.y) { --X.y; dm.lower_ub(x, X.y); }
       }
       if (X.x > X.y || Yl > Yu) dm.set_fail();
+      // An update through a Sum of several variables narrows nothing (term/sum.rs:66-69), so with Sum views in the model
+      // is_subsumed() is evaluated on the domains as they ARE after propagate(), not on the values computed above.
+      if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); Yl = Y.x + d; Yu = Y.y + d; }
       // !XEqY::is_subsumed (x_neq_y.rs:71-73, x_eq_y.rs:87-93): True iff disjoint.
       return (X.x > Yu) || (Yl > X.y);
     } else if (kind == PCP_EQ) {
@@ -263,6 +300,7 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
       if (nl > Yl) dm.raise_lb(y, nl - d);
       if (nu < Yu) dm.lower_ub(y, nu - d);
       if (nl > nu) dm.set_fail();
+      if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); return X.x == X.y && Y.x == Y.y && X.x == Y.x + d; }
       return nl == nu;  // x_eq_y.rs:87-88: both the same singleton
     } else {
       // XLessY::propagate (x_less_y.rs:104-109), both updates from the pre-read values.
@@ -271,6 +309,7 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
       if (nxu < X.y) dm.lower_ub(x, nxu);
       if (nYl > Yl) dm.raise_lb(y, nYl - d);
       if (X.x > nxu || nYl > Yu) dm.set_fail();
+      if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); return X.y < Y.x + d; }
       return nxu < nYl;  // x_less_y.rs:90-91: x.upper() < y.lower()
     }
   }
@@ -278,15 +317,19 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
   int2 X = dm.load(x), Y = dm.load(y), Z = dm.load(z);
   if (kind == PCP_LT3) {
     filter_lt3(X, Y, Z, x, y, z, (long long)d, dm);
+    if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); Z = dm.load(z); }
     return (long long)X.y < (long long)Y.x + Z.x + d;  // x_less_y_plus_z.rs:90-91
   } else if (kind == PCP_GT3) {
     filter_gt3(X, Y, Z, x, y, z, (long long)d, dm);
+    if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); Z = dm.load(z); }
     return (long long)X.x > (long long)Y.y + Z.y + d;  // x_greater_y_plus_z.rs:91-92
   } else if (kind == PCP_EQ3) {
     // XEqYPlusZ = geq.propagate() && leq.propagate() (x_eq_y_plus_z.rs:85-87): leq reads what geq left.
     // geq: (x+1) > y+z  <=>  x > y+z+(d-1);   leq: (x-1) < y+z  <=>  x < y+z+(d+1)   (cmp/mod.rs:62-86)
     filter_gt3(X, Y, Z, x, y, z, (long long)d - 1, dm);
+    if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); Z = dm.load(z); }  // a Sum operand was not narrowed
     filter_lt3(X, Y, Z, x, y, z, (long long)d + 1, dm);
+    if (dm.any_sums()) { X = dm.load(x); Y = dm.load(y); Z = dm.load(z); }
     const bool geq_true = (long long)X.x > (long long)Y.y + Z.y + d - 1;
     const bool leq_true = (long long)X.y < (long long)Y.x + Z.x + d + 1;
     return geq_true && leq_true;  // Kleene and (x_eq_y_plus_z.rs:65-67)
@@ -416,6 +459,7 @@ struct BlockCtx {
   int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
   int32_t* gub;
   uint32_t V;
+  SumTab sums;
 };
 
 template <bool PACKED> struct CellOf { using type = int2; };
@@ -428,11 +472,11 @@ template <bool PACKED> struct DomOf<true, PACKED> { using type = GlobalDom; };
 template <bool GLOBAL, bool PACKED>
 __device__ __forceinline__ typename DomOf<GLOBAL, PACKED>::type make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
   if constexpr (GLOBAL) {
-    return GlobalDom{k.glb, k.gub, static_cast<int2*>(k.dom), k.V, chg_next, &k.misc[M_FAIL], 1u, ctr};  // one node per block
+    return GlobalDom{k.glb, k.gub, static_cast<int2*>(k.dom), k.V, chg_next, &k.misc[M_FAIL], 1u, ctr, k.sums};  // one node per block
   } else if constexpr (PACKED) {
     return LdsDom16{static_cast<uint32_t*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
   } else {
-    return LdsDom{static_cast<int2*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
+    return LdsDom{static_cast<int2*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr, k.sums};
   }
 }
 
@@ -1083,7 +1127,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
       if (a.m.uniform_kind <= PCP_LT) {  // the host has checked the whole table
         ckind = a.m.uniform_kind;
         chunk_fast = shape_ok;
-      } else if (shape_ok) {
+      } else if (shape_ok && a.m.sums.count == 0) {
         uint32_t k_or = 0, k_and = ~0u;
 #pragma unroll
         for (int j = 0; j < kChunk; ++j) {
@@ -1184,7 +1228,7 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
         if (w < w1) {
           const uint32_t kind = rec.xk >> 28;
           const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
-          if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0) {
+          if (!GLOBAL && __all(kind == kind0) && kind0 <= PCP_LT && failm == 0 && a.m.sums.count == 0) {
             const uint64_t alive = readlane64(alive4, j);
             if (alive) {  // some record of this word is live in some node
               if (kind0 == PCP_EQ) {
@@ -1691,6 +1735,8 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
       const uint32_t* cb = cur + (size_t)b * k.Wv;
       bool touched = ((cb[x >> 5] >> (x & 31)) & 1u) | ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u);
       if (tern) touched |= (cb[rec.z >> 5] >> (rec.z & 31)) & 1u;
+      if (a.m.sums.count)  // a Sum operand changes with any of its members: always re-run (conservative)
+        touched |= (x - a.m.sums.first < a.m.sums.count) | (rec.y - a.m.sums.first < a.m.sums.count) | (tern && rec.z - a.m.sums.first < a.m.sums.count);
       const bool mine = ((word >> lane) & 1ull) && touched;
       bool e = false;
       if (mine) {
@@ -1747,7 +1793,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
     if (a.status[node0] != kStatusRetry) return;
   }
-  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V};
+  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V, a.m.sums};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   // adjacency offsets of the variables: an LDS copy behind the carve when the launch has room for it (a round's
@@ -2297,7 +2343,11 @@ struct ConstDom {
   const int32_t* ub;
   const int32_t* cval;
   uint32_t n_vars;
+  SumTab sums;
+  __device__ __forceinline__ int2 load_var(uint32_t v) const { return make_int2(lb[v], ub[v]); }
+  __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
   __device__ __forceinline__ int2 load(uint32_t v) const {
+    if (v - sums.first < sums.count) return sum_read(*this, sums, v);
     if (v >= n_vars) { const int c = cval[v - n_vars]; return make_int2(c, c); }
     return make_int2(lb[v], ub[v]);
   }
@@ -2315,7 +2365,7 @@ __global__ void __launch_bounds__(256) derive_active_kernel(const ModelDev m, co
     const uint32_t r = (w << 6) + lane;
     bool on = false;
     if (r < m.n_recs) {
-      const ConstDom dm{lb + (size_t)node * m.n_vars, ub + (size_t)node * m.n_vars, m.const_val, m.n_vars};
+      const ConstDom dm{lb + (size_t)node * m.n_vars, ub + (size_t)node * m.n_vars, m.const_val, m.n_vars, m.sums};
       on = !eval_record(m.recs[r], dm);
     }
     const uint64_t word = __ballot(on);
@@ -2355,20 +2405,21 @@ __global__ void __launch_bounds__(1024) branch_scan_kernel(const uint8_t* __rest
                                                            uint32_t* __restrict__ counts) {
   __shared__ uint32_t tmp[40];
   __shared__ uint32_t total;
-  uint32_t run = 0, n_true = 0, n_false = 0;
+  uint32_t run = 0, n_true = 0, n_false = 0, n_other = 0;
   for (uint32_t base = 0; base < n_nodes; base += blockDim.x) {
     const uint32_t i = base + threadIdx.x;
     const uint32_t st = i < n_nodes ? status[i] : 255u;
     const uint32_t unk = st == PCP_UNKNOWN ? 1u : 0u;
     n_true += st == PCP_TRUE;
     n_false += st == PCP_FALSE;
+    n_other += (i < n_nodes) && st > PCP_UNKNOWN;  // e.g. PCP_STATUS_HULL: a node the engine refused, neither counted nor branched
     const uint32_t ex = block_exclusive_scan(unk, tmp, &total);
     if (i < n_nodes) child_base[i] = unk ? 2u * (run + ex) : 0xFFFFFFFFu;
     run += total;
     __syncthreads();
   }
-  for (int o = 32; o > 0; o >>= 1) { n_true += __shfl_down(n_true, o); n_false += __shfl_down(n_false, o); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[1], n_true); atomicAdd(&counts[2], n_false); }
+  for (int o = 32; o > 0; o >>= 1) { n_true += __shfl_down(n_true, o); n_false += __shfl_down(n_false, o); n_other += __shfl_down(n_other, o); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&counts[1], n_true); atomicAdd(&counts[2], n_false); if (n_other) atomicAdd(&counts[4], n_other); }
   if (threadIdx.x == 0) { counts[0] = 2u * run; counts[3] = run; }
 }
 
@@ -2425,7 +2476,7 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
                          uint32_t* counts, uint32_t reverse, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(counts, 0, 4 * sizeof(uint32_t), stream);
+  hipError_t e = hipMemsetAsync(counts, 0, 5 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(1024), 0, stream, status, n_nodes, child_base, counts);
   if ((e = hipGetLastError()) != hipSuccess) return e;

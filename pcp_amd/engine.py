@@ -24,7 +24,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 # Every symbol include/pcp_hip.h declares (tests/test_abi.py checks the .so exports each of them).
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
-    "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
+    "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
     "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
@@ -91,6 +91,7 @@ def load_library():
     L.pcp_ctx_destroy.restype = None
     L.pcp_model_reset.argtypes = [vp, u32, u32]
     L.pcp_model_push_props.argtypes = [vp, u32, vp]
+    L.pcp_model_push_sum.argtypes = [vp, u32, vp, C.POINTER(u32)]
     L.pcp_model_truncate.argtypes = [vp, u32]
     L.pcp_model_n_units.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.pcp_model_set_hull.argtypes = [vp, i32, i32]
@@ -102,7 +103,7 @@ def load_library():
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
-    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
+    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
               "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
@@ -143,13 +144,17 @@ class Context:
             raise PcpError(rc, self._L.pcp_last_error(self._h).decode())
 
     # ---- model ------------------------------------------------------------------------------------------
-    def set_model(self, n_vars: int, props: np.ndarray, set_words: int = 0):
+    def set_model(self, n_vars: int, props: np.ndarray, set_words: int = 0, sums=None):
         """pcp_model_reset + pcp_model_push_props.  set_words > 0: IntervalSet<i32> domains (VStoreSet, the reference's default
         FDSpace) carried as bitsets — declare the hull with set_hull(lo, hi) before propagating (value v = bit v - lo)."""
         props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
         self._check(self._L.pcp_model_reset(self._h, n_vars, int(set_words)))
         self.n_vars = int(n_vars)
         self.set_words = int(set_words)
+        for members in (sums or []):  # term::Sum views, numbered in order (pcp_model_push_sum)
+            mv = np.ascontiguousarray(members, np.uint32)
+            t = C.c_uint32()
+            self._check(self._L.pcp_model_push_sum(self._h, len(mv), _np_ptr(mv), C.byref(t)))
         self.push_props(props)
 
     def push_props(self, props: np.ndarray):

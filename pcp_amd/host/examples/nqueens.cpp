@@ -1,9 +1,12 @@
-// nqueens.cpp — the reference's example/src/nqueens.rs:28-74 written against pcp_host.hpp: the model code is the
-// reference's, line for line (variables in [1,n]; for i<j  q_i != q_j + (j-i),  q_i != q_j - (j-i); join_distinct),
-// the propagation fixpoint of every search node runs on the MI355X through libpcp_hip.so.
+// nqueens.cpp — the model of the reference's example (example/src/nqueens.rs:28-74) written against pcp_host.hpp with the
+// reference's constructor names (variables in [1,n]; for i<j  q_i != q_j + (j-i),  q_i != q_j - (j-i); join_distinct); the
+// propagation fixpoint of every search node runs on the MI355X through libpcp_hip.so.  NOTE: this host mirror allocates
+// Interval<i32> domains (VStoreFD); the reference's example runs FDSpace = IntervalSet domains (nqueens.rs:34), which the
+// engine offers as set mode (pcp_model_reset(set_words > 0)) — same solutions, a different (smaller) search tree.
 //
 //   nqueens <n>                 first solution with the default engine (one_solution_engine, search/mod.rs:45-52)
 //   nqueens <n> all [limit]     all solutions (AllSolution), optional StopNode(limit)
+//   nqueens restore-test        label / alloc(x < y) / consistency / restore / alloc(x > y) / consistency on one GpuCStore
 // Prints one JSON line: {"n":..,"status":..,"solutions":..,"nodes":..,"failed":..,"filter_steps":..,"first":[..]}
 #include <cstdio>
 #include <cstdlib>
@@ -13,27 +16,43 @@
 
 using namespace pcp_host;
 
+// FrozenStore::restore followed by a different propagator at the same index (propagation/store.rs:306-324): the device model
+// must follow the host's truncation.
+static int restore_test() {
+  Space space(0);
+  Var x = space.vstore.alloc(Interval(0, 9)), y = space.vstore.alloc(Interval(0, 9));
+  const std::vector<int32_t> lb0 = space.vstore.lbs(), ub0 = space.vstore.ubs();
+  const GpuCStore::Label l = space.cstore.label();
+  space.cstore.alloc(XLessY(x, y));
+  space.consistency();
+  printf("{\"first\": [[%d, %d], [%d, %d]], ", space.vstore[0].lower(), space.vstore[0].upper(), space.vstore[1].lower(), space.vstore[1].upper());
+  space.vstore.lbs() = lb0; space.vstore.ubs() = ub0;
+  space.cstore.restore(l);
+  space.cstore.alloc(x_greater_y(x, y));
+  space.consistency();
+  printf("\"second\": [[%d, %d], [%d, %d]]}\n", space.vstore[0].lower(), space.vstore[0].upper(), space.vstore[1].lower(), space.vstore[1].upper());
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "restore-test")) {
+    try { return restore_test(); } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
+  }
   const int n = argc > 1 ? atoi(argv[1]) : 8;
   const bool all = argc > 2 && !strcmp(argv[2], "all");
   const uint64_t limit = argc > 3 ? strtoull(argv[3], nullptr, 10) : 0;
   try {
     Space space(0);
     std::vector<Var> queens;
-    // 2 queens can't share the same line.
     for (int i = 0; i < n; ++i) queens.push_back(space.vstore.alloc(Interval(1, n)));
     for (int i = 0; i + 1 < n; ++i) {
       for (int j = i + 1; j < n; ++j) {
-        // 2 queens can't share the same diagonal.
-        const int q1 = i + 1, q2 = j + 1;
-        // Xi + i != Xj + j reformulated as: Xi != Xj + j - i
+        const int q1 = i + 1, q2 = j + 1;  // the two diagonals (nqueens.rs:37-47)
         space.cstore.alloc(XNeqY(queens[i], addition(queens[j], q2 - q1)));
-        // Xi - i != Xj - j reformulated as: Xi != Xj - j + i
         space.cstore.alloc(XNeqY(queens[i], addition(queens[j], -q2 + q1)));
       }
     }
-    // 2 queens can't share the same column.
-    if (n > 0) join_distinct(space.vstore, space.cstore, queens);
+    if (n > 0) join_distinct(space.vstore, space.cstore, queens);  // the columns (nqueens.rs:50)
 
     Statistics st;
     std::vector<int32_t> first;

@@ -198,6 +198,14 @@ class GpuCStore {
   void restore(const Label& l) {  // store.rs:319-323
     units_.resize(l.first);
     active_ = l.second;
+    // device-side units that no longer exist on the host: a unit allocated later at the same index is a DIFFERENT
+    // propagator, so the device model is truncated with the host's (sync_model compares unit indices only)
+    size_t keep = 0;
+    while (keep < dev_units_.size() && dev_units_[keep] < l.first) ++keep;
+    if (keep < dev_units_.size()) {
+      check(pcp_model_truncate(ctx_, (uint32_t)keep));
+      dev_units_.resize(keep);
+    }
   }
 
   SKleene consistency(VStore& vs) {  // Consistency::consistency, propagation/store.rs:247-257

@@ -25,6 +25,7 @@ import numpy as np
 
 PCP_CONST = 0xFFFFFFFF
 PCP_NOVAR = 0xFFFFFFFE
+PCP_SUM = 0xC0000000
 PCP_BOUND_MAX = 0x1FFFFFFF
 
 NEQ, EQ, LT, LT3, GT3, EQ3, MUL3 = range(7)
@@ -70,7 +71,18 @@ class Constant:
         return (PCP_CONST, self.value)
 
 
-View = Union[Identity, Addition, Constant]
+@dataclass(frozen=True)
+class Sum:
+    """term::Sum (term/sum.rs:56-92): read = the interval sum of the members; an update through a Sum of several variables
+    only has to overlap (no pruning).  Members may be Identity / Addition / Constant views: their variables become the term,
+    their constants fold into the operand's offset.  Lowered through ``lower_units(..., sums_out=[...])``."""
+    vars: Tuple["View", ...]
+
+    def flat(self):
+        raise ContractViolation("a Sum view is lowered by lower_units(..., sums_out=list)")
+
+
+View = Union[Identity, Addition, Constant, Sum]
 
 
 # ------------------------------------------------------------------------------------------ propagators
@@ -248,8 +260,41 @@ def join_distinct(vstore: VStore, cstore: CStore, vars: Sequence[View]) -> None:
             cstore.alloc(XNeqY(vars[i], vars[j]))
 
 
-def lower_units(units: Sequence[Union[Elementary, Conjunction]], n_vars: int) -> np.ndarray:
-    """Flatten units to pcp_prop rows.  Checks what the reference would panic on."""
+def _flat_operand(op, sums_out):
+    """(var code, offset) of a view; Sum views are appended to sums_out (their members' variable indices) and referred to as
+    PCP_SUM | term.  Also returns the variables the operand subscribes to."""
+    extra = 0
+    while isinstance(op, Addition) and isinstance(_base(op), Sum):
+        extra += op.v
+        op = op.x
+    if isinstance(op, Sum):
+        if sums_out is None:
+            raise ContractViolation("the model has Sum views: pass sums_out=[] to lower_units and give it to set_model(..., sums=)")
+        if len(op.vars) == 0:
+            raise ContractViolation("At least one variable in sum.")
+        members, const = [], 0
+        for m in op.vars:
+            var, off = m.flat()
+            const += off
+            if var != PCP_CONST:
+                members.append(var)
+        if not members:
+            return PCP_CONST, const + extra, []
+        sums_out.append(members)
+        return PCP_SUM | (len(sums_out) - 1), const + extra, members
+    var, off = op.flat()
+    return var, off, ([] if var == PCP_CONST else [var])
+
+
+def _base(op):
+    while isinstance(op, Addition):
+        op = op.x
+    return op
+
+
+def lower_units(units: Sequence[Union[Elementary, Conjunction]], n_vars: int, gid_base: int = 0, sums_out=None) -> np.ndarray:
+    """Flatten units to pcp_prop rows.  Checks what the reference would panic on.  `group` = gid_base + the unit's position
+    (the engine only compares it between consecutive rows of one push)."""
     n_rows = sum(max(1, len(u.rows())) for u in units)
     out = np.zeros(n_rows, dtype=PROP_DTYPE)
     out["var"][:] = PCP_NOVAR
@@ -266,20 +311,20 @@ def lower_units(units: Sequence[Union[Elementary, Conjunction]], n_vars: int) ->
             rec = out[r]
             rec["kind"] = kind
             rec["group_kind"] = u.group_kind if grouped else 0
-            rec["group"] = gid
+            rec["group"] = gid_base + gid
             seen = set()
             for k, op in enumerate(ops):
-                var, off = op.flat()
+                var, off, deps = _flat_operand(op, sums_out)
                 if abs(off) > PCP_BOUND_MAX:
                     raise ContractViolation("offset outside +-PCP_BOUND_MAX")
-                if var != PCP_CONST:
-                    if not (0 <= var < n_vars):
-                        raise ContractViolation(f"variable {var} is not in the vstore (size {n_vars})")
-                    if var in seen:
+                for dv in deps:
+                    if not (0 <= dv < n_vars):
+                        raise ContractViolation(f"variable {dv} is not in the vstore (size {n_vars})")
+                    if dv in seen:
                         # the reactor would panic: "propagator already subscribed to this variable"
                         # (propagation/reactors/indexed_deps.rs:69-77)
                         raise ContractViolation("propagator already subscribed to this variable")
-                    seen.add(var)
+                    seen.add(dv)
                 rec["var"][k] = var
                 rec["off"][k] = off
             seen_unit |= seen

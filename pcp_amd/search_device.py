@@ -52,7 +52,7 @@ class DeviceSearch:
         self.implicit = bool(implicit) or not ctx.words
         self.act = None if self.implicit else torch.empty((self.cap, W), dtype=i64, device=self.dev)
         self.status = torch.zeros(self.batch, dtype=u8, device=self.dev)
-        self.counts = torch.zeros(4, dtype=i32, device=self.dev)
+        self.counts = torch.zeros(5, dtype=i32, device=self.dev)
         self.segs: List[List[int]] = []  # [start, length], bottom to top
         self.stats = DeviceSearchStats()
 
@@ -144,7 +144,9 @@ class DeviceSearch:
             ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream)
             ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
                               self.counts, stream)
-            n_children, n_true, n_false, _ = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
+            n_children, n_true, n_false, _, n_other = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
+            if n_other:
+                raise RuntimeError(f"{n_other} nodes were refused by the engine (bounds outside the declared hull): the search cannot continue")
             rounds += 1
             st.rounds += 1
             st.num_nodes += n

@@ -52,6 +52,30 @@ def nqueens_deep(ctx, n: int, dive: int, nodes: int, rounds: int = 14, implicit:
     return lb.clone(), ub.clone(), (None if act is None else act.clone())
 
 
+def nqueens_frontier_set(ctx, n: int, nodes: int, max_rounds: int = 64):
+    """The N-queens-n frontier over FDSpace (IntervalSet domains, what example/src/nqueens.rs:28-50 really allocates): breadth-first
+    from the root with set-mode propagation (`ctx` holds the model with set_words = ceil(n/64) and the hull [1, n]) until `nodes`
+    open, implicit-active, nodes exist.  Returns their folded sets [nodes, n, set_words] (tree order) and the node / failure
+    counts of the expansion."""
+    from . import search as S
+    sw = ctx.set_words
+    B = M.interval_bits(np.ones(n, np.int64), np.full(n, n, np.int64), sw, 1)[None]
+    n_nodes = n_failed = 0
+    for _ in range(max_rounds):
+        if B.shape[0] >= nodes or B.shape[0] == 0:
+            break
+        ok = B.any(axis=2).all(axis=1)
+        n_failed += int((~ok).sum())
+        B = B[ok]
+        lb, ub, bits, _, status, _ = ctx.propagate_set(B, None)
+        n_nodes += B.shape[0]
+        n_failed += int((status == M.FALSE).sum())
+        unk = status == M.UNKNOWN
+        B, _ = S.branch_set(bits[unk], lb[unk], ub[unk], 1, None)
+    ok = B.any(axis=2).all(axis=1)
+    return B[ok][:nodes], n_nodes, n_failed
+
+
 # ---------------------------------------------------------------------------------------------------------------- C3
 def planted_binary_csp(seed, n_vars=50_000, n_props=500_000, dom=(0, 999)):
     """BASELINE config 3 generator, vectorised: binary props `x ◇ y + c`, endpoints uniform

@@ -193,10 +193,22 @@ def test_declared_hull(ctx):
     t_st = torch.zeros(N, dtype=torch.uint8, device=dev)
     ctx.stats_reset()
     ctx.propagate_device(N, t_lb, t_ub, t_lb, t_ub, t_act, t_act, t_st)
+    st = t_st.cpu().numpy().copy()
+    # the violation is STICKY: a clean launch in between must not make the engine forget it, and pcp_branch_device counts
+    # the refused nodes in counts[4]
+    c_lb = torch.empty((2 * N, V), dtype=torch.int32, device=dev); c_ub = torch.empty_like(c_lb)
+    c_act = torch.empty((2 * N, t_act.shape[1]), dtype=torch.int64, device=dev)
+    counts = torch.zeros(5, dtype=torch.int32, device=dev)
+    ctx.branch_device(N, t_lb, t_ub, t_act, t_st, c_lb, c_ub, c_act, counts)
+    torch.cuda.synchronize()
+    assert counts.cpu().tolist()[4] == 16
+    t2_lb, t2_ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+    t2_st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    ctx.propagate_device(N, t2_lb, t2_ub, t2_lb, t2_ub, None, None, t2_st)
     with pytest.raises(E.PcpError) as ei:
         ctx.stats_read()
     assert ei.value.code == -2
-    st = t_st.cpu().numpy()
+    ctx.stats_read()  # reported once, then cleared
     assert (st[32:48] == 0xFE).all() and (st[:32] != 0xFE).all() and (st[48:] != 0xFE).all()
     assert np.array_equal(t_lb.cpu().numpy()[32:48], Ld[32:48])
     ok = np.ones(N, bool); ok[32:48] = False
@@ -440,10 +452,11 @@ def test_device_branching_matches_host_branching(ctx):
     c_lb = torch.empty((2 * N, V), dtype=torch.int32, device=dev)
     c_ub = torch.empty_like(c_lb)
     c_act = torch.empty((2 * N, W), dtype=torch.int64, device=dev)
-    counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    counts = torch.zeros(5, dtype=torch.int32, device=dev)
     ctx.branch_device(N, d_lb, d_ub, d_act, d_st, c_lb, c_ub, c_act, counts)
     torch.cuda.synchronize()
-    nc, nt, nf, nu = counts.cpu().tolist()
+    nc, nt, nf, nu, n_other = counts.cpu().tolist()
+    assert n_other == 0
     assert (nc, nt, nf, nu) == (2 * int(unk.sum()), int((status == 1).sum()), int((status == 0).sum()), int(unk.sum()))
     assert np.array_equal(c_lb[:nc].cpu().numpy(), hl) and np.array_equal(c_ub[:nc].cpu().numpy(), hu)
     assert np.array_equal(c_act[:nc].cpu().numpy().view(np.uint64), ha)
@@ -528,6 +541,9 @@ def test_cpp_host_mirror_nqueens():
         assert out["solutions"] == counts[n - 1] and out["nodes"] == ss["num_nodes"] and out["failed"] == ss["num_failed_node"]
     out = json.loads(subprocess.run([exe, "6", "all", "10"], check=True, capture_output=True, text=True).stdout)
     assert out["nodes"] == 10 and out["status"] == "EndOfSearch"  # search/stop_node.rs:82-104
+    # label / alloc(x < y) / consistency / restore / alloc(x > y) / consistency must propagate x > y, not the stale x < y
+    out = json.loads(subprocess.run([exe, "restore-test"], check=True, capture_output=True, text=True).stdout)
+    assert out == {"first": [[0, 8], [1, 9]], "second": [[1, 9], [0, 8]]}
 
 
 def test_contract_errors(ctx):
@@ -545,6 +561,28 @@ def test_contract_errors(ctx):
     with pytest.raises(E.PcpError) as e:
         ctx.set_model(2, same)
     assert e.value.code == -2
+
+
+def test_units_never_join_across_pushes_and_active_tail_bits(ctx):
+    """two Conjunction units pushed by two calls with the same `group` value stay two units; `active` rows with
+    bits at or above n_units are rejected."""
+    V = 4
+    u1 = M.Conjunction((M.XLessY(M.Identity(0), M.Identity(1)), M.XLessY(M.Identity(1), M.Identity(2))))
+    u2 = M.Conjunction((M.XNeqY(M.Identity(2), M.Identity(3)), M.XLessY(M.Identity(0), M.Identity(3))))
+    p1, p2 = M.lower_units([u1], V), M.lower_units([u2], V)  # both carry group 0, group_kind 1
+    ctx.set_model(V, p1)
+    ctx.push_props(p2)
+    assert ctx.n_units == 2
+    both = np.concatenate([p1, M.lower_units([u2], V, gid_base=1)])
+    om = orc.OracleModel(V, both)
+    assert om.n_units == 2
+    lb, ub = np.zeros((1, V), np.int32), np.full((1, V), 3, np.int32)
+    ref = om.consistency(lb, ub, None)
+    got = ctx.propagate(lb, ub, E.full_active(1, 2))
+    assert_parity(ref[:4], got[:4], "two pushes, same gid")
+    with pytest.raises(E.PcpError) as e:
+        ctx.propagate(lb, ub, np.array([[0b111]], np.uint64))
+    assert e.value.code == -1
 
 
 def test_truncate_mirrors_restore(ctx):
