@@ -1,0 +1,113 @@
+//! Raw bindings of `include/pcp_hip.h` (ABI v3): one line per exported symbol, `#[repr(C)]` mirrors of its structs.
+//! Every entry point cites the libpcp item it replaces in the header; the safe layer is `pcp-gpu-cstore`.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub const PCP_ABI_VERSION: u32 = 3;
+pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
+pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
+pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
+pub const PCP_BOUND_MAX: i32 = 0x1FFF_FFFF;
+pub const PCP_STATUS_HULL: u8 = 0xFE;
+
+pub const PCP_OK: i32 = 0;
+pub const PCP_ERR_ARG: i32 = -1;
+pub const PCP_ERR_CONTRACT: i32 = -2; // a libpcp assert! would have fired
+pub const PCP_ERR_HIP: i32 = -3;
+pub const PCP_ERR_NOMEM: i32 = -4;
+pub const PCP_ERR_UNSUPPORTED: i32 = -5;
+pub const PCP_ERR_NODEVICE: i32 = -6; // there is no CPU fallback
+
+// pcp_kind
+pub const PCP_NEQ: u8 = 0;
+pub const PCP_EQ: u8 = 1;
+pub const PCP_LT: u8 = 2;
+pub const PCP_LT3: u8 = 3;
+pub const PCP_GT3: u8 = 4;
+pub const PCP_EQ3: u8 = 5;
+pub const PCP_MUL3: u8 = 6;
+// pcp_status == trilean::SKleene
+pub const PCP_FALSE: u8 = 0;
+pub const PCP_TRUE: u8 = 1;
+pub const PCP_UNKNOWN: u8 = 2;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct pcp_prop {
+    pub kind: u8,
+    pub group_kind: u8, // 0 standalone, 1 Conjunction member, 2 Distinct member
+    pub reserved: u16,
+    pub group: u32,
+    pub var: [u32; 3],
+    pub off: [i32; 3],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct pcp_stats {
+    pub steps: u64,
+    pub steps3: u64,
+    pub narrowings: u64,
+    pub waves: u64,
+    pub failed_nodes: u64,
+    pub nodes: u64,
+    pub evaluated: u64,
+    pub full_evals: u64,
+}
+
+#[repr(C)]
+pub struct pcp_device_batch {
+    pub lb_in: *const i32,
+    pub ub_in: *const i32,
+    pub lb_out: *mut i32,
+    pub ub_out: *mut i32,
+    pub active_in: *const u64, // NULL = every unit active = implicit-active nodes
+    pub active_out: *mut u64,
+    pub status: *mut u8,
+    pub bits_in: *const u64, // set mode only
+    pub bits_out: *mut u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct pcp_plan {
+    pub nodes_per_block: u32,
+    pub team: u32,
+    pub packed: u32,
+    pub word_level: u32,
+    pub global_dom: u32,
+    pub compact: u32,
+    pub implicit_active: u32,
+    pub set_mode: u32,
+    pub grid: u32,
+    pub block: u32,
+    pub lds_bytes: u32,
+    pub list_cap: u32,
+}
+
+pub enum pcp_ctx {}
+
+extern "C" {
+    pub fn pcp_abi_version() -> u32;
+    pub fn pcp_strerror(err: i32) -> *const c_char;
+    pub fn pcp_ctx_create(hip_device: i32, out: *mut *mut pcp_ctx) -> i32;
+    pub fn pcp_ctx_destroy(ctx: *mut pcp_ctx);
+    pub fn pcp_last_error(ctx: *const pcp_ctx) -> *const c_char;
+    pub fn pcp_model_reset(ctx: *mut pcp_ctx, n_vars: u32, set_words: u32) -> i32; // Store::empty
+    pub fn pcp_model_push_props(ctx: *mut pcp_ctx, n: u32, props: *const pcp_prop) -> i32; // Store::alloc
+    pub fn pcp_model_push_sum(ctx: *mut pcp_ctx, n_members: u32, vars: *const u32, term: *mut u32) -> i32; // Sum::new
+    pub fn pcp_model_truncate(ctx: *mut pcp_ctx, n_units: u32) -> i32; // FrozenStore::restore
+    pub fn pcp_model_n_units(ctx: *const pcp_ctx, n_units: *mut u32, n_props: *mut u32) -> i32;
+    pub fn pcp_model_set_hull(ctx: *mut pcp_ctx, lo: i32, hi: i32) -> i32; // hull of the VStore::alloc domains
+    pub fn pcp_propagate(ctx: *mut pcp_ctx, n_nodes: u32, lb: *mut i32, ub: *mut i32, bits: *mut u64, active: *mut u64,
+                         status: *mut u8, stats: *mut pcp_stats) -> i32; // Consistency::consistency
+    pub fn pcp_propagate_device(ctx: *mut pcp_ctx, n_nodes: u32, batch: *const pcp_device_batch, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_branch_device(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
+                             child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, counts: *mut u32,
+                             hip_stream: *mut c_void) -> i32; // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter
+    pub fn pcp_stats_reset(ctx: *mut pcp_ctx, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_stats_read(ctx: *mut pcp_ctx, out: *mut pcp_stats, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_last_kernel_ms(ctx: *mut pcp_ctx, ms: *mut f32) -> i32;
+    pub fn pcp_last_plan(ctx: *const pcp_ctx, out: *mut pcp_plan) -> i32;
+    pub fn pcp_set_option(ctx: *mut pcp_ctx, key: *const c_char, value: i64) -> i32;
+}

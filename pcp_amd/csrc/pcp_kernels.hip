@@ -393,6 +393,12 @@ __device__ __forceinline__ uint64_t writelane64(uint64_t old, uint64_t v, uint32
 // node pairs are 16-byte aligned (one ds_read_b128 reads two nodes), and consecutive slots are (B+2)*8 bytes
 // = 12/20/28/36 banks apart for B = 4/8/12/16, so 16 consecutive slots start on 16 distinct 4-bank groups.
 constexpr uint32_t kSummMinTile = 4;  // tiles of at least this many nodes keep per-slot summaries
+// Packed summary / range tables are indexed through tsw(): one padding dword after every 64 slots.  The level -1 test reads
+// T[k][ylo] with ylo = y0 + 64 * lane (consecutive words of an x-block cover consecutive 64-slot y ranges): without the
+// padding all lanes of a wavefront hit ONE LDS bank (measured: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 64 %, the whole
+// sweep of a near-root tile was that serialisation); with it the stride is 65 dwords and the lanes spread over all banks.
+__host__ __device__ inline uint32_t tsw(uint32_t v) { return v + (v >> 6); }
+__host__ __device__ inline uint32_t tsw_slots(uint32_t slots) { return slots + (slots >> 6) + 1u; }
 __host__ __device__ inline uint32_t rmq_levels(uint32_t word_level, bool max_table) {
   return word_level == 0 ? 1u : ((max_table && word_level < 2) ? 1u : kRangeLevels);
 }
@@ -414,7 +420,7 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   // tile summaries (level-0 test of the sweep): two cells per slot, (min -lb, min ub) and (max -lb, max ub) over the nodes
   // packed tiles keep them as two tables Tmin[levels][slots], Tmax[levels][slots] of dwords; with the word-group sweep
   // levels 1..5 hold the minima / maxima over 2^level consecutive slots (range queries of the level -1 test).
-  c.summ = o; o = up(o + (B >= kSummMinTile ? (packed ? (size_t)dom_slots * 4 * (rmq_levels(word_level, false) + rmq_levels(word_level, true))
+  c.summ = o; o = up(o + (B >= kSummMinTile ? (packed ? (size_t)tsw_slots(dom_slots) * 4 * (rmq_levels(word_level, false) + rmq_levels(word_level, true))
                                                      : (size_t)dom_slots * 2 * 8) : 0));
   c.chg_a = o; o = up(o + (size_t)B * Wv * 4);
   c.chg_b = o; o = up(o + (size_t)B * Wv * 4);
@@ -453,7 +459,7 @@ struct BlockCtx {
   void* dom;    // LDS domains [slot][bp]: int2 (-lb,ub), or packed dwords; global variant: the constants' singletons [slot - n_vars]
   uint32_t bp;  // row stride of dom, in cells
   SummPtr summ; // LDS tile summaries (B >= kSummMinTile)
-  uint32_t rmq_stride;  // packed: dwords between two levels of a table (= slots)
+  uint32_t rmq_stride;  // packed: dwords between two levels of a table (= tsw_slots(slots))
   uint32_t S, Wv;
   uint32_t* misc;
   int32_t* glb;  // global variant: this block's node rows in lb_out / ub_out
@@ -965,7 +971,7 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
     if constexpr (IMPLICIT && KIND == PCP_NEQ) {
       uint32_t xn[4], xx[4], yn[4], yx[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { xn[j] = tmin[x[j]]; xx[j] = tmax[x[j]]; yn[j] = tmin[y[j]]; yx[j] = tmax[y[j]]; }
+      for (int j = 0; j < 4; ++j) { xn[j] = tmin[tsw(x[j])]; xx[j] = tmax[tsw(x[j])]; yn[j] = tmin[tsw(y[j])]; yx[j] = tmax[tsw(y[j])]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint32_t tlo, thi;
@@ -976,7 +982,7 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
     } else if (KIND == PCP_NEQ) {  // only the minima: (Xn + Yu, Xu + Yn) in one packed add
       uint32_t xs[4], ys[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { xs[j] = tmin[x[j]]; ys[j] = tmin[y[j]]; }
+      for (int j = 0; j < 4; ++j) { xs[j] = tmin[tsw(x[j])]; ys[j] = tmin[tsw(y[j])]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint32_t t;
@@ -986,7 +992,7 @@ __device__ __forceinline__ void level0_chunk(int (&o)[4], const SummPtr sp, cons
     } else {
       uint32_t xn[4], xx[4], yn[4], yx[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { xn[j] = tmin[x[j]]; xx[j] = tmax[x[j]]; yn[j] = tmin[y[j]]; yx[j] = tmax[y[j]]; }
+      for (int j = 0; j < 4; ++j) { xn[j] = tmin[tsw(x[j])]; xx[j] = tmax[tsw(x[j])]; yn[j] = tmin[tsw(y[j])]; yx[j] = tmax[tsw(y[j])]; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c1 = d[j] - 1, c3 = -d[j];
@@ -1423,8 +1429,8 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     auto part_fails = [&](const WordPart q) -> bool {
       const uint32_t cls = (q.k >> 8) & 15u;
       const uint32_t kx = q.k & 15u, ky = (q.k >> 4) & 15u;
-      const uint32_t xa = __umul24(kx, S) + (q.x & 0xffffu), xb = __umul24(kx, S) + (q.x >> 16);
-      const uint32_t ya = __umul24(ky, S) + (q.y & 0xffffu), yb = __umul24(ky, S) + (q.y >> 16);
+      const uint32_t xa = __umul24(kx, S) + tsw(q.x & 0xffffu), xb = __umul24(kx, S) + tsw(q.x >> 16);
+      const uint32_t ya = __umul24(ky, S) + tsw(q.y & 0xffffu), yb = __umul24(ky, S) + tsw(q.y >> 16);
       const uint32_t Xn = pk_min(tmin[xa], tmin[xb]), Yn = pk_min(tmin[ya], tmin[yb]);  // (min -lb, min ub) over the range
       const int dmin = lo16(q.d), dmax = hi16(q.d);
       if constexpr (IMPLICIT) {
@@ -1528,8 +1534,9 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
         if (t == (uint32_t)u) { ww = pend[u]; rsel = rb[u]; col = cb[u]; }
       if (PCP_ABLATE & 4096) continue;  // profiling: nothing per word
       // alive_w: OR of the column over the nodes (lanes 0..B-1 sit in one DPP row)
-      const uint64_t alive_w = ((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(col >> 32))) << 32) |
-                               __builtin_amdgcn_readfirstlane(row_or16((uint32_t)col));
+      const uint64_t alive_w = IMPLICIT ? ((ww == words - 1) ? tail_mask : ~0ull)
+                                        : (((uint64_t)__builtin_amdgcn_readfirstlane(row_or16((uint32_t)(col >> 32))) << 32) |
+                                           __builtin_amdgcn_readfirstlane(row_or16((uint32_t)col)));
       const Rec rec = expand(rsel);
       const uint32_t kind = rec.xk >> 28;
       const uint32_t kind0 = __builtin_amdgcn_readfirstlane(kind);
@@ -1546,7 +1553,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
           // level 0 on the per-slot summaries, then level 1 on every node
           int o0;
           if constexpr (IMPLICIT) {
-            const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y], xx = tmax[rec.xk & kSlotMask], yx = tmax[rec.y];
+            const uint32_t xs = tmin[tsw(rec.xk & kSlotMask)], ys = tmin[tsw(rec.y)], xx = tmax[tsw(rec.xk & kSlotMask)], yx = tmax[tsw(rec.y)];
             if (kind0 == PCP_NEQ) {
               uint32_t tlo, thi;
               asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tlo) : "v"(xs), "v"(ys));
@@ -1556,20 +1563,30 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
               o0 = (hi16(ys) - hi16(xx) + rec.d - 1) | (lo16(xs) - lo16(yx) + rec.d - 1);
             }
           } else {
-            const uint32_t xs = tmin[rec.xk & kSlotMask], ys = tmin[rec.y];
+            const uint32_t xs = tmin[tsw(rec.xk & kSlotMask)], ys = tmin[tsw(rec.y)];
             if (kind0 == PCP_NEQ) {
               uint32_t t2;
               asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(t2) : "v"(xs), "v"(ys));
               o0 = (lo16(t2) + (rec.d - 1)) | (hi16(t2) + (-rec.d - 1));
             } else {
-              const uint32_t xx = tmax[rec.xk & kSlotMask], yx = tmax[rec.y];
+              const uint32_t xx = tmax[tsw(rec.xk & kSlotMask)], yx = tmax[tsw(rec.y)];
               o0 = (hi16(ys) - hi16(xx) + rec.d - 1) | (lo16(xs) - lo16(yx) + rec.d - 1) | (hi16(xs) + lo16(ys) - rec.d);
             }
           }
           run2 = (__ballot(o0 < 0) & alive_w) != 0;
           if (PCP_ABLATE & 2048) run2 = false;  // profiling: stop after level 0
-          // (no level 1 here: of the words that level -1 AND level 0 leave over, 97 % go on to level 2 anyway, which
-          // decides node by node at about the same cost)
+          // Explicit rows: no level 1 here — of the words that level -1 AND level 0 leave over, 97 % go on to level 2 anyway
+          // (their entailed lanes have to be unlinked), which decides node by node at about the same cost.
+          // Implicit nodes: level 1 over all nodes of the tile first.  Only a lane that can narrow matters, and the words
+          // that reach this point are mostly those of assigned variables whose records are entailed or untouched: the
+          // zero-detection test clears them for the whole tile in one pass.
+          if constexpr (IMPLICIT) {
+            if (run2) {
+              const int o1 = (kind0 == PCP_NEQ) ? fast_signs16<PCP_NEQ, B, true>(px, py, rec.d) : fast_signs16<PCP_LT, B, true>(px, py, rec.d);
+              ctr.ev += (uint32_t)__popcll(col);  // lane b < nb: the pairs of node b (the column register)
+              run2 = (__ballot(o1 < 0) & alive_w) != 0;
+            }
+          }
           if ((PCP_ABLATE & 128) && run2) { ++n_l1; ++n_l2; }
         }
         if (run2) {
@@ -1593,7 +1610,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
               for (int jj = 0; jj < 4; ++jj) {
                 const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
                 if (wd == 0) continue;
-                ctr.add_ev_uniform((uint32_t)__popcll(wd));
+                if (!IMPLICIT) ctr.add_ev_uniform((uint32_t)__popcll(wd));
                 if constexpr (IMPLICIT) {
                   // (t1, t2) = X + swap(Y) + (d, -d): a lane can narrow only where one of them is zero
                   uint32_t Uz;
@@ -1625,7 +1642,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
               for (int jj = 0; jj < 4; ++jj) {
                 const uint64_t wd = readlane64(col, (uint32_t)(g4 + jj));
                 if (wd == 0) continue;
-                ctr.add_ev_uniform((uint32_t)__popcll(wd));
+                if (!IMPLICIT || kind0 == PCP_EQ) ctr.add_ev_uniform((uint32_t)__popcll(wd));
                 const int2 X = unpack16(xs[jj]), Y = unpack16(ys[jj]);
                 uint64_t f, en = 0;
                 if (kind0 == PCP_LT) { f = fast_flag<PCP_LT, IMPLICIT>(X, Y.x + rec.d, Y.y + rec.d); if (!IMPLICIT) en = pure_entailed<PCP_LT>(X, Y.x + rec.d, Y.y + rec.d); }
@@ -1793,7 +1810,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
     if (a.status[node0] != kStatusRetry) return;
   }
-  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * S * rmq_levels(PACKED ? a.word_level : 0, false)}, S, S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V, a.m.sums};
+  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * tsw_slots(S) * rmq_levels(PACKED ? a.word_level : 0, false)}, tsw_slots(S), S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V, a.m.sums};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   // adjacency offsets of the variables: an LDS copy behind the carve when the launch has room for it (a round's
@@ -1860,7 +1877,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     // tile summaries for the sweep's level-0 test: per slot (min -lb, min ub) and (max -lb, max ub) over the tile's nodes
     if constexpr (PACKED) {
       uint32_t* tmin = reinterpret_cast<uint32_t*>(smem + cv.summ);
-      uint32_t* tmax = tmin + (size_t)S * rmq_levels(a.word_level, false);
+      const uint32_t Sp = tsw_slots(S);
+      uint32_t* tmax = tmin + (size_t)Sp * rmq_levels(a.word_level, false);
       for (uint32_t v = tid; v < S; v += nth) {
         uint32_t mn = 0x7fff7fffu, mx = 0x80008000u;
 #pragma unroll
@@ -1869,7 +1887,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           mn = pk_min(pk_min(mn, q.x), pk_min(q.y, pk_min(q.z, q.w)));
           mx = pk_max(pk_max(mx, q.x), pk_max(q.y, pk_max(q.z, q.w)));
         }
-        tmin[v] = mn; tmax[v] = mx;
+        tmin[tsw(v)] = mn; tmax[tsw(v)] = mx;
       }
       // range tables of the level -1 test: level l holds the minimum (maximum) over slots [v, v + 2^l)
       if (a.word_level) {
@@ -1877,8 +1895,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
           __syncthreads();
           for (uint32_t v = tid; v < S; v += nth) {
             const uint32_t v2 = min(v + (1u << (l - 1)), S - 1);
-            tmin[l * S + v] = pk_min(tmin[(l - 1) * S + v], tmin[(l - 1) * S + v2]);
-            if (a.word_level >= 2) tmax[l * S + v] = pk_max(tmax[(l - 1) * S + v], tmax[(l - 1) * S + v2]);
+            tmin[l * Sp + tsw(v)] = pk_min(tmin[(l - 1) * Sp + tsw(v)], tmin[(l - 1) * Sp + tsw(v2)]);
+            if (a.word_level >= 2) tmax[l * Sp + tsw(v)] = pk_max(tmax[(l - 1) * Sp + tsw(v)], tmax[(l - 1) * Sp + tsw(v2)]);
           }
         }
       }

@@ -69,6 +69,11 @@ class DeviceSearch:
     def _top_row(self) -> int:
         return self.segs[-1][0] + self.segs[-1][1] if self.segs else 0
 
+    def _stream(self) -> int:
+        """The HIP stream the engine is launched on (torch's current stream of this GPU; 0 off the GPU: the CPU tests drive
+        this class with an oracle-backed stand-in context)."""
+        return self.torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
+
     def _rows(self):
         return (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
 
@@ -106,13 +111,13 @@ class DeviceSearch:
             self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
         self.segs = [[0, 1]]
         self.stats = DeviceSearchStats()
-        ctx.stats_reset(torch.cuda.current_stream(self.dev).cuda_stream)
+        ctx.stats_reset(self._stream())
 
     def advance(self, all_solutions: bool = True, node_limit: int = 0, max_rounds: int = 0, keep_solutions: int = 0, batch: int = 0) -> bool:
         """Run rounds on the current stack until it is empty, a limit is hit, or (not all_solutions) a solution is
         found.  Returns True when the search is over (stack empty or solution found)."""
         torch, ctx, st = self.torch, self.ctx, self.stats
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        stream = self._stream()
         batch = min(int(batch) if batch else self.batch, self.batch)
         rounds = 0
         done = False

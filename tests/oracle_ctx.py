@@ -16,3 +16,60 @@ class OracleCtx:
     def propagate(self, lb, ub, active=None, want_stats=True):
         lb, ub, act, status, st = self._m.consistency(lb, ub, active, check_dup=False)
         return lb, ub, act, status, {"steps": st["steps"], "steps3": 0, "narrowings": st["narrowings"], "nodes": st["nodes"]}
+
+
+class OracleDeviceCtx(OracleCtx):
+    """The device-resident entry points of pcp_amd.engine.Context (propagate_device / branch_device / stats) over CPU tensors,
+    backed by the oracle and the numpy brancher — lets the CPU suite run pcp_amd.search_device.DeviceSearch and
+    pcp_amd.distributed.parallel_search_device end to end over gloo.  TEST INFRASTRUCTURE."""
+
+    def __init__(self, n_vars, props):
+        super().__init__(n_vars, props)
+        self.device = "cpu"
+        self._opts = {}
+        self._stats = {"steps": 0, "steps3": 0, "narrowings": 0, "nodes": 0, "evaluated": 0, "full_evals": 0, "waves": 0, "failed_nodes": 0}
+
+    def set_option(self, key, value):
+        self._opts[key] = int(value)
+
+    def stats_reset(self, stream=0):
+        for k in self._stats:
+            self._stats[k] = 0
+
+    def stats_read(self, stream=0):
+        return dict(self._stats)
+
+    def propagate_device(self, n, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream=0, bits_in=None, bits_out=None):
+        L, U = lb_in[:n].numpy().copy(), ub_in[:n].numpy().copy()
+        A = None if active_in is None else active_in[:n].numpy().view(np.uint64).copy()
+        bad = (L > U).any(axis=1)  # the device entry reports an empty input domain as a failed node
+        L[bad], U[bad] = 0, 0
+        lb, ub, act, st, s = self._m.consistency(L, U, A, check_dup=False)
+        st = st.copy(); st[bad] = 0
+        import torch
+        lb_out[:n] = torch.from_numpy(lb)
+        ub_out[:n] = torch.from_numpy(ub)
+        if active_out is not None:
+            active_out[:n] = torch.from_numpy(act.view(np.int64))
+        status[:n] = torch.from_numpy(st)
+        self._stats["steps"] += s["steps"]
+        self._stats["nodes"] += n
+
+    def branch_device(self, n, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream=0):
+        import torch
+        from pcp_amd import search as S
+        st = status[:n].numpy()
+        unk = st == 2
+        L, U = lb[:n].numpy()[unk], ub[:n].numpy()[unk]
+        A = None if active is None else active[:n].numpy().view(np.uint64)[unk]
+        k = 0
+        if unk.any():
+            cl, cu, ca = S.branch(L, U, A)
+            if self._opts.get("branch_reverse"):
+                cl, cu, ca = cl[::-1].copy(), cu[::-1].copy(), (None if ca is None else ca[::-1].copy())
+            k = cl.shape[0]
+            child_lb[:k] = torch.from_numpy(cl)
+            child_ub[:k] = torch.from_numpy(cu)
+            if ca is not None:
+                child_active[:k] = torch.from_numpy(ca.view(np.int64))
+        counts[:] = torch.tensor([k, int((st == 1).sum()), int((st == 0).sum()), int(unk.sum()), 0], dtype=counts.dtype)

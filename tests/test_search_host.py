@@ -145,6 +145,45 @@ def test_two_rank_worklist_gloo(batch):
     assert len(res[0][5]) > 0 and len(res[1][5]) > 0  # both ranks did real work
 
 
+def _device_worker(rank, world, port, n, batch, implicit, q):
+    """parallel_search_device end to end over gloo: DeviceSearch on CPU tensors with the oracle-backed stand-in context."""
+    import torch
+    import torch.distributed as dist
+    from oracle_ctx import OracleDeviceCtx
+    from pcp_amd.search_device import DeviceSearch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = OracleDeviceCtx(n, M.nqueens_props(n))
+        ds = DeviceSearch(ctx, batch=batch, capacity=4096, device=torch.device("cpu"), implicit=implicit)
+        info = {}
+        tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, info=info)
+        q.put((rank, tot, ds.stats.num_nodes, info["exchanges"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("implicit", [True, False])
+def test_two_rank_device_search_gloo(implicit):
+    """BASELINE config 5's driver (device-resident stacks, worklist balanced by all_gather + pairwise send/recv, totals by
+    all_reduce) with world_size 2: exactly the reference's tree, work moves, both ranks propagate nodes."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_device_worker, args=(r, 2, port, 8, 8, implicit, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, tot0, n0, x0), (r1, tot1, n1, x1) = res
+    assert tot0 == tot1 and tot0[:3] == (779, 92, 298)   # nodes, solutions, failures of the reference's tree (all_solution.rs:70)
+    assert tot0[4] > 0 and n0 > 0 and n1 > 0 and n0 + n1 == 779 and x0 == x1 > 1
+
+
 def _stack_worker(rank, world, port, q):
     """balance_stacks over gloo with CPU tensors: rows are tagged so that nothing is lost, duplicated or torn."""
     import torch

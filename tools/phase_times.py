@@ -12,11 +12,11 @@ from pcp_amd import workloads as W
 
 n = 1000; nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 implicit = os.environ.get("PCP_ACTIVE", "implicit") == "implicit"
-mode320 = "320" in os.environ.get("PCP_HIP_LIB", "")
+mode320 = os.environ.get("PCP_MODE320", "") == "1" or "320" in os.environ.get("PCP_HIP_LIB", "")
 ctx = E.Context(0); ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
 if os.environ.get('PCP_WORD_LEVEL'): ctx.set_option('word_level', int(os.environ['PCP_WORD_LEVEL'])); print('word_level', os.environ['PCP_WORD_LEVEL'])
 dev = torch.device("cuda:0")
-for D in (0, 500, 3000):
+for D in [int(x) for x in os.environ.get('PCP_DIVES', '0,500,3000').split(',')]:
     ctx.set_option("nodes_per_block", 0)
     if D == 0:
         L, U, A = W.nqueens_frontier(ctx, n, nodes, 0, 8, implicit=implicit)

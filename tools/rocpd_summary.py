@@ -21,8 +21,10 @@ def main():
     agg = defaultdict(list)
     ev2k = {}
     for _id, kid, s, e, gx, wx, lds, ev in rows:
-        agg[names.get(kid, str(kid))].append((e - s, gx, wx, lds))
-        ev2k[ev] = names.get(kid, str(kid))
+        # one line per (kernel, grid): the same instantiation runs the bench batch and, e.g., a 4096-node side leg
+        key = f"{names.get(kid, str(kid))[:86]} grid={gx // max(wx, 1)}"
+        agg[key].append((e - s, gx, wx, lds))
+        ev2k[ev] = key
     tot = sum(sum(d[0] for d in v) for v in agg.values()) or 1
     print(f"# kernel stats from {db}")
     print(f"{'calls':>6} {'total_ms':>12} {'avg_us':>12} {'min_us':>10} {'max_us':>10} {'pct':>6}  grid  wg  lds  name")
@@ -30,7 +32,7 @@ def main():
         if filt and filt not in k:
             continue
         d = [x[0] for x in v]
-        print(f"{len(d):6d} {sum(d)/1e6:12.3f} {sum(d)/len(d)/1e3:12.2f} {min(d)/1e3:10.2f} {max(d)/1e3:10.2f} {100*sum(d)/tot:6.2f}  {v[-1][1]}  {v[-1][2]}  {v[-1][3]}  {k[:90]}")
+        print(f"{len(d):6d} {sum(d)/1e6:12.3f} {sum(d)/len(d)/1e3:12.2f} {min(d)/1e3:10.2f} {max(d)/1e3:10.2f} {100*sum(d)/tot:6.2f}  {v[-1][1]}  {v[-1][2]}  {v[-1][3]}  {k[:110]}")
     n_pmc = c.execute(f"select count(*) from {T('rocpd_pmc_event')}").fetchone()[0]
     if n_pmc:
         pmc = dict(c.execute(f"select id, name from {T('rocpd_info_pmc')}"))
@@ -42,7 +44,7 @@ def main():
             if filt and filt not in k:
                 continue
             n = len(agg.get(k, [])) or 1
-            print(f"kernel {k[:100]}  dispatches={n}")
+            print(f"kernel {k[:110]}  dispatches={n}")
             for name, val in sorted(d.items()):
                 print(f"   {name:28s} sum={val:18.0f}  per_dispatch={val/n:18.1f}")
 
