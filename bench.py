@@ -177,6 +177,7 @@ def run_search_mode(args, torch, dist, world, rank, dev):
         dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
     dt = float(t_dt.item())
     if rank == 0:
+        _flush_c_stdio()
         print(json.dumps({
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: sharded open-node worklist)",
             "value": steps / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
@@ -188,7 +189,17 @@ def run_search_mode(args, torch, dist, world, rank, dev):
                 "exchange_seconds_rank0": info.get("exchange_s"), "exchange_share_rank0": (info.get("exchange_s") or 0) / dt, "exchanges": info.get("exchanges"),
                 "record_bytes": 8 * n, "parallelism": f"worklist sharded over {world} GPU(s)",
             },
-        }))
+        }), flush=True)
+
+
+def _flush_c_stdio():
+    """librccl prints a version banner through C stdio when the process group comes up; flush it now so that the JSON line is
+    the LAST line of rank 0's stdout."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except (OSError, AttributeError):
+        pass
 
 
 def main():
@@ -397,9 +408,11 @@ def main():
         if legs_req != "none":
             legs = side_legs(ctx, torch, dev, n, props, args, set(legs_req.split(",")), L, U)
         out["config"]["legs"] = legs
-        print(json.dumps(out))
+        _flush_c_stdio()
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    _flush_c_stdio()
 
 
 def side_legs(ctx, torch, dev, n, props, args, want, L, U):

@@ -33,6 +33,7 @@ struct pcp_ctx {
   Rec* d_recs = nullptr;
   Rec8* d_recs8 = nullptr; size_t cap_recs8 = 0; bool compact = false;
   WordDesc* d_wdesc = nullptr; size_t cap_wdesc = 0;
+  GroupDesc* d_gdesc = nullptr; size_t cap_gdesc = 0;
   uint32_t word_level = 0;           // 0 = no word descriptors worth using, 1 = XNeqY words only, 2 = XLessY words too
   uint32_t* d_adj_off = nullptr;
   uint32_t* d_adj = nullptr;
@@ -74,6 +75,7 @@ struct pcp_ctx {
   int64_t opt_branch_reverse = 0;   // 1 = pcp_branch_device writes the children in reverse order (row n_children-1-k)
   int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
   int64_t opt_word_level = 1;       // 1 = auto (word-group sweep with the level -1 range test on packed tiles), 0 = never
+  int64_t opt_group_level = 1;      // 1 = implicit nodes test whole groups of 64 words first (needs word descriptors)
   int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
 };
 
@@ -312,6 +314,34 @@ int32_t finalize_model(pcp_ctx* c) {
       if ((rc = ensure(c, c->d_wdesc, c->cap_wdesc, wd.size()))) return rc;
       HIP_TRY(c, hipMemcpy(c->d_wdesc, wd.data(), wd.size() * sizeof(WordDesc), hipMemcpyHostToDevice));
       c->word_level = any_lt ? 2 : 1;
+      // group descriptors: the same idea one level up (64 words at a time; the y operands as a suffix [ylo, n_slots))
+      const size_t G = (W + 63) / 64;
+      std::vector<GroupDesc> gd(G);
+      for (size_t g = 0; g < G; ++g) {
+        GroupDesc q;
+        memset(&q, 0, sizeof(q));
+        const size_t r0 = g * 4096, r1 = std::min(P, r0 + 4096);
+        const uint32_t kind = recs[r0].xk >> 28;
+        bool ok = kind == PCP_NEQ || kind == PCP_LT;
+        uint32_t xlo = ~0u, xhi = 0, ylo = ~0u;
+        int32_t dmin = INT32_MAX, dmax = INT32_MIN;
+        for (size_t r = r0; r < r1 && ok; ++r) {
+          ok = (recs[r].xk >> 28) == kind;
+          const uint32_t x = recs[r].xk & kSlotMask;
+          xlo = std::min(xlo, x); xhi = std::max(xhi, x); ylo = std::min(ylo, recs[r].y);
+          dmin = std::min(dmin, recs[r].d); dmax = std::max(dmax, recs[r].d);
+        }
+        if (ok && xhi - xlo < kRangeMax && dmin >= -30000 && dmax <= 30000) {
+          const uint32_t kx = lg(xhi - xlo + 1);
+          q.x = xlo | ((xhi - (1u << kx) + 1) << 16);
+          q.k = kx | ((kind == PCP_NEQ ? 1u : 2u) << 8);
+          q.ylo = ylo;
+          q.d = ((uint32_t)dmin & 0xffffu) | ((uint32_t)dmax << 16);
+        }
+        gd[g] = q;
+      }
+      if ((rc = ensure(c, c->d_gdesc, c->cap_gdesc, gd.size()))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_gdesc, gd.data(), gd.size() * sizeof(GroupDesc), hipMemcpyHostToDevice));
     }
   }
   if (c->has_groups) {
@@ -425,7 +455,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -541,6 +571,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "packed") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "packed must be 0 or 1");
     c->opt_packed = value;
+  } else if (k == "group_level") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "group_level must be 0 or 1");
+    c->opt_group_level = value;
   } else if (k == "implicit_active") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "implicit_active must be 0 or 1");
     c->opt_implicit = value;
@@ -667,7 +700,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots};
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;
-  a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
+  a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.m.gdesc = (c->word_level && c->opt_group_level) ? c->d_gdesc : nullptr; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   // with a declared hull there is no retry launch: a tile outside the hull raises the STICKY violation word (d_retry[1]),
   // which stays set until pcp_stats_read has reported it — whatever is launched in between
   if (Bp && c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax) a.retry_flag = c->d_retry + 1;

@@ -51,6 +51,15 @@ struct __attribute__((aligned(16))) WordDesc {
   WordPart a, b;
 };
 static_assert(sizeof(WordDesc) == 32, "WordDesc must be 32 bytes");
+// Group descriptor (implicit nodes): what the 64 words = 4096 records of one GROUP have in common, for a test one level above the
+// word test: x slots within a short range (as in WordPart), y slots somewhere in [ylo, n_slots) — queried as a SUFFIX minimum —
+// and offsets in [dmin, dmax].  cls as in WordPart (0 = no group test).
+struct __attribute__((aligned(16))) GroupDesc {
+  uint32_t x;    // xlo | second_x << 16
+  uint32_t k;    // kx | cls << 8
+  uint32_t ylo;  // smallest y slot of the group
+  uint32_t d;    // (dmin & 0xffff) | dmax << 16
+};
 constexpr uint32_t kRangeMax = 64;    // longest slot range a descriptor may cover
 constexpr uint32_t kRangeLevels = 7;  // table levels 2^0 .. 2^6
 
@@ -67,6 +76,7 @@ struct ModelDev {
   const Rec* recs;          // [n_recs]
   const Rec8* recs8;        // [n_recs] or null when the model is not compactable
   const WordDesc* wdesc;    // [ceil(n_recs/64)] word descriptors, or null
+  const GroupDesc* gdesc;   // [ceil(n_recs/4096)] group descriptors (with wdesc), or null
   const uint32_t* adj_off;  // [n_vars + 1]  CSR var -> incident record ids (constants have no adjacency)
   const uint32_t* adj;      // [adj_off[n_vars]]
   const uint2* adjp;        // [adj_off[n_vars]] payload of each adjacency entry of a binary-only model, or null:

@@ -447,7 +447,7 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 #endif  // PCP_TU == 0
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_TOTAL2 = 19, M_ITEMS2 = 20, M_ROUNDMASK2 = 21, M_SCAN = 22, M_WORDS = 24 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_TOTAL2 = 19, M_ITEMS2 = 20, M_ROUNDMASK2 = 21, M_SCAN = 22, M_OPEN0 = 23, M_WORDS = 24 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -1377,7 +1377,8 @@ __device__ __forceinline__ void sweep_fast(const LaunchArgs& a, const BlockCtx& 
 // words instead of phase B, which is organised for a few words.
 template <int B, bool COMPACT, bool IMPLICIT>
 __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx& k, uint32_t node0, uint32_t nb, uint32_t* chg_next,
-                                            uint32_t* remaining, uint32_t* hardmap, uint64_t& steps2, uint64_t& steps3, Ctr& ctr) {
+                                            uint32_t* remaining, uint32_t* hardmap, uint64_t& steps2, uint64_t& steps3, Ctr& ctr,
+                                            uint32_t* gscratch, uint32_t gscratch_words) {
   static_assert(B >= 4 && B <= 16 && B % 4 == 0, "one live register per node and lane; a node column fits one DPP row");
   constexpr bool PACKED = true, GLOBAL = false;
   using Cell = uint32_t;
@@ -1403,6 +1404,64 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
   uint32_t n_l0 = 0, n_l1 = 0, n_l2 = 0, n_bulk = 0;  // words that reached level 0 / 1 / 2; (word,node) pairs unlinked in bulk
   (void)n_bulk;
   const uint64_t tA = (PCP_ABLATE & 128) ? __builtin_amdgcn_s_memtime() : 0;
+  // ================= group level (implicit nodes) =================
+  // One lane per GROUP of 64 words: the x operands through the range tables, the y operands as a SUFFIX [ylo, n_slots) —
+  // the minimum (maximum) of the rest of ylo's 64-slot chunk from the tables and of all later chunks from a small
+  // suffix array — with the group's offset range.  A group that passes needs no word descriptors and no word tests at all
+  // (near the root: every x-block whose operands were not branched on).  Same soundness argument as level -1.
+  uint32_t* gpass = gscratch;  // [ceil(groups/32)] pass bits, then the chunk suffix arrays
+  bool have_g = false;
+  if constexpr (IMPLICIT) {
+    const uint32_t slots = k.S, chunks = (slots + 63) >> 6, gw = (groups + 31) >> 5;
+    have_g = a.m.gdesc != nullptr && a.word_level >= 2 && gw + 2 * (chunks + 1) <= gscratch_words && failm == 0;
+    if (have_g) {
+      uint32_t* sufmin = gscratch + gw;             // [chunks + 1]: min over the slots of chunks >= c
+      uint32_t* sufmax = sufmin + chunks + 1;
+      const uint32_t tid = threadIdx.x;
+      if (tid <= chunks) {
+        uint32_t mn = 0x7fff7fffu, mx = 0x80008000u;
+        for (uint32_t c = tid; c < chunks; ++c) {  // level 6 = the chunk starting at slot 64 c
+          mn = pk_min(mn, tmin[6 * S + tsw(c << 6)]);
+          mx = pk_max(mx, tmax[6 * S + tsw(c << 6)]);
+        }
+        sufmin[tid] = mn; sufmax[tid] = mx;
+      }
+      __syncthreads();
+      for (uint32_t g0 = 0; g0 < groups; g0 += blockDim.x) {
+        const uint32_t gi = g0 + tid;
+        bool pass = false, open0 = false;
+        if (gi < groups) {
+          const GroupDesc q = a.m.gdesc[gi];
+          const uint32_t cls = (q.k >> 8) & 15u, kx = q.k & 15u;
+          if (cls) {
+            const uint32_t xa = __umul24(kx, S) + tsw(q.x & 0xffffu), xb = __umul24(kx, S) + tsw(q.x >> 16);
+            const uint32_t yend = min(q.ylo | 63u, slots - 1), len = yend - q.ylo + 1, ky = 31u - (uint32_t)__builtin_clz(len);
+            const uint32_t ya = __umul24(ky, S) + tsw(q.ylo), yb = __umul24(ky, S) + tsw(yend + 1 - (1u << ky));
+            const uint32_t cn = (q.ylo >> 6) + 1;
+            const uint32_t Xn = pk_min(tmin[xa], tmin[xb]), Xx = pk_max(tmax[xa], tmax[xb]);
+            const uint32_t Yn = pk_min(pk_min(tmin[ya], tmin[yb]), sufmin[cn]), Yx = pk_max(pk_max(tmax[ya], tmax[yb]), sufmax[cn]);
+            const int dmin = lo16(q.d), dmax = hi16(q.d);
+            if (cls == 1) {
+              uint32_t tlo, thi;
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(tlo) : "v"(Xn), "v"(Yn));
+              asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(thi) : "v"(Xx), "v"(Yx));
+              pass = neq_no_zero(tlo, thi, dmin, dmax) == 0;
+              open0 = (lo16(tlo) + dmin > 0) && (hi16(tlo) - dmax > 0);
+            } else {
+              pass = ((hi16(Yn) - hi16(Xx) + dmin - 1) | (lo16(Xn) - lo16(Yx) + dmin - 1)) >= 0;
+            }
+          }
+        }
+        const uint64_t bal = __ballot(pass);
+        const uint32_t wi = (g0 >> 5) + 2 * wave;
+        if (lane == 0) { if (wi < gw) gpass[wi] = (uint32_t)bal; if (wi + 1 < gw) gpass[wi + 1] = (uint32_t)(bal >> 32); }
+        // a group of XNeqY words whose intervals overlap in more than a point in every node: none of its records is entailed
+        // at staging time — if the tile then narrows nothing, every node is known to be Unknown without the final scan
+        if (__ballot(open0) != 0 && lane == 0) atomicOr(&k.misc[M_OPEN0], 1u);
+      }
+      __syncthreads();
+    }
+  }
   // ================= phase A =================
   // The word's descriptor is fetched one group ahead, so that the level -1 arithmetic runs while the group's row loads
   // are in flight instead of behind them.
@@ -1411,6 +1470,16 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     const uint32_t w = g * 64 + lane;
     const bool wv = w < words;
     const uint32_t wc = min(w, words - 1);
+    if constexpr (IMPLICIT) {
+      if (have_g && ((gpass[g >> 5] >> (g & 31u)) & 1u)) {  // the whole group was cleared one level up
+        const uint64_t v = wv ? (wc == words - 1 ? tail_mask : ~0ull) : 0ull;
+        steps_lane += nb * (uint32_t)__popcll(v);
+        if (lane == 0) hard64[g] = 0;
+        const uint32_t gn = g + nw;
+        if (gn < groups && !((gpass[gn >> 5] >> (gn & 31u)) & 1u)) qa_next = a.m.wdesc[min(gn * 64 + lane, words - 1)].a;
+        continue;
+      }
+    }
     const WordPart qa = qa_next;
     uint64_t lv[IMPLICIT ? 1 : B];
     if constexpr (IMPLICIT) {
@@ -1931,7 +2000,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if constexpr (PACKED && B <= 16) {
       if (a.word_level) {  // team == 1 here
         swept = true;
-        if (!sweep_words<B, COMPACT, IMPLICIT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr))
+        if (!sweep_words<B, COMPACT, IMPLICIT>(a, k, node0, nb, cur, remaining, list_id, steps2, steps3, ctr, list_off, C))
           sweep_fast<B, GLOBAL, COMPACT, PACKED, IMPLICIT>(a, k, w0, w1, node0, nb, cur, remaining, steps2, steps3, ctr, reinterpret_cast<const uint64_t*>(list_id));
       }
     }
@@ -2021,6 +2090,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   // few block-wide steps as possible: ONE pass compacts the changed (node, variable) pairs with LDS atomics (their order is
   // irrelevant), a barrier, the incident records run, a barrier.  The counters alternate between two slots and the old
   // `cur` mask is cleared inside the next round's pass, so nothing else needs a barrier of its own.
+  bool tile_clean = false;  // no variable of any node of the tile changed: the domains are the inputs
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_total = (round & 1u) ? M_TOTAL2 : M_TOTAL, m_items = (round & 1u) ? M_ITEMS2 : M_ITEMS, m_mask = (round & 1u) ? M_ROUNDMASK2 : M_ROUNDMASK;
     // (a) compact the changed pairs of the live nodes: (node, var), the variable's adjacency offset and its degree
@@ -2053,7 +2123,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     }
     __syncthreads();
     const uint32_t total = misc[m_total];
-    if (total == 0 || (PCP_ABLATE & 32)) break;
+    if (total == 0 || (PCP_ABLATE & 32)) { tile_clean = round == 0 && total == 0 && failm == 0; break; }
     if (tid == 0) {  // the other slot: last read before this round's barrier
       misc[M_WAVES] += __popc(misc[m_mask]);
       misc[(round & 1u) ? M_TOTAL : M_TOTAL2] = 0; misc[(round & 1u) ? M_ITEMS : M_ITEMS2] = 0; misc[(round & 1u) ? M_ROUNDMASK : M_ROUNDMASK2] = 0;
@@ -2202,6 +2272,9 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     __syncthreads();
     const uint32_t wv3 = __builtin_amdgcn_readfirstlane(tid >> 6), nwv3 = nth >> 6;
     const uint32_t want = (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~misc[M_FAIL];
+    if (tile_clean && misc[M_OPEN0]) {  // shown at staging time and nothing changed since (sweep_words, group level)
+      if (tid == 0) misc[M_UNK] = want;
+    } else
     for (uint32_t w = wv3; w < words; w += nwv3) {
       uint32_t have = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[M_UNK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       if ((have & want) == want) break;
@@ -2240,6 +2313,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     for (uint32_t v = tid; v < V; v += nth)
       bad |= __hip_atomic_load(&k.glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > __hip_atomic_load(&k.gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bad) atomicOr(&misc[M_FAIL], 1u);
+  } else if (tile_clean && a.lb_in == a.lb_out && a.ub_in == a.ub_out) {
+    // in place and nothing narrowed in this tile: the rows in HBM already hold the result
   } else {
     for (uint32_t b = 0; b < nb; ++b) {
       int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;

@@ -1,37 +1,37 @@
 #!/usr/bin/env python
-"""Turn the FETCH_SIZE / WRITE_SIZE lines of a tools/profile_bench.sh summary into profiles/<tag>_traffic.json.
-On gfx950 FETCH_SIZE under-reports reads (exactly 1/2 for 16 B/lane coalesced streams, MI355X_MICROARCH.md §HBM; other
-widths "uncalibrated: calibrate on a known byte count in your own access pattern").  The bench launch has a known
-compulsory read volume — every node's `active` row (8 B/lane coalesced 512-byte rows) and its bounds are read exactly
-once, in place — so the correction factor is known_read_bytes / FETCH_SIZE, clamped to [1, 2]; WRITE_SIZE is taken as
-reported (it matches the bounds written back).  traffic_bytes = factor * FETCH_SIZE + WRITE_SIZE.
-usage: traffic_json.py summary.txt kernel-substring n nodes_per_launch out.json"""
+"""Turn the FETCH_SIZE / WRITE_SIZE lines of a tools/profile_round.sh summary into profiles/<tag>_traffic.json, which bench.py
+reads for `roofline.traffic`.  Correction exactly as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: on gfx950 FETCH_SIZE
+reports half the bytes of a wide coalesced read ("double it before comparing with a byte count"); WRITE_SIZE is taken as reported
+(uncalibrated in the guide).  Both are in KiB per dispatch, from separate --pmc passes.
+usage: traffic_json.py summary.txt kernel-substring grid n nodes_per_launch active out.json"""
 import json
 import re
 import sys
 
-summary, kern, n, nodes, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
-cur, vals = None, {}
+summary, kern, grid, n, nodes, active, out = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], sys.argv[7]
+cur, vals, dur = None, {}, None
 for line in open(summary):
-    m = re.match(r"kernel (\S+)", line)
+    m = re.match(r"kernel (\S+) grid=(\d+)", line)
     if m:
-        cur = m.group(1)
+        cur = (m.group(1), m.group(2))
     m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+sum=\s*\S+\s+per_dispatch=\s*(\S+)", line)
-    if m and cur and kern in cur:
+    if m and cur and kern in cur[0] and cur[1] == grid:
         vals[m.group(1)] = float(m.group(2))
+    m = re.match(r"\s*(\d+)\s+\S+\s+(\S+)\s+\S+\s+\S+\s+\S+\s+\d+\s+\d+\s+\d+\s+(\S+) grid=(\d+)", line)
+    if m and kern in m.group(3) and m.group(4) == grid:
+        dur = float(m.group(2))
 records = 3 * n * (n - 1) // 2                      # N-queens x[i] != x[j] + k decomposition
 words = (records + 63) // 64
-known_read = nodes * (words * 8 + 2 * n * 4)        # active rows + (lb, ub) rows, each read once
+compulsory = nodes * (16 * n + (8 * words if active == "explicit" else 0))
 fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
-factor = min(2.0, max(1.0, known_read / fetch))
 d = {
-    "n": n, "nodes_per_launch": nodes, "kernel": kern,
+    "n": n, "nodes_per_launch": nodes, "active": active, "kernel": kern, "grid": int(grid),
     "fetch_kib_per_launch": vals["FETCH_SIZE"], "write_kib_per_launch": vals["WRITE_SIZE"],
-    "known_read_bytes": known_read, "fetch_correction": factor,
-    "traffic_bytes": factor * fetch + write, "traffic_bytes_if_fetch_x2": 2 * fetch + write,
+    "traffic_bytes": 2 * fetch + write, "compulsory_bytes": compulsory,
+    "rocprof_avg_kernel_us": dur,
     "source": summary,
-    "note": "FETCH_SIZE * (known compulsory read bytes / FETCH_SIZE, clamped to [1,2]) + WRITE_SIZE; separate --pmc passes; "
-            "per-dispatch averages over 12 dispatches of which 11 are bench launches",
+    "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: gfx950 FETCH_SIZE counts 64 B per 128 B request), separate --pmc passes, "
+            "per-dispatch averages over the bench launches (same kernel instantiation and grid)",
 }
 json.dump(d, open(out, "w"), indent=1)
 print(d)
