@@ -123,8 +123,8 @@ class Leg:
             "narrowings_per_launch": per["narrowings"], "waves_per_node": per["waves"] / self.n,
             "steps_per_s": steps / (med * 1e-3), "evaluated_per_s": per["evaluated"] / (med * 1e-3),
             "nodes_per_s": self.n / (med * 1e-3),
-            "compulsory_bytes_per_launch": self.bytes,
-            "hbm_frac": self.bytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "compulsory_bytes_per_launch": self.bytes + 8 * per["narrowings"],
+            "hbm_frac": (self.bytes + 8 * per["narrowings"]) / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "status_false_true_unknown": np.bincount(self.status.cpu().numpy(), minlength=3)[:3].tolist(),
             "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "implicit_active", "grid")},
         }
@@ -134,9 +134,10 @@ class Leg:
 
 
 def node_bytes(V, words, explicit):
-    """Compulsory HBM bytes per node and launch, in place: bounds rows read once and written once (8 B per variable each way);
-    with explicit `active` rows additionally the row read once (its few changed words written back are not counted)."""
-    return 16 * V + (8 * words if explicit else 0)
+    """Compulsory HBM READ bytes per node and launch: the (lb, ub) rows once (8 B per variable); with explicit `active` rows
+    additionally the row once.  In place, the only writes the contract forces are the bounds that changed (8 B per narrowing,
+    added by the caller from the counters) — a tile that narrows nothing writes nothing back."""
+    return 8 * V + (8 * words if explicit else 0)
 
 
 def run_search_mode(args, torch, dist, world, rank, dev):
@@ -328,7 +329,7 @@ def main():
     status = t_status.cpu().numpy()
     if rank == 0:
         k_ms = float(np.median(kernel_ms))
-        compulsory = args.nodes * node_bytes(V, words, not implicit)
+        compulsory = args.nodes * node_bytes(V, words, not implicit) + 8 * per_step["narrowings"]
         alg_bytes = BYTES_BINARY * per_step["steps"] + BYTES_TERNARY * per_step["steps3"] + BYTES_NARROWING * per_step["narrowings"]
         tr = profiled_traffic({"n": n, "nodes_per_launch": args.nodes, "active": args.active})
         achieved = compulsory / (k_ms * 1e-3) / 1e9
@@ -376,8 +377,9 @@ def main():
                 "traffic_source": (tr or {}).get("source"),
                 "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "compulsory_bytes_per_launch": compulsory,
-                "model": "achieved = compulsory HBM bytes per launch / median HIP-event kernel time: every node's (lb, ub) rows read once and written once "
-                         "(16 B per variable and node)" + ("" if implicit else " plus its `active` row read once (8 B per 64 propagators)")
+                "model": "achieved = compulsory HBM bytes per launch / median HIP-event kernel time: every node's (lb, ub) rows read once "
+                         "(8 B per variable and node), 8 B written per narrowing (in place: a tile that narrows nothing writes nothing back)"
+                         + ("" if implicit else ", plus every node's `active` row read once (8 B per 64 propagators)")
                          + "; the model tables (word descriptors, records) are shared by all tiles and stay in L2.  `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of the "
                            "committed rocprofv3 PMC passes (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes), per launch",
                 "algorithmic_bytes_per_launch_survey_8d": alg_bytes,
@@ -486,7 +488,7 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
             ms.append(ctx.last_kernel_ms())
         stt = ctx.stats_read(stream)
         med = float(np.median(ms))
-        cbytes = Ns * (2 * n * sw * 8 + 2 * n * 4)  # the sets in and out, the bounds out
+        cbytes = Ns * (2 * n * sw * 8 + 2 * n * 4)  # the sets in and out (the set kernel always writes back), the bounds out
         removed = int((Bs != copies[1].cpu().numpy().view(np.uint64)).sum())
         legs.append({"name": "C2-set-mode-IntervalSet-frontier", "nodes": Ns, "launches": len(ms), "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
                      "steps_per_launch": (stt["steps"] + stt["steps3"]) / len(ms), "evaluated_per_launch": stt["evaluated"] / len(ms), "full_evals_per_launch": stt["full_evals"] / len(ms),

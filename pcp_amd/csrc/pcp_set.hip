@@ -48,7 +48,7 @@ __host__ __device__ inline SetCarve set_carve(uint32_t V, uint32_t S, uint32_t s
   return c;
 }
 
-enum { S_FAIL = 0, S_TOTAL = 1, S_ITEMS = 2, S_TOTAL2 = 3, S_ITEMS2 = 4, S_WAVES = 5, S_OPEN = 6, S_NARROW = 7, S_STEPS2 = 8, S_STEPS3 = 10, S_EVAL = 12, S_LIVE = 14 };
+enum { S_FAIL = 0, S_TOTAL = 1, S_ITEMS = 2, S_TOTAL2 = 3, S_ITEMS2 = 4, S_WAVES = 5, S_OPEN = 6, S_NARROW = 7, S_STEPS2 = 8, S_STEPS3 = 10, S_EVAL = 12, S_LIVE = 14, S_NSING = 15 };
 
 // One node's domains in LDS.
 struct SetDom {
@@ -276,7 +276,37 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   uint64_t* live_row = IMPLICIT ? nullptr : a.live + (size_t)node * words;
 
   // ---- phase 1: every live propagator once (init_scheduler, store.rs:144-149) --------------------------------------------
-  if (!misc[S_FAIL]) {
+  // Implicit nodes of an all-XNeqY model (N-queens): XNeqY::propagate is a no-op unless one operand is a singleton
+  // (x_neq_y.rs:82-93), so of the whole sweep only the records of ASSIGNED variables can act: they are reached through the
+  // variables' adjacency lists instead of streaming the table (N-queens-1000: a few thousand records instead of 1.5 million).
+  // The other records count as reference-equivalent steps (the reference pops them) but are never looked at.
+  uint64_t ev_only = 0;  // evaluated pairs that are not to be added to the credited steps again
+  bool bulk_sweep = false;
+  if constexpr (IMPLICIT) {
+    bulk_sweep = a.m.uniform_kind == PCP_NEQ && S == V && !misc[S_FAIL];  // (a Constant operand has no adjacency: S == V excludes them)
+    if (bulk_sweep) {
+      for (uint32_t v = tid; v < V; v += nth) {
+        const int2 b = bnd[v];
+        if (b.x == b.y) {
+          const uint32_t pos = atomicAdd(&misc[S_NSING], 1u);
+          if (pos < C) list_id[pos] = v;
+        }
+      }
+      __syncthreads();
+      const uint32_t ns = misc[S_NSING];
+      bulk_sweep = ns <= C;  // more assigned variables than the list holds: stream the table after all
+      if (bulk_sweep) {
+        const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow};
+        for (uint32_t e = 0; e < ns; ++e) {
+          const uint32_t v = list_id[e], o0 = a.m.adj_off[v], o1 = a.m.adj_off[v + 1];
+          for (uint32_t i = o0 + tid; i < o1; i += nth) { (void)eval_set(a.m.recs[a.m.adj[i]], dm, false); ++ev_only; }
+        }
+        if (tid == 0) { *reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]) += (unsigned long long)P; misc[S_LIVE] = 1u; }
+      }
+    }
+  }
+  if (bulk_sweep) {
+  } else if (!misc[S_FAIL]) {
     const uint64_t* in_row = (IMPLICIT || !a.live_in) ? nullptr : a.live_in + (size_t)node * words;
     const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow};
     for (uint32_t w = wv; w < words; w += nwv) {
@@ -302,6 +332,7 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   __syncthreads();
 
   // ---- phase 2: wake-up rounds (react + schedule as waves, store.rs:191-198) --------------------------------------------
+  const bool neq_only = IMPLICIT && a.m.uniform_kind == PCP_NEQ && S == V;
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_total = (round & 1u) ? S_TOTAL2 : S_TOTAL, m_items = (round & 1u) ? S_ITEMS2 : S_ITEMS;
     {
@@ -310,7 +341,7 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
         if (round) nxt[w] = 0;
         uint32_t bitsw = cur[w];
         if (!bitsw) continue;
-        uint32_t pos = atomicAdd(&misc[m_total], (uint32_t)__popc(bitsw));
+        uint32_t dropped = 0;  // changed variables that wake nobody: taken out of `cur`, which the FIFO dedup below reads
         while (bitsw) {
           const uint32_t v = (w << 5) + __builtin_ctz(bitsw);
           bitsw &= bitsw - 1;
@@ -319,14 +350,18 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
             const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
             bnd[v] = b;
             if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+            // all-XNeqY model, implicit node: a propagator acts only through a SINGLETON operand, so a variable that lost
+            // values but is not assigned wakes nobody (the reference wakes all of them on its Inner event: no-op steps)
+            if (neq_only && b.x != b.y) { dropped |= 1u << (v & 31); continue; }
           }
+          const uint32_t pos = atomicAdd(&misc[m_total], 1u);
           if (pos < C) {
             const uint32_t o0 = (v < V) ? a.m.adj_off[v] : 0u, o1 = (v < V) ? a.m.adj_off[v + 1] : 0u;
             list_id[pos] = v; list_off[pos] = o0; list_deg[pos] = o1 - o0;
             degsum += o1 - o0;
           }
-          ++pos;
         }
+        if (dropped) cur[w] &= ~dropped;
       }
       if (degsum) atomicAdd(&misc[m_items], degsum);
     }
@@ -396,9 +431,10 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
     }
   }
   // counters
-  for (int o = 32; o > 0; o >>= 1) { narrow += __shfl_down(narrow, o); steps2 += __shfl_down(steps2, o); steps3 += __shfl_down(steps3, o); }
+  for (int o = 32; o > 0; o >>= 1) { narrow += __shfl_down(narrow, o); steps2 += __shfl_down(steps2, o); steps3 += __shfl_down(steps3, o); ev_only += __shfl_down(ev_only, o); }
   if (lane == 0) {
     if (narrow) atomicAdd(&misc[S_NARROW], narrow);
+    if (ev_only) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[S_EVAL]), (unsigned long long)ev_only);
     if (steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]), (unsigned long long)steps2);
     if (steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[S_STEPS3]), (unsigned long long)steps3);
   }
@@ -420,7 +456,10 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
     const unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[S_STEPS3]);
     if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
     if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
-    if (s2 + s3) { atomicAdd((unsigned long long*)&a.stats->evaluated, s2 + s3); atomicAdd((unsigned long long*)&a.stats->full_evals, s2 + s3); }
+    // evaluated = the pairs that were looked at: everything counted as a step except the bulk sweep's credit, plus its own few
+    const unsigned long long evo = *reinterpret_cast<unsigned long long*>(&misc[S_EVAL]);
+    const unsigned long long looked = s2 + s3 - (misc[S_LIVE] ? (unsigned long long)P : 0ull) + evo;
+    if (looked) { atomicAdd((unsigned long long*)&a.stats->evaluated, looked); atomicAdd((unsigned long long*)&a.stats->full_evals, looked); }
     if (misc[S_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[S_NARROW]);
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(1 + misc[S_WAVES]));
     atomicAdd((unsigned long long*)&a.stats->nodes, 1ull);

@@ -32,7 +32,7 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     om = orc.OracleModel(n_vars, props)
     ref = om.consistency(lb, ub, active)
     ctx.set_model(n_vars, props)
-    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, "group_level": 1, **opts}.items():
         ctx.set_option(k, v)
     got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
     assert_parity(ref[:4], got[:4], what)
@@ -253,7 +253,26 @@ def test_word_group_sweep(ctx, kinds, npb):
         for wl in (1, 0):
             both(ctx, n, props, L, U, act, f"word sweep kinds={kinds} npb={npb} planted={planted} word_level={wl}",
                  nodes_per_block=npb, packed=1, word_level=wl)
+        # implicit nodes with and without the group-level test ahead of the word level
+        both(ctx, n, props, L, U, None, f"word sweep kinds={kinds} npb={npb} planted={planted} group_level=0",
+             nodes_per_block=npb, packed=1, word_level=1, group_level=0)
     ctx.set_option("word_level", 1)
+    ctx.set_option("group_level", 1)
+
+
+@pytest.mark.parametrize("kinds", [[M.NEQ], [M.LT], [M.NEQ, M.LT]])
+def test_group_level_sweep(ctx, kinds):
+    """Implicit nodes on a table with several groups of 64 words (all pairs of 200 variables: 5 groups): the group-level range
+    test clears whole groups on nodes where few variables are narrowed, and hands the others to the word level."""
+    n = 200
+    props, lb, ub, sol = _all_pairs_model(n, kinds, seed=77 + len(kinds), dom=(0, 400))
+    for p_narrow, planted in ((0.02, True), (0.3, True), (0.03, False)):
+        L, U = random_nodes(91, lb, ub, 70, sol if planted else None, p_narrow=p_narrow)
+        for gl in (1, 0):
+            both(ctx, n, props, L, U, None, f"group level kinds={kinds} p={p_narrow} planted={planted} gl={gl}", force_path=1, nodes_per_block=16, packed=1, word_level=1, group_level=gl)
+        pl = ctx.last_plan()
+        assert (pl["word_level"], pl["packed"], pl["nodes_per_block"], pl["implicit_active"]) == (2, 1, 16, 1), pl
+    ctx.set_option("group_level", 1)
 
 
 @pytest.mark.parametrize("n,dive", [(60, 25), (90, 60)])

@@ -222,6 +222,11 @@ def test_set_mode_nqueens_search_nodes(ctx, n):
     ref = (rec["lb_out"][keep], rec["ub_out"][keep], rec["bits_out"][keep], rec["active_out"][keep], rec["status"][keep])
     assert_set_parity(ref, got[:5], f"set nqueens({n}) nodes")
     assert (got[2] != rec["bits_in"][keep]).any()
+    # the same nodes as implicit-active nodes: the all-XNeqY shortcuts (only assigned variables sweep and wake, pcp_set.hip)
+    ref_i = om.consistency_set(rec["bits_in"][keep], 1, None)
+    got_i = ctx.propagate_set(rec["bits_in"][keep], None)
+    assert ctx.last_plan()["implicit_active"] == 1
+    assert_set_parity(ref_i[:5], (got_i[0], got_i[1], got_i[2], None, got_i[4]), f"set nqueens({n}) nodes implicit", check_active=False)
 
 
 @pytest.mark.gpu
