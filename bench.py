@@ -149,7 +149,8 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     from pcp_amd.search_device import DeviceSearch
     n = args.n
     ctx = E.Context(dev.index)
-    ctx.set_model(n, M.nqueens_props(n))
+    set_mode = args.domains == "set"
+    ctx.set_model(n, M.nqueens_props(n), set_words=(n + 63) // 64 if set_mode else 0)
     ctx.set_hull(1, n)
     batch = args.search_batch
     ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
@@ -161,14 +162,14 @@ def run_search_mode(args, torch, dist, world, rank, dev):
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     grp = dist
     # warm-up: a short search (kernels loaded, buffers touched)
-    D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, node_limit=min(args.node_budget, 8 * batch), rounds_per_exchange=args.rounds_per_exchange)
+    D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, node_limit=min(args.node_budget, 8 * batch), rounds_per_exchange=args.rounds_per_exchange, base=1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     info = {}
     nodes, sols, fails, steps, moved = D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, node_limit=args.node_budget,
-                                                                 rounds_per_exchange=args.rounds_per_exchange, info=info)
+                                                                 rounds_per_exchange=args.rounds_per_exchange, info=info, base=1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -184,11 +185,13 @@ def run_search_mode(args, torch, dist, world, rank, dev):
             "value": steps / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {
-                "workload": f"N-queens n={n} parallel subtree search, first {args.node_budget} nodes of the tree (all ranks together), device-resident stacks, "
+                "workload": f"N-queens n={n} parallel subtree search over " + ("IntervalSet<i32> domains (FDSpace, the reference's default)" if set_mode else "Interval<i32> domains")
+                            + f", first {args.node_budget} nodes of the tree (all ranks together), device-resident stacks, "
                             f"batch {batch} nodes per round and GPU, worklist balanced every {args.rounds_per_exchange} rounds by all_gather + pairwise send/recv (RCCL)",
                 "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails, "moved_records": moved,
                 "exchange_seconds_rank0": info.get("exchange_s"), "exchange_share_rank0": (info.get("exchange_s") or 0) / dt, "exchanges": info.get("exchanges"),
-                "record_bytes": 8 * n, "parallelism": f"worklist sharded over {world} GPU(s)",
+                "record_bytes": 8 * n + (8 * n * ((n + 63) // 64) if set_mode else 0), "domains": args.domains,
+                "parallelism": f"worklist sharded over {world} GPU(s)",
             },
         }), flush=True)
 
@@ -213,7 +216,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,c3,c4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,setsearch,c3,c4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -221,6 +224,8 @@ def main():
     ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
     ap.add_argument("--search-batch", type=int, default=4096)
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
+    ap.add_argument("--domains", choices=["interval", "set"], default="interval",
+                    help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
     args = ap.parse_args()
 
     import torch
@@ -390,7 +395,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "explicit,c2,deep500,deep3000,set,c3,c4" if world == 1 else "none"
+            legs_req = "explicit,c2,deep500,deep3000,set,setsearch,c3,c4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -489,7 +494,22 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         stt = ctx.stats_read(stream)
         med = float(np.median(ms))
         cbytes = Ns * (2 * n * sw * 8 + 2 * n * 4)  # the sets in and out (the set kernel always writes back), the bounds out
-        removed = int((Bs != copies[1].cpu().numpy().view(np.uint64)).sum())
+        out_bits = copies[1].cpu().numpy().view(np.uint64)
+        removed = int((Bs != out_bits).sum())
+        cpu_set = None
+        if args.cpu_budget > 0:  # the oracle over IntervalSet domains on the first nodes of this batch: rate + parity of the launch
+            from oracle import oracle as orc
+            om = orc.OracleModel(n, props)
+            t0c, k, osteps = time.perf_counter(), 0, 0
+            while k < Ns and time.perf_counter() - t0c < args.cpu_budget / 4:
+                r = om.consistency_set(Bs[k:k + 1], 1, None, check_dup=False)
+                if int(r[4][0]) != int(t_st[k].item()) or (int(r[4][0]) != 0 and not np.array_equal(r[2][0], out_bits[k])):
+                    raise SystemExit(f"PARITY FAILURE (set mode): node {k} differs from the oracle")
+                osteps += r[5]["steps"]
+                k += 1
+            dtc = time.perf_counter() - t0c
+            cpu_set = {"value": osteps / dtc, "unit": "filter-steps/s", "cores": 1, "kind": "port", "nodes_per_s": k / dtc,
+                       "sample": f"first {k} nodes of this batch, {dtc:.1f} s, oracle over IntervalSet<i32> without the duplicate-subscription assert", "parity_checked_nodes": k}
         legs.append({"name": "C2-set-mode-IntervalSet-frontier", "nodes": Ns, "launches": len(ms), "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
                      "steps_per_launch": (stt["steps"] + stt["steps3"]) / len(ms), "evaluated_per_launch": stt["evaluated"] / len(ms), "full_evals_per_launch": stt["full_evals"] / len(ms),
                      "narrowings_per_launch": stt["narrowings"] / len(ms), "waves_per_node": stt["waves"] / len(ms) / Ns,
@@ -497,9 +517,33 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                      "compulsory_bytes_per_launch": cbytes, "hbm_frac": cbytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "status_false_true_unknown": np.bincount(t_st.cpu().numpy(), minlength=3)[:3].tolist(),
                      "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "implicit_active", "set_mode", "grid")},
+                     "cpu_baseline": cpu_set,
                      "note": f"N-queens n={n} over IntervalSet<i32> domains ({sw} u64 words per variable, 125 KB of sets per node in LDS), {Ns} open nodes of the breadth-first "
                              f"frontier of the FDSpace tree ({exp_nodes} nodes expanded, {exp_failed} failed); one workgroup per node; {removed} set words changed by the launch"})
         del t_bits, copies
+        ctx.set_model(n, props)
+        ctx.set_hull(1, n)
+    if "setsearch" in want:
+        # the reference's own workload end to end: example/src/nqueens.rs over FDSpace, stack + propagation + branching on the GPU
+        reset_opts()
+        sw = (n + 63) // 64
+        ctx.set_model(n, props, set_words=sw)
+        ctx.set_hull(1, n)
+        budget, sb = 100_000, 1024
+        ds = DeviceSearch(ctx, batch=sb, capacity=budget + 8 * sb, implicit=True)
+        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+        ds.run(lb0, ub0, all_solutions=True, node_limit=4 * sb, base=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = ds.run(lb0, ub0, all_solutions=True, node_limit=budget, base=1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        legs.append({"name": "C2-set-mode-device-search", "nodes": st.num_nodes, "seconds": dt, "us_per_node": dt / st.num_nodes * 1e6, "nodes_per_s": st.num_nodes / dt,
+                     "steps_per_s": st.filter_steps / dt, "evaluated_per_s": st.evaluated / dt, "last_kernel_us": ctx.last_kernel_ms() * 1e3,
+                     "failed_nodes": st.num_failed_node, "solutions": st.num_solution, "rounds": st.rounds,
+                     "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "implicit_active", "set_mode", "grid")},
+                     "note": f"N-queens n={n} over IntervalSet<i32> domains (FDSpace): first {budget} nodes of the tree, batch {sb} nodes per round, implicit nodes of 133 KB (sets + bounds)"})
+        del ds
         ctx.set_model(n, props)
         ctx.set_hull(1, n)
     if "c3" in want:

@@ -199,6 +199,13 @@ int32_t pcp_branch_device(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, con
                           const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
                           uint32_t* counts, void* hip_stream);
 
+/* The same over FDSpace (set mode): FirstSmallestVar compares CARDINALITIES (first_smallest_var.rs:30-39: Domain::size()), MiddleVal
+ * is (lower + upper) / 2 of the set's bounds, the children keep the values <= value resp. > value of the variable's set.
+ *   bits [n_nodes][n_vars][set_words], lb/ub [n_nodes][n_vars] = the outputs of pcp_propagate_device;
+ *   child_bits [2*n_nodes][n_vars][set_words] (capacity); active / child_active as above (both NULL for implicit nodes). */
+int32_t pcp_branch_device_set(pcp_ctx* ctx, uint32_t n_nodes, const uint64_t* bits, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                              const uint8_t* status, uint64_t* child_bits, uint64_t* child_active, uint32_t* counts, void* hip_stream);
+
 /* Counters accumulate on the device across pcp_propagate_device calls. */
 int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
 int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */

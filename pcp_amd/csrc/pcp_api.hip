@@ -794,6 +794,24 @@ int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const
   return PCP_OK;
 }
 
+int32_t pcp_branch_device_set(pcp_ctx* c, uint32_t n_nodes, const uint64_t* bits, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                              const uint8_t* status, uint64_t* child_bits, uint64_t* child_active, uint32_t* counts, void* hip_stream) {
+  if (!c || !counts) return PCP_ERR_ARG;
+  if (!c->set_words) return fail(c, PCP_ERR_ARG, "pcp_branch_device_set needs a set-mode model (pcp_model_reset with set_words > 0)");
+  if (!c->hull_set) return fail(c, PCP_ERR_CONTRACT, "set mode needs the hull of the initial domains (pcp_model_set_hull)");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t words = (c->n_units + 63) / 64;
+  if (n_nodes && (!status || (c->n_vars && (!bits || !lb || !ub || !child_bits)) || (words && ((active == nullptr) != (child_active == nullptr)))))
+    return fail(c, PCP_ERR_ARG, "null buffer");
+  int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
+  if (rc) return rc;
+  if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 20, stream)); return PCP_OK; }
+  HIP_TRY(c, launch_set_branch(n_nodes, c->n_vars, c->set_words, c->hull_lo, active ? words : 0u, bits, lb, ub, active, status, child_bits, child_active,
+                               c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
+  return PCP_OK;
+}
+
 int32_t pcp_stats_reset(pcp_ctx* c, void* hip_stream) {
   if (!c) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));

@@ -160,6 +160,12 @@ hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words
                          uint64_t* bits_out, int32_t* lb_out, int32_t* ub_out, const uint64_t* live_in, uint64_t* live, uint8_t* status,
                          pcp_stats* stats, uint64_t* derive_into, hipStream_t stream);
 
+hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t* child_base, uint32_t* counts, hipStream_t stream);
+// Set-mode branching: FirstSmallestVar by CARDINALITY, MiddleVal on the bounds, BinarySplit on the sets.
+hipError_t launch_set_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t set_words, int32_t base, uint32_t words, const uint64_t* bits, const int32_t* lb,
+                             const int32_t* ub, const uint64_t* active, const uint8_t* status, uint64_t* child_bits, uint64_t* child_active,
+                             uint32_t* child_base, uint32_t* counts, uint32_t reverse, hipStream_t stream);
+
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,

@@ -2566,6 +2566,14 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
   for (uint32_t w = tid; w < words; w += nth) { const uint64_t x = pa[w]; a0[w] = x; a1[w] = x; }
 }
 
+// the scan alone (set mode branches with its own kernel, pcp_set.hip)
+hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t* child_base, uint32_t* counts, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(counts, 0, 5 * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(1024), 0, stream, status, n_nodes, child_base, counts);
+  return hipGetLastError();
+}
+
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                          const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
                          uint32_t* counts, uint32_t reverse, hipStream_t stream) {

@@ -518,4 +518,68 @@ hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words
   return e;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter over FDSpace (search/branching/brancher.rs:52-71): the variable of
+// minimal CARDINALITY > 1, first index (first_smallest_var.rs:30-39 uses Domain::size()), the value (lower + upper) / 2
+// (middle_val.rs:25-27), children `x <= v` / `x > v` (binary_split.rs:46-57) folded into the variable's set.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) set_branch_kernel(uint32_t V, uint32_t sw, int32_t base, uint32_t words, const uint64_t* __restrict__ bits,
+                                                         const int32_t* __restrict__ lb, const int32_t* __restrict__ ub,
+                                                         const uint64_t* __restrict__ active, const uint32_t* __restrict__ child_base,
+                                                         uint64_t* __restrict__ child_bits, uint64_t* __restrict__ child_active,
+                                                         const uint32_t* __restrict__ counts, uint32_t reverse) {
+  const uint32_t node = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t slot = child_base[node];
+  if (slot == 0xFFFFFFFFu) return;
+  const uint32_t rowL = reverse ? counts[0] - 1 - slot : slot;
+  const uint32_t rowR = reverse ? rowL - 1 : slot + 1;
+  __shared__ unsigned long long best[4];
+  const uint64_t* pb = bits + (size_t)node * V * sw;
+  unsigned long long key = ~0ull;
+  for (uint32_t v = tid; v < V; v += nth) {
+    unsigned long long size = 0;
+    for (uint32_t k = 0; k < sw; ++k) size += (unsigned long long)__popcll(pb[(size_t)v * sw + k]);
+    if (size > 1) key = min(key, (size << 32) | v);
+  }
+  for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+  if ((tid & 63) == 0) best[tid >> 6] = key;
+  __syncthreads();
+  key = best[0];
+  for (uint32_t w = 1; w < (nth >> 6); ++w) key = min(key, best[w]);
+  const uint32_t var = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)key;
+  long long val = 0;
+  if (var != 0xFFFFFFFFu) val = ((long long)lb[(size_t)node * V + var] + (long long)ub[(size_t)node * V + var]) / 2;
+  uint64_t* b0 = child_bits + (size_t)rowL * V * sw;
+  uint64_t* b1 = child_bits + (size_t)rowR * V * sw;
+  for (size_t i = tid; i < (size_t)V * sw; i += nth) {
+    const uint64_t w = pb[i];
+    uint64_t le = ~0ull;  // the values <= val within this word
+    if ((uint32_t)(i / sw) == var) {
+      const long long t = val - ((long long)base + 64ll * (long long)(i % sw));
+      le = t < 0 ? 0ull : (t >= 63 ? ~0ull : ((2ull << t) - 1ull));
+      b0[i] = w & le;
+      b1[i] = w & ~le;
+    } else {
+      b0[i] = w;
+      b1[i] = w;
+    }
+  }
+  if (active) {
+    const uint64_t* pa = active + (size_t)node * words;
+    uint64_t* a0 = child_active + (size_t)rowL * words;
+    uint64_t* a1 = child_active + (size_t)rowR * words;
+    for (uint32_t w = tid; w < words; w += nth) { const uint64_t x = pa[w]; a0[w] = x; a1[w] = x; }
+  }
+}
+
+hipError_t launch_set_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t set_words, int32_t base, uint32_t words, const uint64_t* bits, const int32_t* lb,
+                             const int32_t* ub, const uint64_t* active, const uint8_t* status, uint64_t* child_bits, uint64_t* child_active,
+                             uint32_t* child_base, uint32_t* counts, uint32_t reverse, hipStream_t stream) {
+  hipError_t e = launch_branch_scan(n_nodes, status, child_base, counts, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(set_branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, set_words, base, words, bits, lb, ub, active, child_base, child_bits,
+                     child_active, counts, reverse);
+  return hipGetLastError();
+}
+
 }  // namespace pcp

@@ -215,7 +215,8 @@ def balance_stacks(stack, dist) -> int:
     dist.all_gather(gathered, mine)
     moves = plan_moves([int(t.item()) for t in gathered])
     ops, incoming, delta, give = [], [], 0, 0
-    rows = tuple(t for t in (stack.lb, stack.ub, stack.act) if t is not None)  # implicit-active stacks carry no `active` rows
+    # implicit-active stacks carry no `active` rows; set-mode stacks carry the sets as well
+    rows = tuple(stack._rows()) if hasattr(stack, "_rows") else tuple(t for t in (stack.lb, stack.ub, stack.act) if t is not None)
     for src, dst, k in moves:
         if rank == src:
             for t in rows:
@@ -247,14 +248,15 @@ def balance_stacks(stack, dist) -> int:
     return delta
 
 
-def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None):
+def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None,
+                           base: int = 0):
     """Sharded subtree search with device-resident stacks: ``search`` is a pcp_amd.search_device.DeviceSearch of this
     rank's GPU.  Rank 0 starts with the root; every ``rounds_per_exchange`` rounds the stacks are balanced GPU-to-GPU
     (X1+X2) and termination / totals agreed on (X3).  Returns the global (nodes, solutions, failures, filter steps)."""
     import torch
     rank = dist.get_rank()
     dev = search.lb.device
-    search.reset(lb0, ub0)
+    search.reset(lb0, ub0, base) if getattr(search, "bits", None) is not None else search.reset(lb0, ub0)
     if rank != 0:
         search.size = 0
     import time

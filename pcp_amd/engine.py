@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -98,13 +98,14 @@ def load_library():
     L.pcp_propagate.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
+    L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -251,6 +252,13 @@ class Context:
             return None if t is None else C.c_void_p(t.data_ptr())
         self._check(self._L.pcp_branch_device(self._h, n_nodes, p(lb), p(ub), p(active), p(status), p(child_lb), p(child_ub), p(child_active),
                                               p(counts), C.c_void_p(stream_ptr)))
+
+    def branch_device_set(self, n_nodes: int, bits, lb, ub, active, status, child_bits, child_active, counts, stream_ptr: int = 0):
+        """pcp_branch_device_set (set mode) on torch tensors of this context's device (counts: int32[5])."""
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self._L.pcp_branch_device_set(self._h, n_nodes, p(bits), p(lb), p(ub), p(active), p(status), p(child_bits), p(child_active),
+                                                  p(counts), C.c_void_p(stream_ptr)))
 
     def stats_reset(self, stream_ptr: int = 0):
         self._check(self._L.pcp_stats_reset(self._h, C.c_void_p(stream_ptr)))

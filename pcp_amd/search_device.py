@@ -51,6 +51,11 @@ class DeviceSearch:
         # domains (a node that descends from an all-active root has active = not entailed)
         self.implicit = bool(implicit) or not ctx.words
         self.act = None if self.implicit else torch.empty((self.cap, W), dtype=i64, device=self.dev)
+        # set mode (IntervalSet domains, the reference's FDSpace): the node is its sets; lb/ub hold the sets' bounds after
+        # propagation (the brancher's MiddleVal reads them)
+        self.set_words = int(getattr(ctx, "set_words", 0))
+        self.base = 0
+        self.bits = torch.empty((self.cap, V, self.set_words), dtype=i64, device=self.dev) if self.set_words else None
         self.status = torch.zeros(self.batch, dtype=u8, device=self.dev)
         self.counts = torch.zeros(5, dtype=i32, device=self.dev)
         self.segs: List[List[int]] = []  # [start, length], bottom to top
@@ -75,7 +80,8 @@ class DeviceSearch:
         return self.torch.cuda.current_stream(self.dev).cuda_stream if self.dev.type == "cuda" else 0
 
     def _rows(self):
-        return (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
+        rows = (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
+        return rows if self.bits is None else rows + (self.bits,)
 
     def _merge_top(self, want: int):
         """Close the holes under the top segments until the top segment holds `want` nodes (or is the only one): only
@@ -101,10 +107,15 @@ class DeviceSearch:
             pos += l
         self.segs = [[0, pos]] if pos else []
 
-    def reset(self, lb0, ub0):
-        """Start a new search: the stack holds the root."""
+    def reset(self, lb0, ub0, base: int = 0):
+        """Start a new search: the stack holds the root (set mode: the variables as IntervalSet::new(lb0, ub0), value v = bit
+        v - base, base = the hull's lower bound declared on the context)."""
         torch, ctx = self.torch, self.ctx
         from .engine import full_active
+        if self.bits is not None:
+            from .model import interval_bits
+            self.base = int(base)
+            self.bits[0] = torch.from_numpy(interval_bits(np.asarray(lb0), np.asarray(ub0), self.set_words, self.base).view(np.int64)).to(self.dev)
         self.lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev)
         self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
         if self.act is not None:
@@ -146,9 +157,14 @@ class DeviceSearch:
             lb, ub = self.lb[lo:top], self.ub[lo:top]
             act = None if self.act is None else self.act[lo:top]
             status = self.status[:n]
-            ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream)
-            ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
-                              self.counts, stream)
+            if self.bits is None:
+                ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream)
+                ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
+                                  self.counts, stream)
+            else:
+                bits = self.bits[lo:top]
+                ctx.propagate_device(n, None, None, lb, ub, act, act, status, stream, bits_in=bits, bits_out=bits)
+                ctx.branch_device_set(n, bits, lb, ub, act, status, self.bits[top:], None if self.act is None else self.act[top:], self.counts, stream)
             n_children, n_true, n_false, _, n_other = (int(x) for x in self.counts.cpu().tolist())  # the round's only D2H sync
             if n_other:
                 raise RuntimeError(f"{n_other} nodes were refused by the engine (bounds outside the declared hull): the search cannot continue")
@@ -177,8 +193,8 @@ class DeviceSearch:
         st.evaluated = s.get("evaluated", 0)
         return done or not self.segs
 
-    def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0) -> DeviceSearchStats:
-        self.reset(lb0, ub0)
+    def run(self, lb0, ub0, all_solutions: bool = True, node_limit: int = 0, keep_solutions: int = 0, base: int = 0) -> DeviceSearchStats:
+        self.reset(lb0, ub0, base)
         self.advance(all_solutions=all_solutions, node_limit=node_limit, keep_solutions=keep_solutions)
         return self.stats
 

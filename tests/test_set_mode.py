@@ -248,6 +248,26 @@ def test_set_mode_search_reproduces_the_fdspace_tree(ctx, n, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,batch,implicit", [(6, 1, True), (8, 1, False), (8, 64, True), (9, 256, True)])
+def test_set_mode_device_resident_search(ctx, n, batch, implicit):
+    """Stack, set-mode propagation and set-mode branching (pcp_branch_device_set: FirstSmallestVar by cardinality) on the GPU:
+    the oracle's DFS over FDSpace exactly (solutions / nodes / failures; with batch 1 also the order)."""
+    from pcp_amd.search_device import DeviceSearch
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props, set_words=1)
+    ctx.set_hull(1, n)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    ss, _, _, sol = orc.OracleModel(n, props).search_set(lb0, ub0, 1, 1, all_solutions=True)
+    st = DeviceSearch(ctx, batch=batch, capacity=4096, implicit=implicit).run(lb0, ub0, all_solutions=True, keep_solutions=400, base=1)
+    assert (st.num_solution, st.num_nodes, st.num_failed_node) == (ss["num_solution"], ss["num_nodes"], ss["num_failed_node"])
+    assert len({tuple(s) for s in st.solutions}) == ss["num_solution"]
+    if batch == 1:
+        one = DeviceSearch(ctx, batch=1, capacity=4096, implicit=implicit).run(lb0, ub0, all_solutions=False, keep_solutions=1, base=1)
+        ss1, _, _, sol1 = orc.OracleModel(n, props).search_set(lb0, ub0, 1, 1)
+        assert one.num_nodes == ss1["num_nodes"] and np.array_equal(one.solutions[0], sol1)
+
+
+@pytest.mark.gpu
 def test_set_mode_contract(ctx):
     import pcp_amd.engine as E
     props = M.lower_units([M.XNeqY(M.Identity(0), M.Identity(1))], 2)
