@@ -15,7 +15,10 @@
 // crate `intervallum` ("^1.2.0", Cargo.toml:22; no lockfile, not vendored): its published Interval<i32>
 // semantics are restated in struct Interval below and are consistent with all transcribed vectors.
 // Unpinned corners (no reference test observes them): i32 overflow at extreme bounds, Interval×Mul with
-// negative operands, IntervalSet interior removal (set mode is not restated at all).
+// negative operands.  SET MODE (IntervalSet<i32>, struct IntervalSet below; the engine is generic in the domain type:
+// pcp_oracle_engine.inc is instantiated for Interval and for IntervalSet, like the reference's Store<Memory, Event>) is pinned
+// ONLY at the search level — the reference's FDSpace tests (all_solution.rs:70, one_solution.rs:121-128, stop_node.rs:83-104) —
+// because no reference test observes an IntervalSet after propagation: "parity unpinned" for set-mode DOMAINS, stated in DESIGN.md §7.
 #pragma once
 #include <algorithm>
 #include <cstdint>
