@@ -552,8 +552,9 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         p3, lb3, ub3, sol3 = W.planted_binary_csp(0xC3, V3, P3)
         L3, U3 = W.unit_narrowing_prefix(0xC3 + 1, lb3, ub3, sol3, N3)
         ctx.set_model(V3, p3)
+        ctx.set_hull(0, 999)  # the variables are allocated with Interval(0, 999): 10-bit LDS cells instead of HBM-resident domains
         leg = Leg(ctx, torch, "C3-random-binary-csp-50k-vars-500k-props", torch.from_numpy(L3).to(dev), torch.from_numpy(U3).to(dev), None,
-                  N3 * node_bytes(V3, ctx.words, False), "4096 nodes, planted solution, unit-narrowing prefixes; domains stay in HBM (400 KB per node)")
+                  N3 * node_bytes(V3, ctx.words, False), "4096 nodes, planted solution, unit-narrowing prefixes; 400 KB of bounds per node, kept in LDS as 10-bit cells (declared hull [0, 999])")
         legs.append(leg.run(launches=3, warmup=1))
         del leg
     if "c4" in want:

@@ -221,7 +221,8 @@ typedef struct {
   uint32_t team;            /* workgroups cooperating on one node (1 = batch geometry)                 */
   uint32_t packed;          /* 1 = 16-bit packed LDS cells                                             */
   uint32_t word_level;      /* 0 = chunked record sweep, 1/2 = word-group sweep (level -1 range test)  */
-  uint32_t global_dom;      /* 1 = domains stay in HBM (variable store larger than LDS)                */
+  uint32_t global_dom;      /* 1 = domains stay in HBM (variable store larger than LDS); 2 = that variant with the domains in
+                               LDS after all as 10-bit cells (declared hull of at most 1024 values)    */
   uint32_t compact;         /* 1 = 8-byte record stream                                                */
   uint32_t implicit_active; /* 1 = no `active` rows: liveness derived from the domains                 */
   uint32_t set_mode;        /* 1 = IntervalSet (bitset) domains                                        */
@@ -231,7 +232,8 @@ int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
 
 /* Knobs (all optional; the defaults pick everything from the model and the batch).  key:
  *   "block_threads" 256/512/1024, "nodes_per_block" 0 = auto, "force_path" (0 auto, 1 batch LDS kernel, 2 team kernel),
- *   "team" workgroups per node, "list_cap", "global_dom" 1 = domains stay in HBM, "packed" 0 = never use 16-bit cells,
+ *   "team" workgroups per node, "list_cap", "global_dom" 1 = domains stay in HBM (2: 10-bit LDS cells allowed), "dom10" 0 = never use
+ *   10-bit cells, "implicit_active" 0 = materialise rows for active_in NULL, "group_level" 0 = no group test, "packed" 0 = never use 16-bit cells,
  *   "word_level" 0 = never use the word-group sweep, "branch_reverse" 1 = pcp_branch_device writes child k of the batch
  *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
  * Unknown key -> PCP_ERR_ARG. */

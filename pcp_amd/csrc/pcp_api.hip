@@ -25,6 +25,7 @@ struct pcp_ctx {
   uint32_t n_units = 0;
   std::vector<std::vector<uint32_t>> sums;  // term::Sum views: member variables of each term (pcp_model_push_sum)
   uint32_t* d_sum_off = nullptr; uint32_t* d_sum_mem = nullptr; size_t cap_sum_off = 0, cap_sum_mem = 0;
+  int32_t* d_mul_off = nullptr; size_t cap_mul_off = 0;  // XEqYMulZ offsets (dx, dy, dz) per MUL3 record
   uint32_t n_sum_slots = 0;             // Sum terms with more than one member (those have a pseudo-slot)
   bool has_groups = false;
   bool dirty = true;
@@ -75,6 +76,7 @@ struct pcp_ctx {
   int64_t opt_branch_reverse = 0;   // 1 = pcp_branch_device writes the children in reverse order (row n_children-1-k)
   int64_t opt_packed = 1;           // 1 = auto (16-bit packed tiles when the batch is large enough), 0 = never
   int64_t opt_word_level = 1;       // 1 = auto (word-group sweep with the level -1 range test on packed tiles), 0 = never
+  int64_t opt_dom10 = 1;            // 1 = variable stores larger than LDS use 10-bit LDS cells when the declared hull allows
   int64_t opt_group_level = 1;      // 1 = implicit nodes test whole groups of 64 words first (needs word descriptors)
   int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
 };
@@ -134,10 +136,6 @@ int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
     return fail(c, PCP_ERR_CONTRACT, "propagator already subscribed to this variable (reactors/indexed_deps.rs:69-77)");
   if (p.kind == PCP_MUL3 && c->set_words)
     return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ over IntervalSet domains is not supported (interval mode only)");
-  if (p.kind == PCP_MUL3)
-    for (int i = 1; i < 3; ++i)
-      if (p.var[i] != PCP_CONST && p.off[i] != 0)
-        return fail(c, PCP_ERR_UNSUPPORTED, "XEqYMulZ with Addition views on y or z is not supported");
   return PCP_OK;
 }
 
@@ -175,6 +173,7 @@ int32_t finalize_model(pcp_ctx* c) {
     f(var);
   };
   std::vector<Rec> recs(P);
+  std::vector<int32_t> mul_off;
   std::vector<uint32_t> deg(c->n_vars + 1, 0);
   bool tern = false;
   for (size_t r = 0; r < P; ++r) {
@@ -189,7 +188,10 @@ int32_t finalize_model(pcp_ctx* c) {
     }
     int64_t d;
     if (n == 2) d = off[1] - off[0];              // X = x, Y = y + d
-    else if (p.kind == PCP_MUL3) d = off[0];      // X = x + d = y*z
+    else if (p.kind == PCP_MUL3) {                // (x + dx) = (y + dy) * (z + dz): the offsets go to a side table, d = its index
+      d = (int64_t)(mul_off.size() / 3);
+      for (int i = 0; i < 3; ++i) mul_off.push_back((int32_t)off[i]);
+    }
     else d = off[1] + off[2] - off[0];            // x  vs  y + z + d
     if (d > PCP_BOUND_MAX || d < -PCP_BOUND_MAX) return fail(c, PCP_ERR_CONTRACT, "folded offset outside +-PCP_BOUND_MAX");
     recs[r].xk = s[0] | ((uint32_t)p.kind << 28);
@@ -244,6 +246,10 @@ int32_t finalize_model(pcp_ctx* c) {
     c->have_adjp = true;
   }
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  if (!mul_off.empty()) {
+    if ((rc = ensure(c, c->d_mul_off, c->cap_mul_off, mul_off.size()))) return rc;
+    HIP_TRY(c, hipMemcpy(c->d_mul_off, mul_off.data(), mul_off.size() * 4, hipMemcpyHostToDevice));
+  }
   if (n_sum) {
     if ((rc = ensure(c, c->d_sum_off, c->cap_sum_off, sum_off.size()))) return rc;
     if ((rc = ensure(c, c->d_sum_mem, c->cap_sum_mem, sum_mem.size()))) return rc;
@@ -455,7 +461,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -560,7 +566,7 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
     if (value < 0 || value > 4096) return fail(c, PCP_ERR_ARG, "team must be in [0,4096]");
     c->opt_team = value;
   } else if (k == "global_dom") {
-    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "global_dom must be 0 or 1");
+    if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "global_dom must be 0, 1 (force the HBM-resident variant) or 2 (force it, 10-bit LDS cells allowed)");
     c->opt_global_dom = value;
   } else if (k == "branch_reverse") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "branch_reverse must be 0 or 1");
@@ -571,6 +577,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "packed") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "packed must be 0 or 1");
     c->opt_packed = value;
+  } else if (k == "dom10") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "dom10 must be 0 or 1");
+    c->opt_dom10 = value;
   } else if (k == "group_level") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "group_level must be 0 or 1");
     c->opt_group_level = value;
@@ -697,13 +706,27 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
-  a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots};
+  a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.m.gdesc = (c->word_level && c->opt_group_level) ? c->d_gdesc : nullptr; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   // with a declared hull there is no retry launch: a tile outside the hull raises the STICKY violation word (d_retry[1]),
   // which stays set until pcp_stats_read has reported it — whatever is launched in between
   if (Bp && c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax) a.retry_flag = c->d_retry + 1;
+  // HBM-resident variable store with a declared hull of at most 1024 values: the domains fit LDS after all as 10-bit cells
+  bool dom10 = global_dom && team == 1 && c->opt_global_dom != 1 && c->opt_dom10 && c->hull_set && (int64_t)c->hull_hi - c->hull_lo <= 1023;
+  if (dom10) {
+    // the cells share LDS with the changed-pair lists: shrink those (down to 256 entries) before giving up on the cells
+    uint32_t cap = list_cap_used;
+    auto total = [&](uint32_t cp) { return lds_bytes_global(c->n_vars, S, cp) + dom10_bytes(c->n_vars); };
+    while (cap > 256 && (!lds_bytes_global(c->n_vars, S, cap) || total(cap) > c->lds_max)) cap /= 2;
+    dom10 = lds_bytes_global(c->n_vars, S, cap) && total(cap) <= c->lds_max;
+    if (dom10) {
+      list_cap_used = cap; a.list_cap = cap; a.adj_cache = 0;
+      plan.lds_bytes = total(cap);
+      a.dom10 = 1u; a.dom10_lo = c->hull_lo; a.retry_flag = c->d_retry + 1;
+    }
+  }
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -740,12 +763,12 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     a.team_fail = a.team_remaining + n_nodes;
     a.team_chg = a.team_fail + n_nodes + (n_nodes & 1);                  // keep alignment tidy
   }
-  if ((team > 1 || global_dom) && bt->lb_out != bt->lb_in && c->n_vars) {
+  if ((team > 1 || global_dom) && !dom10 && bt->lb_out != bt->lb_in && c->n_vars) {
     // team: every slice narrows the node's rows in lb_out/ub_out with atomics; global_dom: they are the working set
     HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
-  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
+  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, dom10 ? 2u : a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation (d_retry[1])

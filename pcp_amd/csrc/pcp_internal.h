@@ -70,6 +70,7 @@ struct SumTab {
   const uint32_t* mem;  // member variable indices
   uint32_t first;       // first sum slot (= n_vars)
   uint32_t count;       // 0 = the model has no Sum view
+  const int32_t* mul_off;  // XEqYMulZ records: (dx, dy, dz) Addition offsets of the three operands, indexed by the record's `d`
 };
 
 struct ModelDev {
@@ -108,6 +109,9 @@ struct LaunchArgs {
   uint32_t packed;           // 1 = 16-bit packed LDS domains (every bound within +-kPackedMax); tiles that do not fit mark
                              //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
   uint32_t adj_cache;        // 1 = (n_vars + 1) words of LDS behind the carve hold a copy of m.adj_off
+  uint32_t dom10;            // global_dom launches only: 1 = the node's domains sit in LDS after all, as 10-bit (lb - lo, ub - lo) cells, three
+                             //     per u64 (a declared hull of at most 1024 values: 50 000 variables = 130 KB), behind the carve
+  int32_t dom10_lo;          // the hull's lower bound
   uint32_t only_marked;      // 1 = second launch of a packed call: run only tiles whose nodes carry kStatusRetry
   uint32_t epoch;            // launch stamp compared with *retry_flag
   uint32_t* retry_flag;      // device word of the context
@@ -141,6 +145,7 @@ struct LaunchPlan {
 // Computes the dynamic-LDS footprint for (n_slots, B, list_cap); returns 0 if it cannot fit.
 size_t lds_bytes_for(uint32_t n_slots, uint32_t nodes_per_block, uint32_t list_cap, uint32_t block, bool packed = false, uint32_t word_level = 0);
 size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap);
+inline size_t dom10_bytes(uint32_t n_vars) { return ((((size_t)n_vars + 2) / 3) * 8 + 15) & ~(size_t)15; }
 
 hipError_t launch_fixpoint(const LaunchArgs& a, const LaunchPlan& p, hipStream_t stream);
 

@@ -89,6 +89,7 @@ struct LdsDom {
   __device__ __forceinline__ int2 load_var(uint32_t v) const { const int2 d = dom[(size_t)v * bp]; return make_int2(-d.x, d.y); }
   __device__ __forceinline__ bool is_sum(uint32_t v) const { return v - sums.first < sums.count; }
   __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return sums.mul_off; }
   __device__ __forceinline__ int2 load(uint32_t v) const { return is_sum(v) ? sum_read(*this, sums, v) : load_var(v); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
@@ -138,6 +139,7 @@ struct LdsDom16 {
 
   // (packed tiles are binary-only models without Sum views: the compact record stream excludes them)
   __device__ __forceinline__ bool any_sums() const { return false; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return nullptr; }  // (packed tiles: binary models only)
   __device__ __forceinline__ int2 load(uint32_t v) const { return unpack16(dom[(size_t)v * bp]); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); }
   __device__ __forceinline__ void set_fail() const { atomicOr(fail, fbit); }
@@ -196,10 +198,45 @@ struct GlobalDom {
   uint32_t fbit;
   Ctr* c;
   SumTab sums;
+  // dom10: the variable store is in LDS after all — 10-bit cells (lb - lo10) | (ub - lo10) << 10, three per u64 — because the
+  // declared hull has at most 1024 values (config 3: 50 000 variables over [0, 999] = 130 KB).  Same policy interface: the sweep
+  // and the rounds do not know the difference; a narrowing is a CAS on the cell's word.
+  unsigned long long* c10;
+  int lo10;
+
+  __device__ __forceinline__ static uint32_t word3(uint32_t v) { return __umulhi(v, 0xAAAAAAABu) >> 1; }  // v / 3
+  __device__ __forceinline__ int2 load10(uint32_t v) const {
+    const uint32_t w = word3(v), sh = (v - 3u * w) * 20u;
+    const uint32_t cell = (uint32_t)(c10[w] >> sh) & 0xFFFFFu;
+    return make_int2(lo10 + (int)(cell & 1023u), lo10 + (int)(cell >> 10));
+  }
+  // narrow one bound of the cell of v: which = 0 raises lb to nv, which = 1 lowers ub to nv (values relative to lo10)
+  __device__ __forceinline__ void narrow10(uint32_t v, int nv, int which) const {
+    const uint32_t w = word3(v), sh = (v - 3u * w) * 20u;
+    unsigned long long* p = &c10[w];
+    unsigned long long old = *p;
+    for (;;) {
+      const uint32_t cell = (uint32_t)(old >> sh) & 0xFFFFFu;
+      const int l = (int)(cell & 1023u), u = (int)(cell >> 10);
+      int nl = l, nu = u;
+      if (which == 0) { if (nv <= l) return; nl = min(nv, 1023); } else { if (nv >= u) return; nu = max(nv, 0); }
+      const unsigned long long neu = (old & ~(0xFFFFFull << sh)) | ((unsigned long long)((uint32_t)nl | ((uint32_t)nu << 10)) << sh);
+      const unsigned long long prev = atomicCAS(p, old, neu);
+      if (prev == old) {
+        ++c->narrow;
+        mark(v);
+        if ((which == 0 ? nv : l) > (which == 0 ? u : nv)) set_fail();
+        return;
+      }
+      old = prev;
+    }
+  }
 
   __device__ __forceinline__ bool is_sum(uint32_t v) const { return v - sums.first < sums.count; }
   __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return sums.mul_off; }
   __device__ __forceinline__ int2 load_var(uint32_t v) const {
+    if (c10) return load10(v);
     int2 d;
     d.x = __hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     d.y = __hip_atomic_load(&ub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -208,6 +245,7 @@ struct GlobalDom {
   __device__ __forceinline__ int2 load(uint32_t v) const {
     if (is_sum(v)) return sum_read(*this, sums, v);
     if (v >= n_vars) return cdom[v - n_vars];
+    if (c10) return load10(v);
     int2 d;
     d.x = __hip_atomic_load(&lb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     d.y = __hip_atomic_load(&ub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -218,6 +256,7 @@ struct GlobalDom {
   __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
     if (is_sum(v)) { if (nlb > sum_read(*this, sums, v).y) set_fail(); return; }
     if (v >= n_vars) { if (nlb > cdom[v - n_vars].y) set_fail(); return; }  // Constant::update (term/constant.rs:49-52)
+    if (c10) { narrow10(v, nlb - lo10, 0); return; }
     const int old = atomicMax(&lb[v], nlb);
     if (old < nlb) {
       ++c->narrow;
@@ -228,6 +267,7 @@ struct GlobalDom {
   __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
     if (is_sum(v)) { if (nub < sum_read(*this, sums, v).x) set_fail(); return; }
     if (v >= n_vars) { if (nub < cdom[v - n_vars].x) set_fail(); return; }
+    if (c10) { narrow10(v, nub - lo10, 1); return; }
     const int old = atomicMin(&ub[v], nub);
     if (old > nub) {
       ++c->narrow;
@@ -334,10 +374,14 @@ __device__ __forceinline__ bool eval_record(const Rec& rec, const D& dm) {
     const bool leq_true = (long long)X.y < (long long)Y.x + Z.x + d + 1;
     return geq_true && leq_true;  // Kleene and (x_eq_y_plus_z.rs:65-67)
   } else {
-    // XEqYMulZ (x_eq_y_mul_z.rs:99-105): x := x ∩ (y·z); here X = dom[x] + d (offsets on y,z are rejected on the host).
-    const long long p0 = (long long)Y.x * Z.x, p1 = (long long)Y.x * Z.y, p2 = (long long)Y.y * Z.x, p3 = (long long)Y.y * Z.y;
+    // XEqYMulZ (x_eq_y_mul_z.rs:99-105): x := x ∩ (y·z) through the operands' Addition views: (x + dx) = (y + dy)·(z + dz);
+    // the three offsets sit in a side table indexed by the record's `d` field.
+    const int32_t* mo = dm.mul_offsets() + 3 * (size_t)d;
+    const long long dx = mo[0], dy = mo[1], dz = mo[2];
+    const long long yl = Y.x + dy, yu = Y.y + dy, zl = Z.x + dz, zu = Z.y + dz;
+    const long long p0 = yl * zl, p1 = yl * zu, p2 = yu * zl, p3 = yu * zu;
     const long long pl = min(min(p0, p1), min(p2, p3)), pu = max(max(p0, p1), max(p2, p3));
-    const int nl = max(X.x, clamp_i32(pl - d)), nu = min(X.y, clamp_i32(pu - d));
+    const int nl = max(X.x, clamp_i32(pl - dx)), nu = min(X.y, clamp_i32(pu - dx));
     if (nl > X.x) dm.raise_lb(x, nl);
     if (nu < X.y) dm.lower_ub(x, nu);
     if (nl > nu) dm.set_fail();
@@ -466,6 +510,8 @@ struct BlockCtx {
   int32_t* gub;
   uint32_t V;
   SumTab sums;
+  unsigned long long* c10;  // global variant with dom10: the LDS cells (else null)
+  int lo10;
 };
 
 template <bool PACKED> struct CellOf { using type = int2; };
@@ -478,7 +524,7 @@ template <bool PACKED> struct DomOf<true, PACKED> { using type = GlobalDom; };
 template <bool GLOBAL, bool PACKED>
 __device__ __forceinline__ typename DomOf<GLOBAL, PACKED>::type make_dom(const BlockCtx& k, uint32_t b, uint32_t* chg_next, Ctr* ctr) {
   if constexpr (GLOBAL) {
-    return GlobalDom{k.glb, k.gub, static_cast<int2*>(k.dom), k.V, chg_next, &k.misc[M_FAIL], 1u, ctr, k.sums};  // one node per block
+    return GlobalDom{k.glb, k.gub, static_cast<int2*>(k.dom), k.V, chg_next, &k.misc[M_FAIL], 1u, ctr, k.sums, k.c10, k.lo10};  // one node per block
   } else if constexpr (PACKED) {
     return LdsDom16{static_cast<uint32_t*>(k.dom) + b, k.bp, chg_next + (size_t)b * k.Wv, &k.misc[M_FAIL], 1u << b, ctr};
   } else {
@@ -1879,7 +1925,9 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
     if (__hip_atomic_load(a.retry_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) return;
     if (a.status[node0] != kStatusRetry) return;
   }
-  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * tsw_slots(S) * rmq_levels(PACKED ? a.word_level : 0, false)}, tsw_slots(S), S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V, a.m.sums};
+  const BlockCtx k{dom, BP, SummPtr{smem + cv.summ, smem + cv.summ + (size_t)4 * tsw_slots(S) * rmq_levels(PACKED ? a.word_level : 0, false)}, tsw_slots(S), S, Wv, misc, a.lb_out + (size_t)node0 * V, a.ub_out + (size_t)node0 * V, V, a.m.sums,
+                   (GLOBAL && a.dom10) ? reinterpret_cast<unsigned long long*>(smem + cv.total + (a.adj_cache ? ((((size_t)V + 1) * 4 + 15) & ~(size_t)15) : 0)) : nullptr,
+                   a.dom10_lo};
 
   // ---- phase 0: stage the nodes' domains in LDS (coalesced SoA reads), zero the masks ------------------
   // adjacency offsets of the variables: an LDS copy behind the carve when the launch has room for it (a round's
@@ -1895,12 +1943,41 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   for (uint32_t i = tid; i < (uint32_t)B * Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   __syncthreads();
   if constexpr (GLOBAL) {
+    if (a.dom10) {
+      // 10-bit LDS cells: three variables per u64, one thread per word (no atomics while staging)
+      bool bad = false, oob = false;
+      const uint32_t nw3 = (V + 2) / 3;
+      for (uint32_t w = tid; w < nw3; w += nth) {
+        unsigned long long word = 0;
+        for (uint32_t j = 0; j < 3; ++j) {
+          const uint32_t v = 3 * w + j;
+          int l = 0, u = 0;
+          if (v < V) {
+            const int lbv = a.lb_in[(size_t)node0 * V + v], ubv = a.ub_in[(size_t)node0 * V + v];
+            bad |= lbv > ubv;
+            oob |= (lbv < a.dom10_lo) | (ubv > a.dom10_lo + 1023) | (lbv > a.dom10_lo + 1023) | (ubv < a.dom10_lo);
+            l = min(max(lbv - a.dom10_lo, 0), 1023); u = min(max(ubv - a.dom10_lo, 0), 1023);
+          }
+          word |= (unsigned long long)((uint32_t)l | ((uint32_t)u << 10)) << (20 * j);
+        }
+        k.c10[w] = word;
+      }
+      for (uint32_t v = V + tid; v < S; v += nth) { int2 d; d.x = d.y = a.m.const_val[v - V]; dom[v - V] = d; }
+      if (bad) atomicOr(&misc[M_FAIL], 1u);
+      if (oob) atomicOr(&misc[M_OOB], 1u);
+      __syncthreads();
+      if (misc[M_OOB]) {  // a bound outside the declared hull: the caller's contract violation (as for packed tiles)
+        if (tid == 0) { a.status[node0] = kStatusRetry; atomicMax(a.retry_flag, 1u); }
+        return;
+      }
+    } else {
     // the node's rows in lb_out/ub_out ARE the working domains (the host copied the inputs there); only check them
     bool bad = false;
     if (g == 0)
       for (uint32_t v = tid; v < V; v += nth) bad |= a.lb_in[(size_t)node0 * V + v] > a.ub_in[(size_t)node0 * V + v];
     for (uint32_t v = V + tid; v < S; v += nth) { int2 d; d.x = d.y = a.m.const_val[v - V]; dom[v - V] = d; }
     if (bad) atomicOr(&misc[M_FAIL], 1u);
+    }
   } else {
     // slot-major: the 2*B bound loads of a slot (one per node row, lanes = consecutive slots: coalesced) are issued
     // together — one memory round trip per pass instead of one per node
@@ -2310,6 +2387,14 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
   }
   if constexpr (GLOBAL) {
     bool bad = false;  // the domains are already in place; a missed failure shows as an empty domain here
+    if (a.dom10) {
+      const GlobalDom dmw = make_dom<GLOBAL, PACKED>(k, 0, nxt, &ctr);
+      for (uint32_t v = tid; v < V; v += nth) {
+        const int2 d = dmw.load10(v);
+        bad |= d.x > d.y;
+        k.glb[v] = d.x; k.gub[v] = d.y;
+      }
+    } else
     for (uint32_t v = tid; v < V; v += nth)
       bad |= __hip_atomic_load(&k.glb[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > __hip_atomic_load(&k.gub[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (bad) atomicOr(&misc[M_FAIL], 1u);
@@ -2439,6 +2524,7 @@ struct ConstDom {
   SumTab sums;
   __device__ __forceinline__ int2 load_var(uint32_t v) const { return make_int2(lb[v], ub[v]); }
   __device__ __forceinline__ bool any_sums() const { return sums.count != 0; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return sums.mul_off; }
   __device__ __forceinline__ int2 load(uint32_t v) const {
     if (v - sums.first < sums.count) return sum_read(*this, sums, v);
     if (v >= n_vars) { const int c = cval[v - n_vars]; return make_int2(c, c); }

@@ -444,11 +444,59 @@ def test_config3_random_binary_csp_full_size(ctx):
     ref = om.consistency(L, U, None)
     assert (ref[3] == 2).all() and ((ref[0] != L) | (ref[1] != U)).sum() > V
     ctx.set_model(V, props)
-    for opts in ({}, {"force_path": 2, "team": 16}):
+    for opts in ({}, {"force_path": 2, "team": 16}, {"hull": 1, "force_path": 1}):
+        if opts.pop("hull", 0):
+            ctx.set_hull(0, 999)  # the declared hull lets the 50 000-variable store sit in LDS as 10-bit cells
         for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
         got = ctx.propagate(L, U, E.full_active(4, P))
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
+    assert ctx.last_plan()["global_dom"] == 2
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_ten_bit_lds_cells(ctx, seed):
+    """The HBM-resident variant with a declared hull of at most 1024 values keeps the domains in LDS as 10-bit cells (three per
+    u64, CAS narrowing): random binary/ternary CSPs with offsets and constants, planted and failing, against the oracle."""
+    V, P, N = 200 + 50 * seed, 1500 + 400 * seed, 60
+    props, lb, ub, sol = random_csp(880 + seed, V, P, planted=seed != 1, dom=(-100, 900))
+    L, U = random_nodes(890 + seed, lb, ub, N, sol if seed != 1 else None, p_narrow=0.2 if seed != 1 else 0.04)
+    act = random_active(895 + seed, N, P, p_off=0.1)
+    om = orc.OracleModel(V, props)
+    ref = om.consistency(L, U, act)
+    ctx.set_model(V, props)
+    ctx.set_hull(-100, 900)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 2, "packed": 1, "word_level": 1}.items():
+        ctx.set_option(k, v)
+    got = ctx.propagate(L, U, act)
+    assert ctx.last_plan()["global_dom"] == 2
+    assert_parity(ref[:4], got[:4], f"10-bit cells seed={seed}")
+    gi = ctx.propagate_implicit(L, U)
+    assert_parity(om.consistency(L, U, None)[:4], gi[:4], f"10-bit cells implicit seed={seed}")
+    ctx.set_option("global_dom", 0)
+    ctx.set_model(V, props)
+
+
+def test_mul3_with_addition_views(ctx):
+    """XEqYMulZ takes arbitrary views (x_eq_y_mul_z.rs:99-105): Addition offsets on all three operands, constants, negative
+    factors staying out of the unpinned corner (non-negative operand ranges)."""
+    rng = np.random.default_rng(2026)
+    units, V = [], 12
+    for _ in range(40):
+        x, y, z = (int(t) for t in rng.choice(V, size=3, replace=False))
+        ops = [M.Addition(M.Identity(x), int(rng.integers(-4, 5))), M.Addition(M.Identity(y), int(rng.integers(0, 4))),
+               M.Addition(M.Identity(z), int(rng.integers(0, 4)))]
+        if rng.random() < 0.2:
+            ops[2] = M.Constant(int(rng.integers(0, 5)))
+        units.append(M.XEqYMulZ(*ops))
+    for i in range(V - 1):
+        units.append(M.XLessY(M.Identity(i), M.Addition(M.Identity(i + 1), 6)))
+    props = M.lower_units(units, V)
+    lb0, ub0 = np.zeros(V, np.int32), np.full(V, 30, np.int32)
+    L, U = random_nodes(4711, lb0, ub0, 80, None, p_narrow=0.3)
+    act = random_active(4712, 80, len(units), p_off=0.1)
+    ref, got = both(ctx, V, props, L, U, act, "mul3 with views")
+    assert got[4]["steps3"] > 0 and (ref[3] == 0).any() and (ref[3] != 0).any()
 
 
 def test_device_branching_matches_host_branching(ctx):

@@ -22,7 +22,7 @@ for line in open(summary):
         dur = float(m.group(2))
 records = 3 * n * (n - 1) // 2                      # N-queens x[i] != x[j] + k decomposition
 words = (records + 63) // 64
-compulsory = nodes * (16 * n + (8 * words if active == "explicit" else 0))
+compulsory = nodes * (8 * n + (8 * words if active == "explicit" else 0))  # reads the contract forces (bench.py node_bytes)
 fetch, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
 d = {
     "n": n, "nodes_per_launch": nodes, "active": active, "kernel": kern, "grid": int(grid),
