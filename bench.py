@@ -460,6 +460,23 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                      "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "implicit_active", "grid")},
                      "note": "per node: one pcp_propagate_device(n_nodes=1) + pcp_branch_device + a 16-byte D2H of the counters (the round's only sync)"})
         del ds
+        # the same 256-node DFS with the stack, the branching and the stop test on the device (pcp_dfs_device): the host enqueues
+        # steps and reads 8 bytes of state per 64 steps
+        ctx.stats_reset()
+        ctx.dfs_device(lb0, ub0, 32, capacity=1024, node_limit=32, chunk=64)
+        torch.cuda.synchronize()
+        ctx.stats_reset()
+        t0 = time.perf_counter()
+        r = ctx.dfs_device(lb0, ub0, 256, capacity=1024, node_limit=256, chunk=64)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        sd = ctx.stats_read()
+        if r["nodes"] != st.num_nodes or r["failed"] != st.num_failed_node:
+            raise SystemExit(f"pcp_dfs_device disagrees with the host-driven DFS: {r['nodes']}/{r['failed']} vs {st.num_nodes}/{st.num_failed_node}")
+        legs.append({"name": "C2-dfs-256-device-side-stack", "nodes": r["nodes"], "seconds": dt, "us_per_node": dt / r["nodes"] * 1e6,
+                     "steps_per_s": sd["steps"] / dt, "evaluated_per_s": sd["evaluated"] / dt,
+                     "note": "pcp_dfs_device: per node a team-scratch memset + the fixpoint kernel + a 1-workgroup branch/stack kernel, no host sync inside a 64-step chunk; "
+                             "bound by the kernels (the fixpoint of a node this deep in the dive), not by the enqueue rate"})
     for dive in (500, 3000):
         if f"deep{dive}" in want:
             reset_opts()

@@ -206,6 +206,32 @@ int32_t pcp_branch_device(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, con
 int32_t pcp_branch_device_set(pcp_ctx* ctx, uint32_t n_nodes, const uint64_t* bits, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                               const uint8_t* status, uint64_t* child_bits, uint64_t* child_active, uint32_t* counts, void* hip_stream);
 
+/* ---- the reference's search loop, one node per step, without the host in the loop -----------------------------------------------
+ * ≡ OneSolution / AllSolution<Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>>> over a VectorStack
+ * (search/mod.rs:45-52, search/engine/one_solution.rs:92-105), optionally under StopNode (search/stop_node.rs:47-62): each step
+ * pops the node on top of a LIFO stack of implicit-active nodes, runs its propagation fixpoint (one node = the reference's
+ * one-consistency-call-per-node pattern, all CUs on that node), and branches it in place — exactly the reference's left-first
+ * order.  n_steps steps are ENQUEUED on hip_stream with no host synchronisation in between: the kernels read the stack pointer
+ * from device memory.  Steps after the stack has emptied (or `stop` was raised: solution found / node limit / error) do nothing.
+ *   lb, ub           : [capacity][n_vars] device rows; rows [0, *sp) are the open nodes, row *sp - 1 the top
+ *   sp, stop         : device uint32 each (the caller initialises *sp = 1 with the root in row 0, *stop = 0)
+ *   status           : [capacity] device scratch
+ *   counters         : device uint64[5] = { nodes, solutions, failed nodes, error (1 stack overflow, 2 hull violation), internal },
+ *                      accumulated (the caller zeroes them)
+ *   first_solution   : [n_vars] device or NULL: the first solution found
+ * Interval mode only. */
+typedef struct {
+  int32_t* lb;
+  int32_t* ub;
+  uint32_t capacity;
+  uint32_t* sp;
+  uint32_t* stop;
+  uint8_t* status;
+  uint64_t* counters;
+  int32_t* first_solution;
+} pcp_dfs_state;
+int32_t pcp_dfs_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
+
 /* Counters accumulate on the device across pcp_propagate_device calls. */
 int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
 int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */

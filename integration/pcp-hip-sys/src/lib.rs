@@ -85,6 +85,20 @@ pub struct pcp_plan {
     pub list_cap: u32,
 }
 
+/// The device-resident DFS of `pcp_dfs_device`: a LIFO stack of implicit-active nodes and its 8 bytes of state.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct pcp_dfs_state {
+    pub lb: *mut i32,
+    pub ub: *mut i32,
+    pub capacity: u32,
+    pub sp: *mut u32,
+    pub stop: *mut u32,
+    pub status: *mut u8,
+    pub counters: *mut u64, // nodes, solutions, failed, error, internal
+    pub first_solution: *mut i32,
+}
+
 pub enum pcp_ctx {}
 
 extern "C" {
@@ -105,6 +119,11 @@ extern "C" {
     pub fn pcp_branch_device(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
                              child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, counts: *mut u32,
                              hip_stream: *mut c_void) -> i32; // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter
+    pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
+                                 status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
+                                 hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains
+    pub fn pcp_dfs_device(ctx: *mut pcp_ctx, st: *const pcp_dfs_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
+                          hip_stream: *mut c_void) -> i32; // OneSolution/AllSolution<Propagation<Brancher<..>>> under StopNode, n_steps nodes
     pub fn pcp_stats_reset(ctx: *mut pcp_ctx, hip_stream: *mut c_void) -> i32;
     pub fn pcp_stats_read(ctx: *mut pcp_ctx, out: *mut pcp_stats, hip_stream: *mut c_void) -> i32;
     pub fn pcp_last_kernel_ms(ctx: *mut pcp_ctx, ms: *mut f32) -> i32;

@@ -62,6 +62,8 @@ struct pcp_ctx {
   void* d_stage = nullptr; size_t cap_stage = 0;
 
   pcp_plan last_plan{};   // geometry of the last launch (pcp_last_plan)
+  const uint32_t* dfs_sp = nullptr;    // set by pcp_dfs_device around its launches: LaunchArgs::sp_ptr / stop_ptr
+  const uint32_t* dfs_stop = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool ev_valid = false;
   int max_dyn_lds_set = 0;
@@ -727,6 +729,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       a.dom10 = 1u; a.dom10_lo = c->hull_lo; a.retry_flag = c->d_retry + 1;
     }
   }
+  a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.live_in = bt->active_in;
   a.status = bt->status;
@@ -769,7 +772,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
   c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, dom10 ? 2u : a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
-  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation (d_retry[1])
   if (Bp && !hull_fits16) {
@@ -784,7 +787,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     plan2.grid = (n_nodes + Bp / 2 - 1) / (Bp / 2);
     HIP_TRY(c, launch_fixpoint(a2, plan2, stream));
   }
-  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (implicit && bt->active_out && P) {
     // the `active` rows on request: record r is live iff it is not entailed under the final domains
     if (c->has_groups) {
@@ -796,8 +799,41 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     }
   } else if (c->has_groups && bt->active_out)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
-  c->ev_valid = true;
+  c->ev_valid = !c->dfs_sp;
   return PCP_OK;
+}
+
+static int32_t dfs_enqueue_steps(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n, uint32_t stop_on_solution, uint64_t node_limit, hipStream_t stream) {
+  pcp_device_batch bt;
+  memset(&bt, 0, sizeof(bt));
+  bt.lb_in = st->lb; bt.ub_in = st->ub; bt.lb_out = st->lb; bt.ub_out = st->ub; bt.status = st->status;  // in place, implicit-active
+  int32_t rc = PCP_OK;
+  for (uint32_t i = 0; i < n && rc == PCP_OK; ++i) {
+    rc = pcp_propagate_device(c, 1, &bt, stream);
+    if (rc == PCP_OK) {
+      hipError_t e = launch_dfs_step(c->n_vars, st->lb, st->ub, st->status, st->capacity, st->sp, st->stop,
+                                     reinterpret_cast<unsigned long long*>(st->counters), st->first_solution, stop_on_solution,
+                                     (unsigned long long)node_limit, stream);
+      if (e != hipSuccess) rc = hip_fail(c, e, "launch_dfs_step");
+    }
+  }
+  return rc;
+}
+
+int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream) {
+  if (!c || !st) return PCP_ERR_ARG;
+  if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_dfs_device runs interval-mode models only");
+  if (!st->lb || !st->ub || !st->sp || !st->stop || !st->status || !st->counters || st->capacity < 2) return fail(c, PCP_ERR_ARG, "null buffer / capacity < 2");
+  // Plain launches on the caller's stream, three per step (team scratch memset, fixpoint, step).  Replaying the steps from captured
+  // HIP graphs was built and measured: no faster (a step is bound by its kernels, ~55 us of fixpoint at this depth, not by the
+  // host's enqueue rate) and not reliable across re-used buffers on this ROCm — dropped.
+  const int64_t keep_path = c->opt_force_path;
+  c->opt_force_path = 2;  // one node per step: the team geometry
+  c->dfs_sp = st->sp; c->dfs_stop = st->stop;
+  const int32_t rc = dfs_enqueue_steps(c, st, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
+  c->dfs_sp = nullptr; c->dfs_stop = nullptr;
+  c->opt_force_path = keep_path;
+  return rc;
 }
 
 int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,

@@ -115,6 +115,9 @@ struct LaunchArgs {
   uint32_t only_marked;      // 1 = second launch of a packed call: run only tiles whose nodes carry kStatusRetry
   uint32_t epoch;            // launch stamp compared with *retry_flag
   uint32_t* retry_flag;      // device word of the context
+  const uint32_t* sp_ptr;    // device-side DFS (pcp_dfs_device): the node to run is row *sp_ptr - 1 of the buffers below (nothing to do
+                             //     when *sp_ptr == 0 or *stop_ptr != 0); null = rows [0, n_nodes)
+  const uint32_t* stop_ptr;
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -170,6 +173,12 @@ hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t*
 hipError_t launch_set_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t set_words, int32_t base, uint32_t words, const uint64_t* bits, const int32_t* lb,
                              const int32_t* ub, const uint64_t* active, const uint8_t* status, uint64_t* child_bits, uint64_t* child_active,
                              uint32_t* child_base, uint32_t* counts, uint32_t reverse, hipStream_t stream);
+
+// One step of the device-side DFS after the fixpoint of the top node: count it, branch it in place (right child over the parent's
+// row, left child on top) or pop it, keep the first solution.
+hipError_t launch_dfs_step(uint32_t n_vars, int32_t* lb, int32_t* ub, const uint8_t* status, uint32_t capacity, uint32_t* sp, uint32_t* stop,
+                           unsigned long long* counters, int32_t* first_solution, uint32_t stop_on_solution, unsigned long long node_limit,
+                           hipStream_t stream);
 
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,

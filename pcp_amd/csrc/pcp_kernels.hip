@@ -1893,7 +1893,15 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 // The fixpoint kernel.  grid = ceil(n_nodes / B) (team == 1)  or  n_nodes * team (B == 1).
 // ------------------------------------------------------------------------------------------------
 template <int B, bool GLOBAL, bool COMPACT, bool PACKED, bool IMPLICIT>
-__global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a) {
+__global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
+  LaunchArgs a = a_in;
+  if (a.sp_ptr) {
+    // device-side DFS: this launch runs the node on top of the stack (one logical node: n_nodes == 1, team geometry)
+    const uint32_t sp = *a.sp_ptr;
+    if (sp == 0 || *a.stop_ptr) return;
+    const size_t off = (size_t)(sp - 1) * a.m.n_vars;
+    a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
+  }
   static_assert(!GLOBAL || B == 1, "the global-domain variant runs one node per block");
   static_assert(!PACKED || (!GLOBAL && B >= 8 && B % 4 == 0), "packed tiles: LDS-resident, a multiple of four nodes");
   static_assert(B <= 32, "fail / todo masks are 32 bits wide");
@@ -2650,6 +2658,86 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
   uint64_t* a0 = child_active + (size_t)rowL * words;
   uint64_t* a1 = child_active + (size_t)rowR * words;
   for (uint32_t w = tid; w < words; w += nth) { const uint64_t x = pa[w]; a0[w] = x; a1[w] = x; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side DFS step (pcp_dfs_device): what OneSolution / AllSolution do with the node Propagation::enter has just propagated
+// (search/engine/one_solution.rs:92-105, search/monitor.rs:19-68, search/stop_node.rs:47-62): count it; True -> a solution
+// (the first one is kept), False -> a failure, both pop the node; Unknown -> Brancher<FirstSmallestVar, MiddleVal, BinarySplit>
+// (brancher.rs:52-71): the right child `x > v` replaces the parent's row, the left child `x <= v` goes on top, so the next
+// step takes the left child first like the reference's reversed push (one_solution.rs:46-51).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dfs_step_kernel(uint32_t V, int32_t* __restrict__ lb, int32_t* __restrict__ ub, const uint8_t* __restrict__ status,
+                                                       uint32_t capacity, uint32_t* __restrict__ sp_ptr, uint32_t* __restrict__ stop,
+                                                       unsigned long long* __restrict__ counters, int32_t* __restrict__ first_solution,
+                                                       uint32_t stop_on_solution, unsigned long long node_limit) {
+  const uint32_t tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t sp = *sp_ptr;
+  if (sp == 0 || *stop) return;
+  const uint32_t node = sp - 1;
+  const uint32_t st = status[node];
+  int32_t* plb = lb + (size_t)node * V;
+  int32_t* pub = ub + (size_t)node * V;
+  __shared__ unsigned long long best[4];
+  uint32_t new_sp = sp - 1;
+  if (st == PCP_UNKNOWN) {
+    unsigned long long key = ~0ull;
+    for (uint32_t v = tid; v < V; v += nth) {
+      const unsigned long long size = (unsigned long long)((long long)pub[v] - (long long)plb[v] + 1);
+      if (size > 1) key = min(key, (size << 32) | v);
+    }
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+    if ((tid & 63) == 0) best[tid >> 6] = key;
+    __syncthreads();
+    key = best[0];
+    for (uint32_t w = 1; w < (nth >> 6); ++w) key = min(key, best[w]);
+    if (key != ~0ull && sp < capacity) {
+      const uint32_t var = (uint32_t)key;
+      const long long s2 = (long long)plb[var] + (long long)pub[var];
+      const int32_t val = (int32_t)(s2 / 2);  // MiddleVal (middle_val.rs:25-27)
+      int32_t* l0 = lb + (size_t)sp * V;      // the left child, on top
+      int32_t* u0 = ub + (size_t)sp * V;
+      __syncthreads();
+      for (uint32_t v = tid; v < V; v += nth) {
+        const int32_t a0 = plb[v], b0 = pub[v];
+        l0[v] = a0;
+        u0[v] = (v == var) ? min(b0, val) : b0;
+        if (v == var) plb[v] = max(a0, val + 1);  // the parent's row becomes the right child
+      }
+      new_sp = sp + 1;
+    } else if (key != ~0ull) {
+      if (tid == 0) { counters[3] = 1; *stop = 1u; }  // stack overflow
+      new_sp = sp;
+    }
+  }
+  if (tid == 0) {
+    const unsigned long long n = ++counters[0];
+    if (st == PCP_TRUE) {
+      if (counters[1]++ == 0 && first_solution) counters[4] = 1;  // flag for the copy below
+      if (stop_on_solution) *stop = 1u;
+    } else if (st == PCP_FALSE) {
+      ++counters[2];
+    } else if (st > PCP_UNKNOWN) {
+      counters[3] = 2; *stop = 1u;  // a node the engine refused (PCP_STATUS_HULL)
+    }
+    if (node_limit && n >= node_limit) *stop = 1u;  // StopNode (stop_node.rs:57-62)
+    *sp_ptr = new_sp;
+  }
+  if (st == PCP_TRUE && first_solution) {
+    __syncthreads();
+    if (counters[4] == 1) {
+      for (uint32_t v = tid; v < V; v += nth) first_solution[v] = plb[v];
+      __syncthreads();
+      if (tid == 0) counters[4] = 2;
+    }
+  }
+}
+hipError_t launch_dfs_step(uint32_t n_vars, int32_t* lb, int32_t* ub, const uint8_t* status, uint32_t capacity, uint32_t* sp, uint32_t* stop,
+                           unsigned long long* counters, int32_t* first_solution, uint32_t stop_on_solution, unsigned long long node_limit,
+                           hipStream_t stream) {
+  hipLaunchKernelGGL(dfs_step_kernel, dim3(1), dim3(256), 0, stream, n_vars, lb, ub, status, capacity, sp, stop, counters, first_solution,
+                     stop_on_solution, node_limit);
+  return hipGetLastError();
 }
 
 // the scan alone (set mode branches with its own kernel, pcp_set.hip)

@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -47,6 +47,11 @@ class PcpPlan(C.Structure):
 class DeviceBatch(C.Structure):
     _fields_ = [("lb_in", C.c_void_p), ("ub_in", C.c_void_p), ("lb_out", C.c_void_p), ("ub_out", C.c_void_p),
                 ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p), ("bits_in", C.c_void_p), ("bits_out", C.c_void_p)]
+
+
+class DfsState(C.Structure):
+    _fields_ = [("lb", C.c_void_p), ("ub", C.c_void_p), ("capacity", C.c_uint32), ("sp", C.c_void_p), ("stop", C.c_void_p), ("status", C.c_void_p),
+                ("counters", C.c_void_p), ("first_solution", C.c_void_p)]
 
 
 class EngineUnavailable(RuntimeError):
@@ -99,13 +104,14 @@ def load_library():
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
+    L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -259,6 +265,36 @@ class Context:
             return None if t is None else C.c_void_p(t.data_ptr())
         self._check(self._L.pcp_branch_device_set(self._h, n_nodes, p(bits), p(lb), p(ub), p(active), p(status), p(child_bits), p(child_active),
                                                   p(counts), C.c_void_p(stream_ptr)))
+
+    def dfs_device(self, lb0, ub0, n_steps: int, capacity: int = 4096, stop_on_solution: bool = True, node_limit: int = 0, chunk: int = 256):
+        """pcp_dfs_device: the reference's one-node-per-step DFS entirely on the device.  Runs until the stack is empty, a stop
+        condition holds or n_steps steps were enqueued (in chunks of `chunk` steps between two reads of the 8-byte state).
+        Returns dict(nodes, solutions, failed, error, open, steps_enqueued, first_solution)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        V = self.n_vars
+        lb = torch.zeros((capacity, V), dtype=torch.int32, device=dev)
+        ub = torch.zeros((capacity, V), dtype=torch.int32, device=dev)
+        lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(dev)
+        ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(dev)
+        state = torch.tensor([1, 0], dtype=torch.int32, device=dev)  # sp, stop
+        status = torch.zeros(capacity, dtype=torch.uint8, device=dev)
+        counters = torch.zeros(5, dtype=torch.int64, device=dev)
+        sol = torch.zeros(V, dtype=torch.int32, device=dev)
+        st = DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), sol.data_ptr())
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        done = 0
+        while done < n_steps:
+            k = min(chunk, n_steps - done)
+            self._check(self._L.pcp_dfs_device(self._h, C.byref(st), k, int(bool(stop_on_solution)), int(node_limit), C.c_void_p(stream)))
+            done += k
+            sp, stop = state.cpu().tolist()
+            if sp == 0 or stop:
+                break
+        cn = counters.cpu().tolist()
+        sp, stop = state.cpu().tolist()
+        return {"nodes": cn[0], "solutions": cn[1], "failed": cn[2], "error": cn[3], "open": sp, "stopped": bool(stop), "steps_enqueued": done,
+                "first_solution": sol.cpu().numpy() if cn[1] else None}
 
     def stats_reset(self, stream_ptr: int = 0):
         self._check(self._L.pcp_stats_reset(self._h, C.c_void_p(stream_ptr)))

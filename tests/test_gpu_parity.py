@@ -482,18 +482,32 @@ def test_mul3_with_addition_views(ctx):
     factors staying out of the unpinned corner (non-negative operand ranges)."""
     rng = np.random.default_rng(2026)
     units, V = [], 12
-    for _ in range(40):
-        x, y, z = (int(t) for t in rng.choice(V, size=3, replace=False))
-        ops = [M.Addition(M.Identity(x), int(rng.integers(-4, 5))), M.Addition(M.Identity(y), int(rng.integers(0, 4))),
-               M.Addition(M.Identity(z), int(rng.integers(0, 4)))]
-        if rng.random() < 0.2:
-            ops[2] = M.Constant(int(rng.integers(0, 5)))
-        units.append(M.XEqYMulZ(*ops))
+    val = np.full(V, -1, np.int64)  # a planted assignment: variables 0..5 are factors, 6..11 products
+    val[:6] = rng.integers(0, 5, size=6)
+    while len(units) < 40:
+        x = int(rng.integers(6, 12))
+        y, z = (int(t) for t in rng.choice(6, size=2, replace=False))
+        b, c = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+        const = rng.random() < 0.2
+        zc = int(rng.integers(0, 5)) if const else int(val[z]) + c
+        prod = (int(val[y]) + b) * zc
+        if val[x] < 0:
+            a = int(rng.integers(-4, 5))
+            if not 0 <= prod - a <= 30:
+                continue
+            val[x] = prod - a
+        else:
+            a = prod - int(val[x])
+            if not -4 <= a <= 4:
+                continue
+        units.append(M.XEqYMulZ(M.Addition(M.Identity(x), a), M.Addition(M.Identity(y), b), M.Constant(zc) if const else M.Addition(M.Identity(z), c)))
     for i in range(V - 1):
-        units.append(M.XLessY(M.Identity(i), M.Addition(M.Identity(i + 1), 6)))
+        units.append(M.XLessY(M.Identity(i), M.Addition(M.Identity(i + 1), 31)))
     props = M.lower_units(units, V)
     lb0, ub0 = np.zeros(V, np.int32), np.full(V, 30, np.int32)
-    L, U = random_nodes(4711, lb0, ub0, 80, None, p_narrow=0.3)
+    L1, U1 = random_nodes(4711, lb0, ub0, 40, val, p_narrow=0.3)    # boxes around the planted assignment
+    L2, U2 = random_nodes(4713, lb0, ub0, 40, None, p_narrow=0.15)  # arbitrary boxes (mostly inconsistent)
+    L, U = np.concatenate([L1, L2]), np.concatenate([U1, U2])
     act = random_active(4712, 80, len(units), p_off=0.1)
     ref, got = both(ctx, V, props, L, U, act, "mul3 with views")
     assert got[4]["steps3"] > 0 and (ref[3] == 0).any() and (ref[3] != 0).any()
@@ -561,6 +575,30 @@ def test_device_resident_search(ctx, n, batch):
         one = DeviceSearch(ctx, batch=1, capacity=4096).run(lb0, ub0, all_solutions=False, keep_solutions=1)
         ss1, _, _, sol1 = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=False)
         assert one.num_nodes == ss1["num_nodes"] and np.array_equal(one.solutions[0], sol1)
+
+
+@pytest.mark.parametrize("n", [1, 4, 6, 8, 10])
+def test_device_side_dfs(ctx, n):
+    """pcp_dfs_device: the reference's one-node-per-step search with no host in the loop == the oracle's DFS, node for node:
+    first solution (one_solution.rs:121-128 statuses), all solutions (all_solution.rs:70), StopNode (stop_node.rs:83-104)."""
+    props = M.nqueens_props(n) if n > 1 else M.lower_units([], 1)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1}.items():
+        ctx.set_option(k, v)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    om = orc.OracleModel(n, props)
+    ss1, _, _, sol1 = om.search(lb0, ub0, all_solutions=False)
+    one = ctx.dfs_device(lb0, ub0, 100000, capacity=256, stop_on_solution=True)
+    assert (one["nodes"], one["solutions"], one["failed"], one["error"]) == (ss1["num_nodes"], ss1["num_solution"], ss1["num_failed_node"], 0)
+    if ss1["num_solution"]:
+        assert np.array_equal(one["first_solution"], sol1)
+    ssa, _, _, _ = om.search(lb0, ub0, all_solutions=True)
+    al = ctx.dfs_device(lb0, ub0, 100000, capacity=256, stop_on_solution=False, chunk=97)
+    assert (al["nodes"], al["solutions"], al["failed"], al["open"]) == (ssa["num_nodes"], ssa["num_solution"], ssa["num_failed_node"], 0)
+    if n == 6:
+        lim = ctx.dfs_device(lb0, ub0, 100000, capacity=256, stop_on_solution=False, node_limit=10)
+        assert lim["nodes"] == 10 and lim["stopped"]
+    assert ctx.propagate(lb0[None], ub0[None])[3][0] in (0, 1, 2)  # the context still serves ordinary calls
 
 
 def test_parallel_search_device_single_rank(ctx):
