@@ -260,7 +260,8 @@ int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
  *   "block_threads" 256/512/1024, "nodes_per_block" 0 = auto, "force_path" (0 auto, 1 batch LDS kernel, 2 team kernel),
  *   "team" workgroups per node, "list_cap", "global_dom" 1 = domains stay in HBM (2: 10-bit LDS cells allowed), "dom10" 0 = never use
  *   10-bit cells, "implicit_active" 0 = materialise rows for active_in NULL, "group_level" 0 = no group test, "packed" 0 = never use 16-bit cells,
- *   "word_level" 0 = never use the word-group sweep, "branch_reverse" 1 = pcp_branch_device writes child k of the batch
+ *   "word_level" 0 = never use the word-group sweep, "solo_cascade" 0 = a wake-up round with one changed variable is an ordinary round
+ *   (1, the default: its records are re-run in place and a bound jumps over the values assigned neighbours forbid), "branch_reverse" 1 = pcp_branch_device writes child k of the batch
  *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
  * Unknown key -> PCP_ERR_ARG. */
 int32_t pcp_set_option(pcp_ctx* ctx, const char* key, int64_t value);

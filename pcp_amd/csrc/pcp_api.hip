@@ -73,6 +73,7 @@ struct pcp_ctx {
   int64_t opt_nodes_per_block = 0;  // 0 = auto
   int64_t opt_force_path = 0;       // 0 auto, 1 batch, 2 team
   int64_t opt_team = 0;             // 0 = auto
+  int64_t opt_solo = 1;             // 1 = single-variable rounds re-run in place with the forbidden-value jump (pcp_kernels.hip, rounds c0)
   int64_t opt_list_cap = 2048;
   int64_t opt_global_dom = 0;       // 1 = force the HBM-resident-domain variant (tests)
   int64_t opt_branch_reverse = 0;   // 1 = pcp_branch_device writes the children in reverse order (row n_children-1-k)
@@ -564,6 +565,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "force_path") {
     if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "force_path must be 0, 1 or 2");
     c->opt_force_path = value;
+  } else if (k == "solo_cascade") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "solo_cascade must be 0 or 1");
+    c->opt_solo = value;
   } else if (k == "team") {
     if (value < 0 || value > 4096) return fail(c, PCP_ERR_ARG, "team must be in [0,4096]");
     c->opt_team = value;
@@ -711,6 +715,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;
+  a.solo = (uint32_t)c->opt_solo;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.m.gdesc = (c->word_level && c->opt_group_level) ? c->d_gdesc : nullptr; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   // with a declared hull there is no retry launch: a tile outside the hull raises the STICKY violation word (d_retry[1]),
   // which stays set until pcp_stats_read has reported it — whatever is launched in between
@@ -828,7 +833,7 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   // HIP graphs was built and measured: no faster (a step is bound by its kernels, ~55 us of fixpoint at this depth, not by the
   // host's enqueue rate) and not reliable across re-used buffers on this ROCm — dropped.
   const int64_t keep_path = c->opt_force_path;
-  c->opt_force_path = 2;  // one node per step: the team geometry
+  if (!keep_path) c->opt_force_path = 2;  // one node per step: the team geometry unless the caller forced a path
   c->dfs_sp = st->sp; c->dfs_stop = st->stop;
   const int32_t rc = dfs_enqueue_steps(c, st, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
   c->dfs_sp = nullptr; c->dfs_stop = nullptr;

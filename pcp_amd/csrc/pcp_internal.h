@@ -109,6 +109,7 @@ struct LaunchArgs {
   uint32_t packed;           // 1 = 16-bit packed LDS domains (every bound within +-kPackedMax); tiles that do not fit mark
                              //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
   uint32_t adj_cache;        // 1 = (n_vars + 1) words of LDS behind the carve hold a copy of m.adj_off
+  uint32_t solo;             // 1 = a round with a single changed variable re-runs its records in place and jumps over forbidden values (rounds, c0)
   uint32_t dom10;            // global_dom launches only: 1 = the node's domains sit in LDS after all, as 10-bit (lb - lo, ub - lo) cells, three
                              //     per u64 (a declared hull of at most 1024 values: 50 000 variables = 130 KB), behind the carve
   int32_t dom10_lo;          // the hull's lower bound

@@ -26,6 +26,9 @@
 // the same greatest fixpoint as the reference's FIFO (SURVEY.md §7 "chaotic-iteration equivalence").
 #include <algorithm>
 #include <type_traits>
+#ifndef PCP_SOLO
+#define PCP_SOLO 1
+#endif
 
 #include "pcp_internal.h"
 
@@ -473,7 +476,7 @@ __host__ __device__ inline Carve carve(uint32_t dom_slots, uint32_t B, uint32_t 
   c.list_off = o; o = up(o + (size_t)list_cap * 4);
   c.tmp = o; o = up(o + 40 * 4);
   c.remaining = o; o = up(o + (size_t)B * 4);
-  c.misc = o; o = up(o + 24 * 4);
+  c.misc = o; o = up(o + 32 * 4);
   c.total = o;
   return c;
 }
@@ -491,7 +494,7 @@ size_t lds_bytes_global(uint32_t n_vars, uint32_t n_slots, uint32_t list_cap) {
 #endif  // PCP_TU == 0
 
 // misc[] indices (u32 words; STEPS2/STEPS3 are 64-bit counters occupying two words each)
-enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_TOTAL2 = 19, M_ITEMS2 = 20, M_ROUNDMASK2 = 21, M_SCAN = 22, M_OPEN0 = 23, M_WORDS = 24 };
+enum { M_FAIL = 0, M_TOTAL = 1, M_ITEMS = 2, M_ISLAST = 3, M_NARROW = 4, M_WAVES = 5, M_ROUNDMASK = 6, M_OOB = 7, M_STEPS2 = 8, M_STEPS3 = 10, M_HARD = 12, M_EVAL = 14, M_FULL = 16, M_UNK = 18, M_TOTAL2 = 19, M_ITEMS2 = 20, M_ROUNDMASK2 = 21, M_SCAN = 22, M_OPEN0 = 23, M_SOLO = 24, M_BASE_LO = 25, M_BASE_HI = 26, M_WORDS = 28 };
 
 // Summaries of a packed tile: tmin[slot] = (min -lb, min ub), tmax[slot] = (max -lb, max ub) as 16-bit pairs; of an
 // unpacked tile: summ[2*slot] = int2 minima, summ[2*slot+1] = int2 maxima.
@@ -2176,6 +2179,10 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
   // irrelevant), a barrier, the incident records run, a barrier.  The counters alternate between two slots and the old
   // `cur` mask is cleared inside the next round's pass, so nothing else needs a barrier of its own.
   bool tile_clean = false;  // no variable of any node of the tile changed: the domains are the inputs
+  uint32_t dbg_r[6] = {0, 0, 0, 0, 0, 0};  // profiling build (PCP_ABLATE & 1024): rounds by number of changed pairs, solo passes
+  unsigned long long dbg_t[5] = {0, 0, 0, 0, 0}, dbg_t0 = 0;  // and their time (100 MHz ticks)
+  uint32_t dbg_class = 0;
+  unsigned long long dbg_slow = 0;  // slowest round: ticks << 40 | pairs << 28 | items
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_total = (round & 1u) ? M_TOTAL2 : M_TOTAL, m_items = (round & 1u) ? M_ITEMS2 : M_ITEMS, m_mask = (round & 1u) ? M_ROUNDMASK2 : M_ROUNDMASK;
     // (a) compact the changed pairs of the live nodes: (node, var), the variable's adjacency offset and its degree
@@ -2209,6 +2216,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
     __syncthreads();
     const uint32_t total = misc[m_total];
     if (total == 0 || (PCP_ABLATE & 32)) { tile_clean = round == 0 && total == 0 && failm == 0; break; }
+    if (PCP_ABLATE & 1024) { dbg_class = total == 1 ? 0 : total <= 4 ? 1 : total <= 16 ? 2 : total <= C ? 3 : 4; ++dbg_r[dbg_class]; dbg_t0 = wall_clock64(); }
     if (tid == 0) {  // the other slot: last read before this round's barrier
       misc[M_WAVES] += __popc(misc[m_mask]);
       misc[(round & 1u) ? M_TOTAL : M_TOTAL2] = 0; misc[(round & 1u) ? M_ITEMS : M_ITEMS2] = 0; misc[(round & 1u) ? M_ROUNDMASK : M_ROUNDMASK2] = 0;
@@ -2227,20 +2235,21 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
         __syncthreads();
       }
       const uint32_t T = misc[m_items];
-      uint32_t my2 = 0, my3 = 0;
+      uint32_t my2 = 0, my3 = 0, myf = 0;
       // one item = one (changed var, incident record).  Runs a live record woken from variable v of node b unless a
       // lower-numbered changed variable of the same record will run it (RelaxedFifo dedup, relaxed_fifo.rs:42-48).
-      auto run_item = [&](uint32_t b, uint32_t v, uint32_t r, uint32_t lbits, const Rec rec) {
+      auto run_item = [&](uint32_t b, uint32_t v, uint32_t r, uint32_t lbits, const Rec rec) -> bool {  // true = ran and is entailed
         const uint32_t bit = 1u << (r & 31);
-        if (!IMPLICIT && !(lbits & bit)) return;  // unlinked (store.rs:200-207)
+        if (!IMPLICIT && !(lbits & bit)) return false;  // unlinked (store.rs:200-207)
         const uint32_t* cb = cur + (size_t)b * Wv;
         const uint32_t x = rec.xk & kSlotMask;
         const bool tern = (rec.xk >> 28) > PCP_LT;
-        if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) return;
-        if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) return;
-        if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
+        if (x < v && ((cb[x >> 5] >> (x & 31)) & 1u)) return false;
+        if (rec.y < v && ((cb[rec.y >> 5] >> (rec.y & 31)) & 1u)) return false;
+        if (tern && rec.z < v && ((cb[rec.z >> 5] >> (rec.z & 31)) & 1u)) return false;
         const auto dm = make_dom<GLOBAL, PACKED>(k, b, nxt, &ctr);
         if (tern) ++my3; else ++my2;
+        ++myf;
         const bool entailed = eval_record(rec, dm);
         if constexpr (!IMPLICIT) {
           if (entailed) {
@@ -2249,6 +2258,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
             if (old & bit) atomicSub(&remaining[b], 1u);
           }
         }
+        return entailed;
       };
       if (high_degree) {
         // (c1) high-degree variables (N-queens: 2997 records each): a wavefront walks an adjacency list 4 x 64 entries at
@@ -2261,50 +2271,264 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
         // With at least one pair per wavefront each wavefront takes whole pairs; with fewer (the tail of a long cascade:
         // one changed variable) every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its
         // list, so that the round is spread over the whole workgroup instead of being run by one wave.
-        const bool whole = total >= nwv;
-        for (uint32_t e = whole ? wv : 0u; e < total; e += whole ? nwv : 1u) {
-          const uint32_t id = list_id[e], b = id >> 26, v = id & ((1u << 26) - 1);
-          const uint32_t deg = list_pre[e], aoff = list_off[e];
-          const uint32_t* ap = a.m.adj + aoff;
-          const uint32_t* lrow = IMPLICIT ? nullptr : reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + b) * words);
-          for (uint32_t k0 = whole ? 0u : wv * 64 * U; k0 < deg; k0 += (whole ? 1u : nwv) * 64 * U) {
-            uint32_t r[U], lb_[U];
-            Rec rc[U];
-            bool ok[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              const uint32_t idx = k0 + u * 64 + lane;
-              ok[u] = idx < deg;
-              // the record id is only needed for its live bit (explicit rows) or to fetch the record (no payloads)
-              r[u] = (IMPLICIT && a.m.adjp) ? 0u : ap[ok[u] ? idx : 0];
-            }
-            if (a.m.adjp) {
-              // binary-only model: the record is rebuilt from the adjacency payload (a coalesced 8-byte stream next
-              // to the ids) — one dependent gather per entry (the live word) instead of two
-              const uint2* pp = a.m.adjp + aoff;
+        bool solo = false;
+        if constexpr (!GLOBAL && PCP_SOLO) solo = a.solo && total == 1 && list_pre[0] <= nwv * 64 * U && C >= 192;
+        {
+          // (c1) every piece of 4 x 64 entries is two stages: the coalesced streams (record ids, payloads) and what depends on
+          // them (live words, records without payloads).  The first stage of the NEXT piece is issued before the current one
+          // is evaluated: at 16 wavefronts per CU nothing else hides the ~2 us those loads take, and a round of a few dozen
+          // changed variables is a chain of ~40 pieces per wavefront.
+          struct Piece { uint32_t b, v, deg, aoff, k0; };
+          // Every wavefront visits every pair and takes the 256-entry pieces p with (p + e) % nwv == wv of pair e's list: a
+          // round with a single changed variable (the tail of a long cascade) is spread over the whole workgroup, and a round
+          // of a few dozen pairs is balanced to within a piece whatever the number of pairs.
+          const uint32_t k_step = nwv * 64 * U;
+          // (two copies of the loop: binary-only models carry the record in the adjacency payload and need no ids unless
+          // `active` rows are explicit; keeping them apart keeps each within the register budget)
+          auto walk = [&](auto with_payload) {
+            constexpr bool PAY = decltype(with_payload)::value;
+            constexpr bool IDS = !(IMPLICIT && PAY);
+            auto stage1 = [&](const Piece& pc, uint32_t (&r)[U], uint2 (&q)[U]) {
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                const uint2 q = pp[ok[u] ? k0 + u * 64 + lane : 0];
-                const uint32_t other = q.x & kSlotMask, kind = (q.x >> 28) & 7u;
-                const bool is_y = (q.x >> 31) != 0;
-                rc[u].xk = (is_y ? other : v) | (kind << 28);
-                rc[u].y = is_y ? v : other;
-                rc[u].z = 0;
-                rc[u].d = (int32_t)q.y;
+                const uint32_t idx = pc.k0 + u * 64 + lane;
+                const uint32_t at = pc.aoff + (idx < pc.deg ? idx : 0u);
+                r[u] = IDS ? a.m.adj[at] : 0u;
+                q[u] = PAY ? a.m.adjp[at] : make_uint2(0u, 0u);
               }
+            };
+            auto process = [&](auto solo_c, const Piece& pc, const uint32_t (&r)[U], const uint2 (&q)[U]) {
+              constexpr bool SOLO = decltype(solo_c)::value;
+              const uint32_t* cb = cur + (size_t)pc.b * Wv;
+              const auto dm = make_dom<GLOBAL, PACKED>(k, pc.b, nxt, &ctr);
+              if constexpr (IMPLICIT && PAY && PACKED && !GLOBAL) {
+                // The common case written out: binary records from payloads over packed cells, no `active` rows.  A wave is
+                // VALU-bound here (4 items per lane, ~20 of them a round per changed variable), so an item that cannot act
+                // costs the payload decode, one cell, one dedup word and the test.  With v on either side of x ◇ y + d and
+                // t = d if v is y, -d if v is x:  x != y + d can act iff lb(v) + t == ub(other) or ub(v) + t == lb(other)
+                // (fast_flag's condition), and a singleton other side forbids the value other - t for v.
+                const uint32_t* dcol = static_cast<const uint32_t*>(k.dom) + pc.b;
+                const int2 Vd = unpack16(dcol[(size_t)pc.v * k.bp]);
+                uint32_t oc[U], cw[U];
 #pragma unroll
-              for (int u = 0; u < U; ++u) lb_[u] = IMPLICIT ? ~0u : __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
+                for (int u = 0; u < U; ++u) {
+                  const uint32_t other = q[u].x & kSlotMask;
+                  oc[u] = dcol[(size_t)other * k.bp];
+                  cw[u] = cb[other >> 5];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                  const uint32_t other = q[u].x & kSlotMask, kind = (q[u].x >> 28) & 7u;
+                  const bool is_y = (q[u].x >> 31) != 0;
+                  if (!(pc.k0 + u * 64 + lane < pc.deg)) continue;
+                  if (other < pc.v && ((cw[u] >> (other & 31)) & 1u)) continue;  // RelaxedFifo dedup (relaxed_fifo.rs:42-48)
+                  ++my2;
+                  const int2 O = unpack16(oc[u]);
+                  const int d = (int32_t)q[u].y;
+                  bool act;
+                  if (kind == PCP_NEQ) {
+                    const int t = is_y ? d : -d;
+                    act = (Vd.x + t == O.y) || (Vd.y + t == O.x);
+                    if constexpr (SOLO) {
+                      if (O.x == O.y && other != pc.v) {
+                        const int f = O.x - t;
+                        const uint32_t dl = (uint32_t)(f - (int)misc[M_BASE_LO]), dh = (uint32_t)((int)misc[M_BASE_HI] - f);
+                        if (dl < 4096u) atomicOr(&list_off[64 + (dl >> 5)], 1u << (dl & 31));
+                        if (dh < 4096u) atomicOr(&list_pre[64 + (dh >> 5)], 1u << (dh & 31));
+                      }
+                    }
+                  } else {
+                    const int2 X = is_y ? O : Vd, Y = is_y ? Vd : O;
+                    const int Yl = Y.x + d, Yu = Y.y + d;
+                    act = kind == PCP_LT ? (X.y >= Yu || Yl <= X.x) : (X.x != Yl || X.y != Yu);
+                  }
+                  if (!act) continue;
+                  ++myf;
+                  Rec rec;
+                  rec.xk = (is_y ? other : pc.v) | (kind << 28);
+                  rec.y = is_y ? pc.v : other;
+                  rec.z = 0;
+                  rec.d = d;
+                  eval_record(rec, dm);
+                }
+                return;
+              }
+              uint32_t lw[U];
+              Rec rc[U];
+              if constexpr (!IMPLICIT) {
+                const uint32_t* lrow = reinterpret_cast<const uint32_t*>(a.live + (size_t)(node0 + pc.b) * words);
+#pragma unroll
+                for (int u = 0; u < U; ++u) lw[u] = __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
 #pragma unroll
               for (int u = 0; u < U; ++u) {
-                lb_[u] = IMPLICIT ? ~0u : __hip_atomic_load(lrow + (r[u] >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rc[u] = a.m.recs[r[u]];
+                if constexpr (PAY) {
+                  const uint32_t other = q[u].x & kSlotMask, kind = (q[u].x >> 28) & 7u;
+                  const bool is_y = (q[u].x >> 31) != 0;
+                  rc[u].xk = (is_y ? other : pc.v) | (kind << 28);
+                  rc[u].y = is_y ? pc.v : other;
+                  rc[u].z = 0;
+                  rc[u].d = (int32_t)q[u].y;
+                } else {
+                  rc[u] = a.m.recs[r[u]];
+                }
               }
-            }
+              // the four items together: dedup words and domains are read for all of them before the first test, and the
+              // filter proper only runs where the domains say it can act (fast_flag's conditions, per lane)
+              bool run[U];
+              int2 X[U], Y[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-              if (ok[u]) run_item(b, v, r[u], lb_[u], rc[u]);
-          }
+              for (int u = 0; u < U; ++u) {
+                const uint32_t x = rc[u].xk & kSlotMask, y = rc[u].y;
+                const uint32_t wx = cb[x >> 5], wy = cb[y >> 5];
+                bool go = pc.k0 + u * 64 + lane < pc.deg;
+                if constexpr (!IMPLICIT) go = go && ((lw[u] >> (r[u] & 31)) & 1u);  // unlinked (store.rs:200-207)
+                go = go && !(x < pc.v && ((wx >> (x & 31)) & 1u)) && !(y < pc.v && ((wy >> (y & 31)) & 1u));  // RelaxedFifo dedup (relaxed_fifo.rs:42-48)
+                run[u] = go;
+                X[u] = dm.load(x);
+                Y[u] = dm.load(y);
+              }
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                if (!run[u]) continue;
+                const uint32_t kind = rc[u].xk >> 28;
+                if constexpr (SOLO) {
+                  // x != y + d with a singleton on the other side of v: its value is forbidden for v (window marks, see c0)
+                  const uint32_t x = rc[u].xk & kSlotMask;
+                  const int2 O = (x == pc.v) ? Y[u] : X[u];
+                  if (kind == PCP_NEQ && x != rc[u].y && O.x == O.y) {
+                    const int f = (x == pc.v) ? O.x + rc[u].d : O.x - rc[u].d;
+                    const uint32_t dl = (uint32_t)(f - (int)misc[M_BASE_LO]), dh = (uint32_t)((int)misc[M_BASE_HI] - f);
+                    if (dl < 4096u) atomicOr(&list_off[64 + (dl >> 5)], 1u << (dl & 31));
+                    if (dh < 4096u) atomicOr(&list_pre[64 + (dh >> 5)], 1u << (dh & 31));
+                  }
+                }
+                if (!PAY && kind > PCP_LT) {
+                  const uint32_t z = rc[u].z;
+                  if (z < pc.v && ((cb[z >> 5] >> (z & 31)) & 1u)) continue;
+                  ++my3;
+                } else {
+                  ++my2;
+                  if (!dm.any_sums()) {
+                    const int Yl = Y[u].x + rc[u].d, Yu = Y[u].y + rc[u].d;
+                    bool act;
+                    if constexpr (IMPLICIT) act = kind == PCP_NEQ ? (X[u].x == Yu || Yl == X[u].y) : kind == PCP_LT ? (X[u].y >= Yu || Yl <= X[u].x) : (X[u].x != Yl || X[u].y != Yu);
+                    else act = kind == PCP_NEQ ? (X[u].x >= Yu || Yl >= X[u].y) : kind == PCP_LT ? (X[u].y >= Yu || Yl <= X[u].x || X[u].y < Yl) : (X[u].x != Yl || X[u].y != Yu || X[u].x == X[u].y);
+                    if (!act) continue;
+                  }
+                }
+                ++myf;
+                const bool entailed = eval_record(rc[u], dm);
+                if constexpr (!IMPLICIT) {
+                  if (entailed) {
+                    const uint32_t bit = 1u << (r[u] & 31);
+                    uint32_t* lwp = reinterpret_cast<uint32_t*>(a.live + (size_t)(node0 + pc.b) * words) + (r[u] >> 5);
+                    const uint32_t old = atomicAnd(lwp, ~bit);
+                    if (old & bit) atomicSub(&remaining[pc.b], 1u);
+                  }
+                }
+              }
+            };
+            auto k_first = [&](uint32_t e_) { return ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U; };
+            uint32_t e = 0, k0 = solo ? wv * 64 * U : k_first(0);
+            auto settle = [&]() { while (e < total && k0 >= list_pre[e]) { ++e; k0 = k_first(e); } };
+            auto piece_at = [&](uint32_t e_, uint32_t k_) { const uint32_t id = list_id[e_]; return Piece{id >> 26, id & ((1u << 26) - 1), list_pre[e_], list_off[e_], k_}; };
+            settle();
+            bool have = e < total;
+            Piece pa{0, 0, 0, 0, 0};
+            uint32_t rA[U];
+            uint2 qA[U];
+            if (have) { pa = piece_at(e, k0); stage1(pa, rA, qA); }
+            if (solo) {
+              // (c0) the tail of a cascade: ONE changed variable v of ONE node.  Its whole adjacency list is held in the
+              // workgroup's registers (one piece per wavefront), so the records are fetched once and re-run while v itself
+              // keeps changing — a pass costs two barriers instead of a round (compaction, fetch, three barriers).  And the
+              // commonest chain, a bound of v walking through values that assigned neighbours forbid (x != y + c removes a
+              // value only at a bound, x_neq_y.rs:82-93, so the reference takes one wake-up per value), is taken in one
+              // jump: every live x != y + c whose other side is a singleton marks its forbidden value in a 4096-bit window
+              // above lb(v) / below ub(v) (entries >= 64 of the pair list are free in this round), and wave 0 moves the
+              // bound to the first unmarked value.  Each skipped value is one the NEQ filter would remove at the bound, so
+              // the fixpoint is the same (it is unique); v leaves the wake list because all its records have run after its
+              // last change.
+              const uint32_t id = list_id[0], b = id >> 26, v = id & ((1u << 26) - 1);
+              uint32_t* flo = list_off + 64;
+              uint32_t* fhi = list_pre + 64;
+              uint32_t* vw = nxt + (size_t)b * Wv + (v >> 5);
+              const uint32_t vbit = 1u << (v & 31);
+              const auto dmv = make_dom<GLOBAL, PACKED>(k, b, nxt, &ctr);
+              if (tid < 128) { flo[tid] = 0; fhi[tid] = 0; }
+              if (tid == 0) { const int2 d = dmv.load(v); misc[M_BASE_LO] = (uint32_t)d.x; misc[M_BASE_HI] = (uint32_t)d.y; }
+              __syncthreads();
+              for (;;) {
+                if (have) process(std::true_type{}, pa, rA, qA);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (wv == 0) {
+                  const int blo = (int)misc[M_BASE_LO], bhi = (int)misc[M_BASE_HI];
+                  const int2 d = dmv.load(v);
+                  const bool dead = ((misc[M_FAIL] >> b) & 1u) != 0 || d.x > d.y;
+                  // first unmarked position >= off of a 4096-bit window, 64 bits per lane (4096 if there is none)
+                  auto first_free = [&](const uint32_t* win, uint32_t off) -> uint32_t {
+                    unsigned long long w = ~(((unsigned long long)win[2 * lane + 1] << 32) | win[2 * lane]);
+                    const uint32_t base = lane * 64;
+                    if (base + 63 < off) w = 0;
+                    else if (base < off) w &= ~0ull << (off - base);
+                    const unsigned long long has = __ballot(w != 0);
+                    if (!has) return 4096u;
+                    const int src = __builtin_ctzll(has);
+                    const uint32_t mine = base + (w ? (uint32_t)__builtin_ctzll(w) : 0u);
+                    return (uint32_t)__shfl((int)mine, src);
+                  };
+                  uint32_t go = 0;
+                  if (!dead) {
+                    const uint32_t pl = first_free(flo, (uint32_t)(d.x - blo));
+                    const uint32_t ph = first_free(fhi, (uint32_t)(bhi - d.y));
+                    if (lane == 0) {
+                      const int nl = min(blo + (int)pl, d.y + 1);
+                      if (nl > d.x) dmv.raise_lb(v, nl);
+                      if (nl <= d.y) {
+                        const int nu = bhi - (int)ph;
+                        if (nu < d.y) dmv.lower_ub(v, nu);
+                      }
+                      const bool failed = ((__hip_atomic_load(&misc[M_FAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> b) & 1u) != 0;
+                      const bool changed = (__hip_atomic_load(vw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & vbit) != 0;
+                      if (changed && !failed) {
+                        go = 1;
+                        atomicAnd(vw, ~vbit);
+                        const int2 d2 = dmv.load(v);
+                        misc[M_BASE_LO] = (uint32_t)d2.x; misc[M_BASE_HI] = (uint32_t)d2.y;
+                        misc[M_WAVES] += 1;
+                      }
+                    }
+                  }
+                  if (lane == 0) misc[M_SOLO] = go;
+                  flo[lane] = 0; flo[lane + 64] = 0; fhi[lane] = 0; fhi[lane + 64] = 0;
+                }
+                __syncthreads();
+                if (!misc[M_SOLO]) break;
+                if (PCP_ABLATE & 1024) ++dbg_r[5];
+              }
+              have = false;
+            }
+            while (have) {
+              k0 += k_step;
+              if (k0 >= pa.deg) { ++e; k0 = k_first(e); }
+              settle();
+              const bool have_n = e < total;
+              Piece pb = pa;
+              uint32_t rB[U];
+              uint2 qB[U];
+              if (have_n) { pb = piece_at(e, k0); stage1(pb, rB, qB); }
+              process(std::false_type{}, pa, rA, qA);
+              if (have_n) {
+                pa = pb;
+#pragma unroll
+                for (int u = 0; u < U; ++u) { rA[u] = rB[u]; qA[u] = qB[u]; }
+              }
+              have = have_n;
+            }
+          };
+          if (a.m.adjp) walk(std::true_type{}); else walk(std::false_type{});
         }
       } else {
         // (c2) low-degree variables: flat item space, load-balanced over the whole block by binary search in the
@@ -2332,11 +2556,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
           run_item(b, v, r, lbits, rec);
         }
       }
-      for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); }
-      my2 = __builtin_amdgcn_readfirstlane(my2); my3 = __builtin_amdgcn_readfirstlane(my3);
+      for (int o = 32; o > 0; o >>= 1) { my2 += __shfl_down(my2, o); my3 += __shfl_down(my3, o); myf += __shfl_down(myf, o); }
+      my2 = __builtin_amdgcn_readfirstlane(my2); my3 = __builtin_amdgcn_readfirstlane(my3); myf = __builtin_amdgcn_readfirstlane(myf);
       steps2 += my2; steps3 += my3;
       ctr.add_ev_uniform(my2 + my3);
-      ctr.add_full_uniform(my2 + my3);
+      ctr.add_full_uniform(myf);
     } else {
       __syncthreads();
       uint32_t rem_sub = 0;
@@ -2345,6 +2569,11 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (PCP_ABLATE & 1024) {
+      const unsigned long long dt = wall_clock64() - dbg_t0;
+      dbg_t[dbg_class] += dt;
+      if (dt > (dbg_slow >> 40)) dbg_slow = dt << 40 | (unsigned long long)(total & 0xfffu) << 28 | (misc[m_items] & 0xfffffffu);
+    }
     uint32_t* t = cur; cur = nxt; nxt = t;  // the old `cur` is cleared by the next round's pass
   }
 
@@ -2453,15 +2682,28 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
       nr += __hip_atomic_load(&a.team_counters[(size_t)node0 * kTeamCounters + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
+    if (!(PCP_ABLATE & 1024)) {
     if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
     if (nr) atomicAdd((unsigned long long*)&a.stats->narrowings, nr);
     if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
     if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[M_WAVES]));
-    atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
+    }
+    if (PCP_ABLATE & 1024) atomicMax((unsigned long long*)&a.stats->nodes, dbg_slow);
+    else atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[M_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1)));
-    if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    if (nf && !(PCP_ABLATE & 1024)) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
     if ((PCP_ABLATE & 320) == 320) atomicAdd((unsigned long long*)&a.stats->nodes, wall_clock64() - t_entry);  // whole block
+    if (PCP_ABLATE & 1024) {  // rounds histogram: per class count << 40 | ticks, summed over tiles; slowest tile's rounds time in waves
+      atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)dbg_r[0] << 40 | dbg_t[0]);
+      atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)dbg_r[1] << 40 | dbg_t[1]);
+      atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)dbg_r[2] << 40 | dbg_t[2]);
+      atomicAdd((unsigned long long*)&a.stats->evaluated, (unsigned long long)dbg_r[3] << 40 | dbg_t[3]);
+      atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)dbg_r[4] << 40 | dbg_t[4]);
+      const unsigned long long tt = dbg_t[0] + dbg_t[1] + dbg_t[2] + dbg_t[3] + dbg_t[4];
+      // slowest tile: total ticks << 40 | ticks in (>C) << 20 | ticks in (17..C)
+      atomicMax((unsigned long long*)&a.stats->waves, tt << 40 | (dbg_t[4] & 0xfffff) << 20 | (dbg_t[3] & 0xfffff));
+    }
   }
 }
 

@@ -275,6 +275,47 @@ def test_group_level_sweep(ctx, kinds):
     ctx.set_option("group_level", 1)
 
 
+def test_solo_cascade_forbidden_value_jump(ctx):
+    """The tail of a cascade (one changed variable per round) is re-run in place, and a bound that walks through values
+    forbidden by assigned neighbours is moved in one jump (pcp_kernels.hip, rounds c0) — same fixpoint as the reference's
+    one-value-per-wake-up chain, with the shortcut on and off, packed and 32-bit cells, explicit and implicit nodes."""
+    # (1) partial N-queens assignments: every unassigned queen's bounds climb through the columns / diagonals taken
+    n = 72
+    props = M.nqueens_props(n)
+    rng = np.random.default_rng(11)
+    N = 48
+    L, U = np.ones((N, n), np.int32), np.full((N, n), n, np.int32)
+    for i in range(N):
+        k = int(rng.integers(n // 4, n - 1))
+        placed = []
+        for r_ in rng.permutation(n)[:k]:  # k queens placed without a clash; propagation then fails about a third of the nodes
+            free = [c for c in range(1, n + 1) if all(c != pc and abs(c - pc) != abs(int(r_) - pr) for pr, pc in placed)]
+            if not free:
+                break
+            c = int(rng.choice(free))
+            placed.append((int(r_), c))
+            L[i, r_] = c; U[i, r_] = c
+    try:
+        for solo in (1, 0):
+            for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 16, "packed": 0}, {"nodes_per_block": 1}, {"force_path": 2}):
+                ref, got = both(ctx, n, props, L, U, None, f"solo cascade nqueens solo={solo} {opts}", solo_cascade=solo, **({"force_path": 1} | opts))
+        assert (ref[3] == M.FALSE).any() and (ref[3] != M.FALSE).any()
+        act = random_active(5, N, orc.OracleModel(n, props).n_units, p_off=0.1)
+        for solo in (1, 0):
+            both(ctx, n, props, L, U, act, f"solo cascade nqueens explicit rows solo={solo}", solo_cascade=solo, force_path=1, nodes_per_block=16)
+        # (2) one variable against 3900 constants: x != c for c in [0, 2000) and (2099, 4000] leaves [2000, 2099] — two jumps
+        units = [M.XNeqY(M.Identity(0), M.Constant(c)) for c in list(range(0, 2000)) + list(range(2100, 4001))]
+        units += [M.XLessY(M.Identity(1), M.Identity(0))]  # x1 < x0: follows the jump in the next round
+        props2 = M.lower_units(units, 2)
+        L2 = np.array([[0, 0], [5, 0], [0, 0], [2000, 1990], [1000, 0]], np.int32)
+        U2 = np.array([[4000, 4000], [3990, 4000], [1999, 10], [2099, 2050], [3000, 999]], np.int32)
+        for solo in (1, 0):
+            ref, got = both(ctx, 2, props2, L2, U2, None, f"solo cascade constants solo={solo}", solo_cascade=solo, force_path=1, nodes_per_block=1)
+        assert ref[3][2] == M.FALSE and (ref[0][0] == [2000, 0]).all() and (ref[1][0] == [2099, 2098]).all()
+    finally:
+        ctx.set_option("solo_cascade", 1)
+
+
 @pytest.mark.parametrize("n,dive", [(60, 25), (90, 60)])
 def test_packed_tiles_deep_search_nodes(ctx, n, dive):
     """Open nodes taken from deep in a device-resident search (many assigned queens: the range tests clear little, the
