@@ -2316,40 +2316,49 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
                   oc[u] = dcol[(size_t)other * k.bp];
                   cw[u] = cb[other >> 5];
                 }
+                // no branch until an item can act: the predicates are folded into one mask per piece
+                const bool all_neq = a.m.uniform_kind == PCP_NEQ;
+                uint32_t actm = 0;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                  const uint32_t other = q[u].x & kSlotMask, kind = (q[u].x >> 28) & 7u;
+                  const uint32_t other = q[u].x & kSlotMask;
                   const bool is_y = (q[u].x >> 31) != 0;
-                  if (!(pc.k0 + u * 64 + lane < pc.deg)) continue;
-                  if (other < pc.v && ((cw[u] >> (other & 31)) & 1u)) continue;  // RelaxedFifo dedup (relaxed_fifo.rs:42-48)
-                  ++my2;
+                  const bool live = (pc.k0 + u * 64 + lane < pc.deg) && !(other < pc.v && ((cw[u] >> (other & 31)) & 1u));  // RelaxedFifo dedup (relaxed_fifo.rs:42-48)
+                  my2 += live ? 1u : 0u;
                   const int2 O = unpack16(oc[u]);
                   const int d = (int32_t)q[u].y;
-                  bool act;
-                  if (kind == PCP_NEQ) {
-                    const int t = is_y ? d : -d;
-                    act = (Vd.x + t == O.y) || (Vd.y + t == O.x);
-                    if constexpr (SOLO) {
-                      if (O.x == O.y && other != pc.v) {
-                        const int f = O.x - t;
-                        const uint32_t dl = (uint32_t)(f - (int)misc[M_BASE_LO]), dh = (uint32_t)((int)misc[M_BASE_HI] - f);
-                        if (dl < 4096u) atomicOr(&list_off[64 + (dl >> 5)], 1u << (dl & 31));
-                        if (dh < 4096u) atomicOr(&list_pre[64 + (dh >> 5)], 1u << (dh & 31));
-                      }
-                    }
-                  } else {
+                  const int t = is_y ? d : -d;
+                  bool act = (Vd.x + t == O.y) || (Vd.y + t == O.x);
+                  if (!all_neq) {
+                    const uint32_t kind = (q[u].x >> 28) & 7u;
                     const int2 X = is_y ? O : Vd, Y = is_y ? Vd : O;
                     const int Yl = Y.x + d, Yu = Y.y + d;
-                    act = kind == PCP_LT ? (X.y >= Yu || Yl <= X.x) : (X.x != Yl || X.y != Yu);
+                    if (kind != PCP_NEQ) act = kind == PCP_LT ? (X.y >= Yu || Yl <= X.x) : (X.x != Yl || X.y != Yu);
                   }
-                  if (!act) continue;
-                  ++myf;
-                  Rec rec;
-                  rec.xk = (is_y ? other : pc.v) | (kind << 28);
-                  rec.y = is_y ? pc.v : other;
-                  rec.z = 0;
-                  rec.d = d;
-                  eval_record(rec, dm);
+                  actm |= (live && act) ? 1u << u : 0u;
+                  if constexpr (SOLO) {
+                    if (live && O.x == O.y && other != pc.v && (all_neq || ((q[u].x >> 28) & 7u) == PCP_NEQ)) {
+                      const int f = O.x - t;
+                      const uint32_t dl = (uint32_t)(f - (int)misc[M_BASE_LO]), dh = (uint32_t)((int)misc[M_BASE_HI] - f);
+                      if (dl < 4096u) atomicOr(&list_off[64 + (dl >> 5)], 1u << (dl & 31));
+                      if (dh < 4096u) atomicOr(&list_pre[64 + (dh >> 5)], 1u << (dh & 31));
+                    }
+                  }
+                }
+                if (actm) {
+#pragma unroll
+                  for (int u = 0; u < U; ++u) {
+                    if (!((actm >> u) & 1u)) continue;
+                    const uint32_t other = q[u].x & kSlotMask, kind = (q[u].x >> 28) & 7u;
+                    const bool is_y = (q[u].x >> 31) != 0;
+                    ++myf;
+                    Rec rec;
+                    rec.xk = (is_y ? other : pc.v) | (kind << 28);
+                    rec.y = is_y ? pc.v : other;
+                    rec.z = 0;
+                    rec.d = (int32_t)q[u].y;
+                    eval_record(rec, dm);
+                  }
                 }
                 return;
               }

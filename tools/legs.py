@@ -10,4 +10,4 @@ for l in c.get("legs", []):
         print(f"{l['name']:45s} nodes={l['nodes']:6d} ms={l['kernel_ms']['median']:9.3f} steps/s={l['steps_per_s']:.3e} eval/s={l['evaluated_per_s']:.3e} eval={l['evaluated_per_launch']:.3e} full={l['full_evals_per_launch']:.3e} "
               f"narrow={l['narrowings_per_launch']:.0f} waves/node={l['waves_per_node']:.2f} hbm_frac={l['hbm_frac']:.4f} status={l['status_false_true_unknown']} B={l['plan']['nodes_per_block']} wl={l['plan'].get('word_level')}")
     else:
-        print(f"{l['name']:45s} nodes={l['nodes']:6d} us/node={l['us_per_node']:.2f} nodes/s={l['nodes'] / l['seconds']:.3e} steps/s={l['steps_per_s']:.3e} kernel_us={l['last_kernel_us']:.1f} team={l['plan']['team']}")
+        print(f"{l['name']:45s} nodes={l['nodes']:6d} us/node={l['us_per_node']:.2f} nodes/s={l['nodes'] / l['seconds']:.3e} steps/s={l['steps_per_s']:.3e} kernel_us={l.get('last_kernel_us', float('nan')):.1f} team={l.get('plan', {}).get('team', '-')}")
