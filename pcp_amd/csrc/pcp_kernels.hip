@@ -2301,15 +2301,21 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
               constexpr bool SOLO = decltype(solo_c)::value;
               const uint32_t* cb = cur + (size_t)pc.b * Wv;
               const auto dm = make_dom<GLOBAL, PACKED>(k, pc.b, nxt, &ctr);
-              if constexpr (IMPLICIT && PAY && PACKED && !GLOBAL) {
-                // The common case written out: binary records from payloads over packed cells, no `active` rows.  A wave is
+              if constexpr (IMPLICIT && PAY && !GLOBAL) if (PACKED || !dm.any_sums()) {
+                // The common case written out: binary records from payloads over LDS cells, no `active` rows, no Sum views.  A wave is
                 // VALU-bound here (4 items per lane, ~20 of them a round per changed variable), so an item that cannot act
                 // costs the payload decode, one cell, one dedup word and the test.  With v on either side of x ◇ y + d and
                 // t = d if v is y, -d if v is x:  x != y + d can act iff lb(v) + t == ub(other) or ub(v) + t == lb(other)
                 // (fast_flag's condition), and a singleton other side forbids the value other - t for v.
-                const uint32_t* dcol = static_cast<const uint32_t*>(k.dom) + pc.b;
-                const int2 Vd = unpack16(dcol[(size_t)pc.v * k.bp]);
-                uint32_t oc[U], cw[U];
+                using Cell = typename CellOf<PACKED>::type;
+                const Cell* dcol = static_cast<const Cell*>(k.dom) + pc.b;
+                auto bounds = [](const Cell c) -> int2 {  // (lb, ub)
+                  if constexpr (PACKED) return unpack16(c);
+                  else return make_int2(-c.x, c.y);
+                };
+                const int2 Vd = bounds(dcol[(size_t)pc.v * k.bp]);
+                Cell oc[U];
+                uint32_t cw[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                   const uint32_t other = q[u].x & kSlotMask;
@@ -2325,7 +2331,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
                   const bool is_y = (q[u].x >> 31) != 0;
                   const bool live = (pc.k0 + u * 64 + lane < pc.deg) && !(other < pc.v && ((cw[u] >> (other & 31)) & 1u));  // RelaxedFifo dedup (relaxed_fifo.rs:42-48)
                   my2 += live ? 1u : 0u;
-                  const int2 O = unpack16(oc[u]);
+                  const int2 O = bounds(oc[u]);
                   const int d = (int32_t)q[u].y;
                   const int t = is_y ? d : -d;
                   bool act = (Vd.x + t == O.y) || (Vd.y + t == O.x);
