@@ -63,6 +63,7 @@ struct pcp_ctx {
 
   pcp_plan last_plan{};   // geometry of the last launch (pcp_last_plan)
   const uint32_t* dfs_sp = nullptr;    // set by pcp_dfs_device around its launches: LaunchArgs::sp_ptr / stop_ptr
+  size_t dfs_team_words = 0;           // words of d_team the step kernel zeroes after each step (0: the launch clears them itself)
   const uint32_t* dfs_stop = nullptr;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool ev_valid = false;
@@ -763,7 +764,9 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     const size_t per_node_words = 4 + Wv + 2 * kTeamCounters;
     const size_t nwords = (size_t)n_nodes * per_node_words + 2;
     if ((rc = ensure(c, c->d_team, c->cap_team, nwords))) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->d_team, 0, nwords * 4, stream));
+    // (inside pcp_dfs_device the step kernel hands the scratch back zeroed: only the first step of a call clears it here)
+    if (!(c->dfs_sp && c->dfs_team_words == nwords)) HIP_TRY(c, hipMemsetAsync(c->d_team, 0, nwords * 4, stream));
+    c->dfs_team_words = c->dfs_sp ? nwords : 0;
     uint32_t* base = c->d_team;
     a.team_counters = reinterpret_cast<uint64_t*>(base);                 // [n_nodes][kTeamCounters] u64 (8-byte aligned at base)
     a.team_ticket = base + (size_t)n_nodes * 2 * kTeamCounters;
@@ -818,7 +821,7 @@ static int32_t dfs_enqueue_steps(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n
     if (rc == PCP_OK) {
       hipError_t e = launch_dfs_step(c->n_vars, st->lb, st->ub, st->status, st->capacity, st->sp, st->stop,
                                      reinterpret_cast<unsigned long long*>(st->counters), st->first_solution, stop_on_solution,
-                                     (unsigned long long)node_limit, stream);
+                                     (unsigned long long)node_limit, c->dfs_team_words ? c->d_team : nullptr, (uint32_t)c->dfs_team_words, stream);
       if (e != hipSuccess) rc = hip_fail(c, e, "launch_dfs_step");
     }
   }
@@ -834,9 +837,9 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   // host's enqueue rate) and not reliable across re-used buffers on this ROCm — dropped.
   const int64_t keep_path = c->opt_force_path;
   if (!keep_path) c->opt_force_path = 2;  // one node per step: the team geometry unless the caller forced a path
-  c->dfs_sp = st->sp; c->dfs_stop = st->stop;
+  c->dfs_sp = st->sp; c->dfs_stop = st->stop; c->dfs_team_words = 0;
   const int32_t rc = dfs_enqueue_steps(c, st, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
-  c->dfs_sp = nullptr; c->dfs_stop = nullptr;
+  c->dfs_sp = nullptr; c->dfs_stop = nullptr; c->dfs_team_words = 0;
   c->opt_force_path = keep_path;
   return rc;
 }

@@ -179,7 +179,7 @@ hipError_t launch_set_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t set_wor
 // row, left child on top) or pop it, keep the first solution.
 hipError_t launch_dfs_step(uint32_t n_vars, int32_t* lb, int32_t* ub, const uint8_t* status, uint32_t capacity, uint32_t* sp, uint32_t* stop,
                            unsigned long long* counters, int32_t* first_solution, uint32_t stop_on_solution, unsigned long long node_limit,
-                           hipStream_t stream);
+                           uint32_t* team_scratch, uint32_t team_words, hipStream_t stream);
 
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,

@@ -2927,8 +2927,11 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
 __global__ void __launch_bounds__(256) dfs_step_kernel(uint32_t V, int32_t* __restrict__ lb, int32_t* __restrict__ ub, const uint8_t* __restrict__ status,
                                                        uint32_t capacity, uint32_t* __restrict__ sp_ptr, uint32_t* __restrict__ stop,
                                                        unsigned long long* __restrict__ counters, int32_t* __restrict__ first_solution,
-                                                       uint32_t stop_on_solution, unsigned long long node_limit) {
+                                                       uint32_t stop_on_solution, unsigned long long node_limit,
+                                                       uint32_t* __restrict__ team_scratch, uint32_t team_words) {
   const uint32_t tid = threadIdx.x, nth = blockDim.x;
+  // the team kernel's per-node scratch (tickets, merged masks, counters) is handed back zeroed for the next step's launch
+  for (uint32_t i = tid; i < team_words; i += nth) team_scratch[i] = 0;
   const uint32_t sp = *sp_ptr;
   if (sp == 0 || *stop) return;
   const uint32_t node = sp - 1;
@@ -2991,9 +2994,9 @@ __global__ void __launch_bounds__(256) dfs_step_kernel(uint32_t V, int32_t* __re
 }
 hipError_t launch_dfs_step(uint32_t n_vars, int32_t* lb, int32_t* ub, const uint8_t* status, uint32_t capacity, uint32_t* sp, uint32_t* stop,
                            unsigned long long* counters, int32_t* first_solution, uint32_t stop_on_solution, unsigned long long node_limit,
-                           hipStream_t stream) {
+                           uint32_t* team_scratch, uint32_t team_words, hipStream_t stream) {
   hipLaunchKernelGGL(dfs_step_kernel, dim3(1), dim3(256), 0, stream, n_vars, lb, ub, status, capacity, sp, stop, counters, first_solution,
-                     stop_on_solution, node_limit);
+                     stop_on_solution, node_limit, team_scratch, team_words);
   return hipGetLastError();
 }
 
