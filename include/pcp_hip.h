@@ -144,7 +144,9 @@ int32_t pcp_model_n_units(const pcp_ctx* ctx, uint32_t* n_units, uint32_t* n_pro
  * A node whose bounds leave the declared hull is a contract violation: pcp_propagate returns PCP_ERR_CONTRACT;
  * pcp_propagate_device leaves that node's outputs untouched, sets its status to PCP_STATUS_HULL and raises a sticky device
  * flag: the next pcp_stats_read returns PCP_ERR_CONTRACT however many launches happened in between (pcp_branch_device counts
- * such nodes in counts[4]).  pcp_model_reset forgets the hull. */
+ * such nodes in counts[4]).  pcp_model_reset forgets the hull.
+ * The same refusal (status PCP_STATUS_HULL, outputs untouched, sticky flag) meets a node of pcp_propagate_device with a bound
+ * beyond +-PCP_BOUND_MAX, hull or not: every tile checks the bounds it stages. */
 int32_t pcp_model_set_hull(pcp_ctx* ctx, int32_t lo, int32_t hi);
 #define PCP_STATUS_HULL 0xFE
 

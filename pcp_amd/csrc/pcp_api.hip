@@ -717,6 +717,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;
   a.solo = (uint32_t)c->opt_solo;
+  a.violation = c->d_retry + 1;
   a.packed = Bp ? 1u : 0u; a.word_level = Bp ? wl_used : 0u; a.m.wdesc = c->d_wdesc; a.m.gdesc = (c->word_level && c->opt_group_level) ? c->d_gdesc : nullptr; a.retry_flag = c->d_retry; a.epoch = Bp ? ++c->epoch : 0u;
   // with a declared hull there is no retry launch: a tile outside the hull raises the STICKY violation word (d_retry[1]),
   // which stays set until pcp_stats_read has reported it — whatever is launched in between
@@ -896,7 +897,7 @@ int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
   if (flag) {  // some launch since the last read met a node outside the declared hull
     HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));
     c->trusted_epoch = 0;
-    return fail(c, PCP_ERR_CONTRACT, "a node's bounds lie outside the hull declared with pcp_model_set_hull (status PCP_STATUS_HULL)");
+    return fail(c, PCP_ERR_CONTRACT, "a node's bounds lie outside the hull declared with pcp_model_set_hull, or beyond +-(2^29 - 1) (status PCP_STATUS_HULL)");
   }
   return PCP_OK;
 }

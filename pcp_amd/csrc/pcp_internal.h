@@ -110,6 +110,7 @@ struct LaunchArgs {
                              //     their nodes kStatusRetry, raise *retry_flag to `epoch` and leave the outputs untouched
   uint32_t adj_cache;        // 1 = (n_vars + 1) words of LDS behind the carve hold a copy of m.adj_off
   uint32_t solo;             // 1 = a round with a single changed variable re-runs its records in place and jumps over forbidden values (rounds, c0)
+  uint32_t* violation;       // sticky device word (pcp_stats_read reports and clears it): a node was refused with PCP_STATUS_HULL
   uint32_t dom10;            // global_dom launches only: 1 = the node's domains sit in LDS after all, as 10-bit (lb - lo, ub - lo) cells, three
                              //     per u64 (a declared hull of at most 1024 values: 50 000 variables = 130 KB), behind the carve
   int32_t dom10_lo;          // the hull's lower bound
@@ -138,6 +139,7 @@ struct LaunchArgs {
 
 constexpr uint32_t kTeamCounters = 6;
 constexpr int32_t kPackedMax = 16383;   // |bound| limit of the packed tiles: sums of two bounds fit int16
+constexpr int kBoundMax = (1 << 29) - 1;  // the engine's arithmetic (sums of two bounds and an offset) is exact for |bound| <= kBoundMax
 constexpr uint8_t kStatusRetry = 0xFE;  // internal: never visible to the caller (the second launch overwrites it)
 
 struct LaunchPlan {

@@ -1983,16 +1983,21 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
       }
     } else {
     // the node's rows in lb_out/ub_out ARE the working domains (the host copied the inputs there); only check them
-    bool bad = false;
+    bool bad = false, wide = false;
     if (g == 0)
-      for (uint32_t v = tid; v < V; v += nth) bad |= a.lb_in[(size_t)node0 * V + v] > a.ub_in[(size_t)node0 * V + v];
+      for (uint32_t v = tid; v < V; v += nth) {
+        const int l = a.lb_in[(size_t)node0 * V + v], u = a.ub_in[(size_t)node0 * V + v];
+        bad |= l > u;
+        wide |= (l < -kBoundMax) | (l > kBoundMax) | (u < -kBoundMax) | (u > kBoundMax);
+      }
     for (uint32_t v = V + tid; v < S; v += nth) { int2 d; d.x = d.y = a.m.const_val[v - V]; dom[v - V] = d; }
-    if (bad) atomicOr(&misc[M_FAIL], 1u);
+    if (bad | wide) atomicOr(&misc[M_FAIL], 1u);
+    if (wide) atomicOr(&misc[M_OOB], 1u);
     }
   } else {
     // slot-major: the 2*B bound loads of a slot (one per node row, lanes = consecutive slots: coalesced) are issued
     // together — one memory round trip per pass instead of one per node
-    uint32_t badm = 0;
+    uint32_t badm = 0, widem = 0;
     bool oob = false;
     for (uint32_t v = tid; v < S; v += nth) {
       int lbv[B], ubv[B];
@@ -2015,14 +2020,18 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
           oob |= (lbv[b] < -kPackedMax) | (lbv[b] > kPackedMax) | (ubv[b] < -kPackedMax) | (ubv[b] > kPackedMax);
           dom[(size_t)v * BP + b] = pack16(lbv[b], ubv[b]);
         } else {
+          // the engine's arithmetic is exact for |bound| < 2^29 (pcp_hip.h): a node beyond that is refused, not wrapped
+          if (((lbv[b] < -kBoundMax) | (lbv[b] > kBoundMax) | (ubv[b] < -kBoundMax) | (ubv[b] > kBoundMax)) && (uint32_t)b < nb) widem |= 1u << b;
           dom[(size_t)v * BP + b] = make_int2(-lbv[b], ubv[b]);  // LDS holds (-lb, ub)
         }
       }
     }
-    if (badm) atomicOr(&misc[M_FAIL], badm);
+    if (badm | widem) atomicOr(&misc[M_FAIL], badm | widem);  // (a refused node is inert like a failed one)
     if (PACKED && oob) atomicOr(&misc[M_OOB], 1u);
+    if (!PACKED && widem) atomicOr(&misc[M_OOB], widem);
   }
   __syncthreads();
+  if (!PACKED && misc[M_OOB] && tid == 0) atomicMax(a.violation, 1u);  // sticky: reported by pcp_stats_read
   if (PACKED && misc[M_OOB]) {
     // some bound of this tile does not fit the packed cells: hand the tile back untouched (pcp_api.hip launches the
     // 32-bit kernel right behind this one; it runs exactly the tiles marked here)
@@ -2654,6 +2663,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
     // in place and nothing narrowed in this tile: the rows in HBM already hold the result
   } else {
     for (uint32_t b = 0; b < nb; ++b) {
+      if (!PACKED && ((misc[M_OOB] >> b) & 1u)) continue;  // a refused node's outputs are left alone
       int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
       int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
       bool bad = false;
@@ -2681,7 +2691,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
     // Consistency::consistency (store.rs:250-256): False if a propagate failed, True if no subscription
     // remains (every live propagator got entailed), else Unknown.
     const bool none_open = IMPLICIT ? !((misc[M_UNK] >> tid) & 1u) : remaining[tid] == 0;
-    a.status[node0 + tid] = failed ? (uint8_t)PCP_FALSE : (none_open ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
+    const bool refused = !PACKED && ((misc[M_OOB] >> tid) & 1u);  // a bound beyond +-kBoundMax
+    a.status[node0 + tid] = refused ? kStatusRetry : failed ? (uint8_t)PCP_FALSE : (none_open ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
   }
   if (tid == 0) {
     unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[M_STEPS2]);

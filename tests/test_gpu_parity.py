@@ -275,6 +275,44 @@ def test_group_level_sweep(ctx, kinds):
     ctx.set_option("group_level", 1)
 
 
+def test_device_entry_refuses_bounds_beyond_bound_max(ctx):
+    """pcp_propagate_device checks the bounds it stages: a node with a bound beyond +-PCP_BOUND_MAX is refused (status
+    PCP_STATUS_HULL, outputs untouched, sticky flag reported by pcp_stats_read) instead of wrapping i32; its neighbours in the
+    tile are propagated as usual.  32-bit tiles, the team geometry and the HBM-resident variant."""
+    import torch
+    V, P, N = 60, 400, 37
+    props, lb, ub, sol = random_csp(77, V, P, planted=True, p_tern=0.2, dom=(-300000, 300000))
+    L, U = random_nodes(78, lb, ub, N, sol, p_narrow=0.3)
+    om = orc.OracleModel(V, props)
+    ref = om.consistency(L, U, None)
+    dev = torch.device("cuda:0")
+    Lb, Ub = L.copy(), U.copy()
+    Lb[5, 3] = -M.PCP_BOUND_MAX - 1
+    Ub[20, 11] = M.PCP_BOUND_MAX + 7
+    ok = np.ones(N, bool); ok[[5, 20]] = False
+    ctx.set_model(V, props)
+    for opts in ({"force_path": 1, "nodes_per_block": 8}, {"force_path": 1, "nodes_per_block": 1}, {"force_path": 1, "global_dom": 1}):
+        for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
+            ctx.set_option(k, v)
+        t_lb, t_ub = torch.from_numpy(Lb).to(dev), torch.from_numpy(Ub).to(dev)
+        t_st = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ctx.stats_reset()
+        ctx.propagate_device(N, t_lb, t_ub, t_lb, t_ub, None, None, t_st)
+        with pytest.raises(E.PcpError) as ei:
+            ctx.stats_read()
+        assert ei.value.code == -2, opts
+        ctx.stats_read()
+        st, gl, gu = t_st.cpu().numpy(), t_lb.cpu().numpy(), t_ub.cpu().numpy()
+        assert st[5] == 0xFE and st[20] == 0xFE, (opts, st)
+        assert np.array_equal(st[ok], ref[3][ok]), opts
+        live = ok & (ref[3] != M.FALSE)
+        assert np.array_equal(gl[live], ref[0][live]) and np.array_equal(gu[live], ref[1][live]), opts
+        if not opts.get("global_dom"):
+            assert np.array_equal(gl[[5, 20]], Lb[[5, 20]]) and np.array_equal(gu[[5, 20]], Ub[[5, 20]]), opts
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "global_dom": 0}.items():
+        ctx.set_option(k, v)
+
+
 def test_solo_cascade_forbidden_value_jump(ctx):
     """The tail of a cascade (one changed variable per round) is re-run in place, and a bound that walks through values
     forbidden by assigned neighbours is moved in one jump (pcp_kernels.hip, rounds c0) — same fixpoint as the reference's
@@ -442,6 +480,16 @@ def test_golomb_distinct_sum_network(ctx):
         got = ctx.propagate(L, U, A)
         assert_parity(ref[:4], got[:4], f"golomb {opts}")
         assert got[4]["steps3"] > 0
+    # the bench leg's own size: a 4096-node frontier (grown with the engine), every node against the oracle
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "team": 0}.items():
+        ctx.set_option(k, v)
+    L4, U4, A4, _ = S.bfs_frontier(ctx, lb0, ub0, 4096, max_rounds=24)
+    assert L4.shape[0] >= 2048
+    ref4 = om.consistency(L4, U4, A4)
+    got4 = ctx.propagate(L4, U4, A4)
+    assert_parity(ref4[:4], got4[:4], f"golomb frontier of {L4.shape[0]} nodes")
+    got4i = ctx.propagate_implicit(L4, U4)
+    assert_parity(om.consistency(L4, U4, None)[:4], got4i[:4], f"golomb frontier of {L4.shape[0]} nodes [implicit]")
 
 
 @pytest.mark.parametrize("n", [6, 9])
@@ -480,7 +528,7 @@ def test_config3_random_binary_csp_full_size(ctx):
     the HBM-resident-domain variant runs), 500 000 `x ◇ y + c` constraints, planted solution, long cascades."""
     V, P = 50_000, 500_000
     props, lb, ub, sol = planted_binary_csp(0xC3, V, P)
-    L, U = unit_narrowing_prefix(0xC3 + 1, lb, ub, sol, 4)
+    L, U = unit_narrowing_prefix(0xC3 + 1, lb, ub, sol, 32)
     om = orc.OracleModel(V, props)
     ref = om.consistency(L, U, None)
     assert (ref[3] == 2).all() and ((ref[0] != L) | (ref[1] != U)).sum() > V
@@ -490,7 +538,7 @@ def test_config3_random_binary_csp_full_size(ctx):
             ctx.set_hull(0, 999)  # the declared hull lets the 50 000-variable store sit in LDS as 10-bit cells
         for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, **opts}.items():
             ctx.set_option(k, v)
-        got = ctx.propagate(L, U, E.full_active(4, P))
+        got = ctx.propagate(L, U, E.full_active(L.shape[0], P))
         assert_parity(ref[:4], got[:4], f"config3 {opts}")
     assert ctx.last_plan()["global_dom"] == 2
 
