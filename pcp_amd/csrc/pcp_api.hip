@@ -46,6 +46,7 @@ struct pcp_ctx {
   uint32_t n_slots = 0;
   bool has_ternary = false;
   uint32_t uniform_kind = 0xFFFFFFFFu;
+  uint32_t max_deg = 0;
   bool consts_fit16 = true;      // every interned constant within +-kPackedMax (packed tiles)
   size_t cap_recs = 0, cap_adj = 0, cap_adj_off = 0, cap_const = 0;
 
@@ -210,6 +211,8 @@ int32_t finalize_model(pcp_ctx* c) {
   if (n_slots >= kMaxSlots) return fail(c, PCP_ERR_UNSUPPORTED, "too many variables");
   std::vector<uint32_t> adj_off(c->n_vars + 1, 0);
   for (uint32_t v = 0; v < c->n_vars; ++v) adj_off[v + 1] = adj_off[v] + deg[v];
+  c->max_deg = 0;
+  for (uint32_t v = 0; v < c->n_vars; ++v) c->max_deg = std::max(c->max_deg, deg[v]);
   std::vector<uint32_t> adj(adj_off[c->n_vars]);
   {
     std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1);
@@ -381,7 +384,7 @@ int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   ModelDev m;
   memset(&m, 0, sizeof(m));
   m.recs = c->d_recs; m.adj_off = c->d_adj_off; m.adj = c->d_adj; m.const_val = c->d_const;
-  m.n_recs = P; m.n_vars = c->n_vars; m.n_slots = S; m.has_ternary = c->has_ternary; m.uniform_kind = c->uniform_kind;
+  m.n_recs = P; m.n_vars = c->n_vars; m.n_slots = S; m.has_ternary = c->has_ternary; m.uniform_kind = c->uniform_kind; m.max_deg = c->max_deg;
   const bool implicit = bt->active_in == nullptr && c->opt_implicit;
   const uint32_t unit_words = (c->n_units + 63) / 64;
   const uint64_t* live_in = nullptr;
@@ -712,7 +715,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   LaunchArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.recs8 = c->compact ? c->d_recs8 : nullptr; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
-  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind;
+  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
   a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.team = team; a.list_cap = list_cap_used; a.global_dom = global_dom ? 1u : 0u;
   a.adj_cache = adj_cache ? 1u : 0u;

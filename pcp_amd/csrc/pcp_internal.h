@@ -89,6 +89,7 @@ struct ModelDev {
   uint32_t n_slots;  // n_vars + number of interned constants
   uint32_t has_ternary;
   uint32_t uniform_kind;  // the kind shared by ALL records when that is NEQ or LT, else 0xFFFFFFFF (the sweep then classifies each chunk)
+  uint32_t max_deg;       // longest adjacency list of a variable
   SumTab sums;            // Sum views; with count > 0 every record takes the generic path (no compact stream, no payloads)
 };
 

@@ -2281,7 +2281,10 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
         // one changed variable) every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its
         // list, so that the round is spread over the whole workgroup instead of being run by one wave.
         bool solo = false;
-        if constexpr (!GLOBAL && PCP_SOLO) solo = a.solo && total == 1 && list_pre[0] <= nwv * 64 * U && C >= 192;
+        // (compiled for packed tiles and one-node blocks only: with it the 32-bit tile kernels spill ~70 VGPRs for a case
+        // — a lone straggler among the B nodes of such a tile — that their workloads hardly have)
+        constexpr bool kSolo = !GLOBAL && PCP_SOLO && (PACKED || B == 1);
+        if constexpr (kSolo) solo = a.solo && total == 1 && list_pre[0] <= nwv * 64 * U && C >= 192;
         {
           // (c1) every piece of 4 x 64 entries is two stages: the coalesced streams (record ids, payloads) and what depends on
           // them (live words, records without payloads).  The first stage of the NEXT piece is issued before the current one
@@ -2453,9 +2456,12 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
                 }
               }
             };
-            auto k_first = [&](uint32_t e_) { return ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U; };
-            uint32_t e = 0, k0 = solo ? wv * 64 * U : k_first(0);
-            auto settle = [&]() { while (e < total && k0 >= list_pre[e]) { ++e; k0 = k_first(e); } };
+            // (lists of at most one piece: pair e simply belongs to wavefront e % nwv)
+            const bool one_piece = a.m.max_deg <= 64u * U;
+            const uint32_t e_step = one_piece ? nwv : 1u;
+            auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U; };
+            uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
+            auto settle = [&]() { while (e < total && k0 >= list_pre[e]) { e += e_step; k0 = k_first(e); } };
             auto piece_at = [&](uint32_t e_, uint32_t k_) { const uint32_t id = list_id[e_]; return Piece{id >> 26, id & ((1u << 26) - 1), list_pre[e_], list_off[e_], k_}; };
             settle();
             bool have = e < total;
@@ -2463,7 +2469,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
             uint32_t rA[U];
             uint2 qA[U];
             if (have) { pa = piece_at(e, k0); stage1(pa, rA, qA); }
-            if (solo) {
+            if constexpr (kSolo) if (solo) {
               // (c0) the tail of a cascade: ONE changed variable v of ONE node.  Its whole adjacency list is held in the
               // workgroup's registers (one piece per wavefront), so the records are fetched once and re-run while v itself
               // keeps changing — a pass costs two barriers instead of a round (compaction, fetch, three barriers).  And the
@@ -2536,7 +2542,7 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
             }
             while (have) {
               k0 += k_step;
-              if (k0 >= pa.deg) { ++e; k0 = k_first(e); }
+              if (k0 >= pa.deg) { e += e_step; k0 = k_first(e); }
               settle();
               const bool have_n = e < total;
               Piece pb = pa;
