@@ -1619,7 +1619,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
   uint64_t pattern = 0;  // the words of a group this wavefront takes: bit positions congruent to `wave` modulo the wavefront count
   for (uint32_t i = wave; i < 64; i += nw) pattern |= 1ull << i;
   constexpr int kBatch = 4;
-  uint32_t pend[kBatch];
+  uint32_t pendv = 0;  // the pending words, word t in lane t (a dynamically indexed array would live in scratch memory)
   uint32_t npend = 0;
   uint64_t* const my_live = IMPLICIT ? nullptr : a.live + (size_t)(node0 + (lane < nb ? lane : 0u)) * words;  // lane b = node b: the word's column
   uint64_t tfl[2] = {0, 0};  // PCP_ABLATE & 128: ticks waiting for a batch's loads / processing it
@@ -1629,7 +1629,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
     uint64_t cb[kBatch];
 #pragma unroll
     for (int t = 0; t < kBatch; ++t) {
-      const uint32_t ww = pend[(uint32_t)t < npend ? t : 0];
+      const uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)pendv, (uint32_t)t < npend ? t : 0);
       rb[t] = (rec_stream + (size_t)ww * 64)[lane];
       uint64_t v = ~0ull;
       if constexpr (!IMPLICIT) v = __hip_atomic_load(my_live + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: phase A stored it
@@ -1644,12 +1644,12 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       tfl[0] += tf1 - tf0;
     }
     for (uint32_t t = 0; t < npend; ++t) {
-      uint32_t ww = pend[0];
+      const uint32_t ww = (uint32_t)__builtin_amdgcn_readlane((int)pendv, (int)t);
       RecT rsel = rb[0];
       uint64_t col = cb[0];
 #pragma unroll
       for (int u = 1; u < kBatch; ++u)
-        if (t == (uint32_t)u) { ww = pend[u]; rsel = rb[u]; col = cb[u]; }
+        if (t == (uint32_t)u) { rsel = rb[u]; col = cb[u]; }
       if (PCP_ABLATE & 4096) continue;  // profiling: nothing per word
       // alive_w: OR of the column over the nodes (lanes 0..B-1 sit in one DPP row)
       const uint64_t alive_w = IMPLICIT ? ((ww == words - 1) ? tail_mask : ~0ull)
@@ -1820,10 +1820,7 @@ __device__ __forceinline__ bool sweep_words(const LaunchArgs& a, const BlockCtx&
       while (bits) {
         const uint32_t j = __builtin_ctzll(bits);
         bits &= bits - 1;
-        // SGPR array with a dynamic index: written as selects
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u)
-          if (npend == (uint32_t)u) pend[u] = g * 64 + j;
+        pendv = (lane == npend) ? g * 64 + j : pendv;  // (a v_cndmask on the lane id)
         if (++npend == kBatch) flush();
       }
     }
