@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Randomised soak of the packed / word-group paths against the oracle (not a pytest: run it when the kernels change).
+"""Randomised soak of the packed / word-group paths and the wake-up rounds against the oracle, explicit rows and implicit nodes
+(not a pytest: run it when the kernels change).
 usage: python tools/soak.py [seconds] [seed0]"""
 import os, sys, time
 import numpy as np
@@ -38,17 +39,36 @@ while time.time() - t0 < budget:
     lb = np.full(n, lo, np.int32); ub = np.full(n, hi, np.int32)
     N = int(rng.integers(1, 140))
     L, U = random_nodes(seed0 + 7 * it, lb, ub, N, sol if planted else None, p_narrow=float(rng.uniform(0.02, 0.5)))
+    if rng.random() < 0.5:
+        # many assigned variables (the deep-tile regime: long wake-up cascades, single-variable tails, forbidden-value walks)
+        for i in range(N):
+            k = int(rng.integers(1, max(2, n - 2)))
+            vs = rng.choice(n, size=k, replace=False)
+            vals = sol[vs] if (planted and rng.random() < 0.7) else rng.integers(lo, hi + 1, size=k)
+            L[i, vs] = vals; U[i, vs] = vals
     act = random_active(seed0 + 11 * it, N, P, p_off=float(rng.uniform(0.0, 0.4)))
     om = orc.OracleModel(n, props)
     ref = om.consistency(L, U, act)
+    ref_i = om.consistency(L, U, None)
     ctx.set_model(n, props)
     if rng.random() < 0.5:
         ctx.set_hull(lo, hi)
     for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "word_level": 0}, {"nodes_per_block": 32}, {}):
         for k, v in {"nodes_per_block": 0, "packed": 1, "word_level": 1, "block_threads": int(rng.choice([256, 512, 1024])), **opts}.items():
             ctx.set_option(k, v)
+        ctx.set_option("solo_cascade", int(rng.integers(0, 2)))
         got = ctx.propagate(L, U, act)
         assert_parity(ref[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} {opts}")
-        checked += 1
+        got = ctx.propagate_implicit(L, U)
+        assert_parity(ref_i[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} {opts} [implicit]")
+        checked += 2
+    if N <= 8:  # the team geometry (one node per team of workgroups) and one-node blocks
+        for opts in ({"force_path": 2}, {"force_path": 1, "nodes_per_block": 1}):
+            for k, v in {"nodes_per_block": 0, "force_path": 0, "block_threads": 1024, **opts}.items():
+                ctx.set_option(k, v)
+            got = ctx.propagate_implicit(L, U)
+            assert_parity(ref_i[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} {opts} [implicit]")
+            checked += 1
+        ctx.set_option("force_path", 0)
     it += 1
 print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s")
