@@ -453,8 +453,8 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
     c->num_cu = prop.multiProcessorCount;
     c->lds_max = (size_t)prop.maxSharedMemoryPerMultiProcessor >= 160 * 1024 ? 160 * 1024 : 64 * 1024;
   }
-  if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), sizeof(pcp_stats)) != hipSuccess ||
-      hipMemset(c->d_stats, 0, sizeof(pcp_stats)) != hipSuccess ||
+  if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
+      hipMemset(c->d_stats, 0, kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->d_retry), 8) != hipSuccess || hipMemset(c->d_retry, 0, 8) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
     delete c;
@@ -886,17 +886,23 @@ int32_t pcp_branch_device_set(pcp_ctx* c, uint32_t n_nodes, const uint64_t* bits
 int32_t pcp_stats_reset(pcp_ctx* c, void* hip_stream) {
   if (!c) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, sizeof(pcp_stats), reinterpret_cast<hipStream_t>(hip_stream)));
+  HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, kStatSlots * sizeof(pcp_stats), reinterpret_cast<hipStream_t>(hip_stream)));
   return PCP_OK;
 }
 
 int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
   if (!c || !out) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, hipMemcpyAsync(out, c->d_stats, sizeof(pcp_stats), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
+  pcp_stats slots[kStatSlots];
+  HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats, sizeof(slots), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   uint32_t flag = 0;
   HIP_TRY(c, hipMemcpyAsync(&flag, c->d_retry + 1, 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   HIP_TRY(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+  static_assert(sizeof(pcp_stats) % sizeof(uint64_t) == 0, "pcp_stats is a struct of u64 counters");
+  memset(out, 0, sizeof(*out));
+  for (uint32_t s = 0; s < kStatSlots; ++s)
+    for (size_t i = 0; i < sizeof(pcp_stats) / sizeof(uint64_t); ++i)
+      reinterpret_cast<uint64_t*>(out)[i] += reinterpret_cast<const uint64_t*>(&slots[s])[i];
   if (flag) {  // some launch since the last read met a node outside the declared hull
     HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));
     c->trusted_epoch = 0;

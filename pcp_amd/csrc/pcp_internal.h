@@ -140,6 +140,8 @@ struct LaunchArgs {
 
 constexpr uint32_t kTeamCounters = 6;
 constexpr int32_t kPackedMax = 16383;   // |bound| limit of the packed tiles: sums of two bounds fit int16
+constexpr uint32_t kStatSlots = 64;  // the device counters are striped over this many pcp_stats structs (workgroup b adds to slot b % kStatSlots;
+                                      // pcp_stats_read sums them): same-address device atomics serialise at ~12 ns each, chip-wide
 constexpr int kBoundMax = (1 << 29) - 1;  // the engine's arithmetic (sums of two bounds and an offset) is exact for |bound| <= kBoundMax
 constexpr uint8_t kStatusRetry = 0xFE;  // internal: never visible to the caller (the second launch overwrites it)
 

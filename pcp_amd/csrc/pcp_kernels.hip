@@ -1895,6 +1895,7 @@ __device__ __forceinline__ void sweep_filtered(const LaunchArgs& a, const BlockC
 template <int B, bool GLOBAL, bool COMPACT, bool PACKED, bool IMPLICIT>
 __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
   LaunchArgs a = a_in;
+  if (!PCP_ABLATE) a.stats += blockIdx.x & (kStatSlots - 1);  // striped counters (pcp_internal.h); profiling builds keep maxima in slot 0
   if (a.sp_ptr) {
     // device-side DFS: this launch runs the node on top of the stack (one logical node: n_nodes == 1, team geometry)
     const uint32_t sp = *a.sp_ptr;

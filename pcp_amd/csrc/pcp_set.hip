@@ -21,6 +21,9 @@
 #include <algorithm>
 
 #include "pcp_internal.h"
+#ifndef PCP_ABLATE
+#define PCP_ABLATE 0  // profiling builds (tools/build_variant.py): bit 2048 = phase timers of setfix_kernel in the counters
+#endif
 
 namespace pcp {
 
@@ -254,14 +257,24 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   uint32_t* list_deg = reinterpret_cast<uint32_t*>(smem + cv.list_deg);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
   const uint32_t node = blockIdx.x;
+  pcp_stats* const st_slot = a.stats + (PCP_ABLATE ? 0u : (blockIdx.x & (kStatSlots - 1)));  // striped counters (pcp_internal.h)
   const uint64_t tail_mask = (P & 63) ? ((1ull << (P & 63)) - 1) : ~0ull;
 
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};  // profiling build: phase boundaries (100 MHz ticks)
+  if (PCP_ABLATE & 2048) tph[0] = wall_clock64();
   // ---- phase 0: stage the sets, derive their bounds ---------------------------------------------------------------------
   if (tid < 32) misc[tid] = 0;
   for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
   {
     const uint64_t* src = a.bits_in + (size_t)node * V * sw;
-    for (size_t i = tid; i < (size_t)V * sw; i += nth) bits[i] = src[i];
+    const uint32_t nwords = V * sw;
+    if (!(nwords & 1u) && !((size_t)src & 15)) {  // 16 bytes per lane: half the memory instructions of the node's 125 KB
+      const uint4* s4 = reinterpret_cast<const uint4*>(src);
+      uint4* d4 = reinterpret_cast<uint4*>(bits);
+      for (uint32_t i = tid; i < nwords / 2; i += nth) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = tid; i < nwords; i += nth) bits[i] = src[i];
+    }
   }
   __syncthreads();
   for (uint32_t v = tid; v < V; v += nth) {
@@ -274,6 +287,7 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   uint32_t narrow = 0;
   uint64_t steps2 = 0, steps3 = 0;
   uint64_t* live_row = IMPLICIT ? nullptr : a.live + (size_t)node * words;
+  if (PCP_ABLATE & 2048) tph[1] = wall_clock64();
 
   // ---- phase 1: every live propagator once (init_scheduler, store.rs:144-149) --------------------------------------------
   // Implicit nodes of an all-XNeqY model (N-queens): XNeqY::propagate is a no-op unless one operand is a singleton
@@ -331,10 +345,20 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  if (PCP_ABLATE & 2048) tph[2] = wall_clock64();
   // ---- phase 2: wake-up rounds (react + schedule as waves, store.rs:191-198) --------------------------------------------
   const bool neq_only = IMPLICIT && a.m.uniform_kind == PCP_NEQ && S == V;
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_total = (round & 1u) ? S_TOTAL2 : S_TOTAL, m_items = (round & 1u) ? S_ITEMS2 : S_ITEMS;
+    // the exact bounds of every changed variable, from its words (an emptied set: the node has failed) — one thread per
+    // variable: left to the compaction pass below (one thread per 32 variables) this rescan was most of a node's time
+    for (uint32_t v = tid; v < V; v += nth) {
+      if (!((cur[v >> 5] >> (v & 31)) & 1u)) continue;
+      const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+      bnd[v] = b;
+      if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+    }
+    __syncthreads();
     {
       uint32_t degsum = 0;
       for (uint32_t w = tid; w < Wv; w += nth) {
@@ -346,10 +370,7 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
           const uint32_t v = (w << 5) + __builtin_ctz(bitsw);
           bitsw &= bitsw - 1;
           if (v < V) {
-            // the exact bounds of a changed variable, from its words (an emptied set: the node has failed)
-            const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
-            bnd[v] = b;
-            if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+            const int2 b = bnd[v];
             // all-XNeqY model, implicit node: a propagator acts only through a SINGLETON operand, so a variable that lost
             // values but is not assigned wakes nobody (the reference wakes all of them on its Inner event: no-op steps)
             if (neq_only && b.x != b.y) { dropped |= 1u << (v & 31); continue; }
@@ -412,6 +433,7 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   }
   __syncthreads();
 
+  if (PCP_ABLATE & 2048) tph[3] = wall_clock64();
   // ---- phase 3: status.  True iff no propagator is left that is not entailed (store.rs:250-256) -------------------------------
   const bool failed = misc[S_FAIL] != 0;
   if (!failed) {
@@ -440,10 +462,18 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
   }
   __syncthreads();
 
+  if (PCP_ABLATE & 2048) tph[4] = wall_clock64();
   // ---- phase 4: write back ------------------------------------------------------------------------------------------------
   {
     uint64_t* dst = a.bits_out + (size_t)node * V * sw;
-    for (size_t i = tid; i < (size_t)V * sw; i += nth) dst[i] = bits[i];
+    const uint32_t nwords = V * sw;
+    if (!(nwords & 1u) && !((size_t)dst & 15)) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(bits);
+      uint4* d4 = reinterpret_cast<uint4*>(dst);
+      for (uint32_t i = tid; i < nwords / 2; i += nth) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = tid; i < nwords; i += nth) dst[i] = bits[i];
+    }
     for (uint32_t v = tid; v < V; v += nth) {
       const int2 b = bnd[v];
       a.lb_out[(size_t)node * V + v] = b.x;
@@ -454,16 +484,27 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
     a.status[node] = failed ? (uint8_t)PCP_FALSE : (misc[S_OPEN] ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
     const unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]);
     const unsigned long long s3 = *reinterpret_cast<unsigned long long*>(&misc[S_STEPS3]);
-    if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
-    if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
+    if (s2) atomicAdd((unsigned long long*)&st_slot->steps, s2);
+    if (s3) atomicAdd((unsigned long long*)&st_slot->steps3, s3);
     // evaluated = the pairs that were looked at: everything counted as a step except the bulk sweep's credit, plus its own few
     const unsigned long long evo = *reinterpret_cast<unsigned long long*>(&misc[S_EVAL]);
     const unsigned long long looked = s2 + s3 - (misc[S_LIVE] ? (unsigned long long)P : 0ull) + evo;
-    if (looked) { atomicAdd((unsigned long long*)&a.stats->evaluated, looked); atomicAdd((unsigned long long*)&a.stats->full_evals, looked); }
-    if (misc[S_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[S_NARROW]);
-    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(1 + misc[S_WAVES]));
-    atomicAdd((unsigned long long*)&a.stats->nodes, 1ull);
-    if (failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, 1ull);
+    if (looked) { atomicAdd((unsigned long long*)&st_slot->evaluated, looked); atomicAdd((unsigned long long*)&st_slot->full_evals, looked); }
+    if (misc[S_NARROW]) atomicAdd((unsigned long long*)&st_slot->narrowings, (unsigned long long)misc[S_NARROW]);
+    atomicAdd((unsigned long long*)&st_slot->waves, (unsigned long long)(1 + misc[S_WAVES]));
+    atomicAdd((unsigned long long*)&st_slot->nodes, 1ull);
+    if (failed) atomicAdd((unsigned long long*)&st_slot->failed_nodes, 1ull);
+  }
+  if (PCP_ABLATE & 2048) {  // staging / sweep / rounds / status / write-back ticks, summed over the nodes
+    __syncthreads();
+    if (tid == 0) {
+      tph[5] = wall_clock64();
+      atomicAdd((unsigned long long*)&st_slot->steps3, tph[1] - tph[0]);
+      atomicAdd((unsigned long long*)&st_slot->narrowings, tph[2] - tph[1]);
+      atomicAdd((unsigned long long*)&st_slot->failed_nodes, tph[3] - tph[2]);
+      atomicAdd((unsigned long long*)&st_slot->waves, tph[4] - tph[3]);
+      atomicAdd((unsigned long long*)&st_slot->evaluated, tph[5] - tph[4]);
+    }
   }
 }
 
