@@ -383,7 +383,7 @@ int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (!lds || lds > c->lds_max) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode variable store does not fit one CU's LDS (n_vars * (set_words + 1) * 8 bytes)");
   ModelDev m;
   memset(&m, 0, sizeof(m));
-  m.recs = c->d_recs; m.adj_off = c->d_adj_off; m.adj = c->d_adj; m.const_val = c->d_const;
+  m.recs = c->d_recs; m.adj_off = c->d_adj_off; m.adj = c->d_adj; m.adjp = c->have_adjp ? c->d_adjp : nullptr; m.const_val = c->d_const;
   m.n_recs = P; m.n_vars = c->n_vars; m.n_slots = S; m.has_ternary = c->has_ternary; m.uniform_kind = c->uniform_kind; m.max_deg = c->max_deg;
   const bool implicit = bt->active_in == nullptr && c->opt_implicit;
   const uint32_t unit_words = (c->n_units + 63) / 64;

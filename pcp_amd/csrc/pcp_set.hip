@@ -311,9 +311,33 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
       bulk_sweep = ns <= C;  // more assigned variables than the list holds: stream the table after all
       if (bulk_sweep) {
         const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow};
+        // four records per thread in flight; binary models rebuild the record from the adjacency payload (one coalesced
+        // load instead of an index load and a gather that depends on it)
+        constexpr int U = 4;
         for (uint32_t e = 0; e < ns; ++e) {
           const uint32_t v = list_id[e], o0 = a.m.adj_off[v], o1 = a.m.adj_off[v + 1];
-          for (uint32_t i = o0 + tid; i < o1; i += nth) { (void)eval_set(a.m.recs[a.m.adj[i]], dm, false); ++ev_only; }
+          for (uint32_t i0 = o0 + tid; i0 < o1; i0 += nth * U) {
+            Rec rc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const uint32_t i = i0 + u * nth;
+              const uint32_t at = i < o1 ? i : o0;
+              if (a.m.adjp) {
+                const uint2 q = a.m.adjp[at];
+                const uint32_t other = q.x & kSlotMask, kind = (q.x >> 28) & 7u;
+                const bool is_y = (q.x >> 31) != 0;
+                rc[u].xk = (is_y ? other : v) | (kind << 28);
+                rc[u].y = is_y ? v : other;
+                rc[u].z = 0;
+                rc[u].d = (int32_t)q.y;
+              } else {
+                rc[u] = a.m.recs[a.m.adj[at]];
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              if (i0 + u * nth < o1) { (void)eval_set(rc[u], dm, false); ++ev_only; }
+          }
         }
         if (tid == 0) { *reinterpret_cast<unsigned long long*>(&misc[S_STEPS2]) += (unsigned long long)P; misc[S_LIVE] = 1u; }
       }
