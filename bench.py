@@ -352,20 +352,18 @@ def main():
             "dtype": "i32",
             "data": "synthetic",
             "config": {
-                "workload": f"N-queens n={n}, x[i]!=x[j]+k decomposition (V={n}, P={len(props)} XNeqY), Interval<i32> domains (NOT the reference's default FDSpace/IntervalSet "
-                            f"mode: bounds-only propagation, in which near-root nodes narrow almost nothing); {args.nodes} open nodes per GPU per step = this rank's share of the "
-                            f"breadth-first frontier of the search tree, one fixpoint per node, 1 launch per step, in place on a fresh copy of the frontier per step; "
-                            + ("nodes are domains only (implicit `active`: every unit active on entry, liveness derived from the domains)" if implicit
-                               else "nodes carry explicit `active` rows (183 KB per node)"),
-                "value_is": "reference-equivalent filter steps per second: the (propagator, node) pairs the reference's scheduler would pop to reach the same fixpoints; "
-                            "most are proven no-ops in bulk (range tests over whole 64-propagator words) and never looked at individually",
+                "workload": f"N-queens n={n} (V={n}, P={len(props)} XNeqY), Interval<i32> domains (not the reference's default IntervalSet mode: see legs), "
+                            f"{args.nodes} open nodes per GPU per step = this rank's share of the BFS frontier, 1 launch per step, in place on a fresh copy; "
+                            + ("implicit-active nodes (domains only)" if implicit else "explicit `active` rows (183 KB per node)"),
+                "value_is": "reference-equivalent filter steps/s: the (propagator, node) pairs the reference's scheduler would pop; most are proven no-ops in bulk "
+                            "(steps_evaluated_per_s = pairs tested one by one)",
                 "steps_evaluated_per_s": eval_all / dt_max,
                 "full_filter_evals_per_s": full_all / dt_max,
                 "nodes_per_s": args.nodes * world * args.steps / dt_max,
                 "nodes_per_gpu": args.nodes,
                 "active_rows": args.active,
                 "plan": plan,
-                "domain_cells": "Interval<i32> bounds in and out; in LDS as 16-bit packed (-lb, ub) cells (declared hull [1,n]), i32 arithmetic in the full filter",
+                "domain_cells": "i32 bounds in/out; 16-bit packed (-lb, ub) LDS cells under the declared hull [1,n]",
                 "fresh_inputs": max(0, min(args.steps, len(pool) - args.warmup)),
                 "filter_steps_per_step_per_gpu": per_step["steps"] + per_step["steps3"],
                 "evaluated_per_step_per_gpu": per_step["evaluated"],
@@ -382,15 +380,12 @@ def main():
                 "traffic_source": (tr or {}).get("source"),
                 "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "compulsory_bytes_per_launch": compulsory,
-                "model": "achieved = compulsory HBM bytes per launch / median HIP-event kernel time: every node's (lb, ub) rows read once "
-                         "(8 B per variable and node), 8 B written per narrowing (in place: a tile that narrows nothing writes nothing back)"
-                         + ("" if implicit else ", plus every node's `active` row read once (8 B per 64 propagators)")
-                         + "; the model tables (word descriptors, records) are shared by all tiles and stay in L2.  `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of the "
-                           "committed rocprofv3 PMC passes (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half the bytes), per launch",
+                "model": "achieved = compulsory HBM bytes per launch (every node's lb/ub rows read once"
+                         + ("" if implicit else " + its `active` row")
+                         + ", 8 B written per narrowing) / median HIP-event kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, per launch",
                 "algorithmic_bytes_per_launch_survey_8d": alg_bytes,
                 "algorithmic_frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_note": "SURVEY.md §8d's 28 B per reference-equivalent step; far above 1 because those bytes are never moved (domains live in LDS, whole words are "
-                                    "cleared from range tables) — a labelled side figure, not the roofline",
+                "algorithmic_note": "SURVEY.md §8d's 28 B per reference-equivalent step: never moved (LDS-resident domains, bulk range tests) - a side figure, not the roofline",
             },
         }
         legs_req = args.legs
@@ -414,7 +409,28 @@ def main():
             out["config"]["parity_checked_nodes"] = k
         if legs_req != "none":
             legs = side_legs(ctx, torch, dev, n, props, args, set(legs_req.split(",")), L, U)
-        out["config"]["legs"] = legs
+        # the ONE JSON line stays short (the driver reads the tail of stdout): per leg its headline figures; everything else
+        # of the legs goes to stderr and to gpurun_out/bench_legs.json
+        def brief(l):
+            b = {"name": l["name"], "nodes": l.get("nodes")}
+            if isinstance(l.get("kernel_ms"), dict):
+                b["kernel_ms"] = round(l["kernel_ms"]["median"], 4)
+            for k in ("us_per_node", "steps_per_s", "nodes_per_s"):
+                if k in l:
+                    b[k] = float(f"{l[k]:.4g}")
+            if "hbm_frac" in l:
+                b["hbm_frac"] = float(f"{l['hbm_frac']:.3g}")
+            return b
+        out["config"]["legs"] = [brief(l) for l in legs]
+        if legs:
+            full = json.dumps({"legs": legs})
+            print(full, file=sys.stderr, flush=True)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_legs.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError:
+                pass
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
     if world > 1:
