@@ -2268,23 +2268,17 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
         return entailed;
       };
       if (high_degree) {
-        // (c1) high-degree variables (N-queens: 2997 records each): a wavefront walks an adjacency list 4 x 64 entries at
-        // a time — the index loads are coalesced, and the 4 x (live word, record) gathers that depend on them are all
-        // in flight together, instead of one dependent chain per item.
+        // (c1) high-degree variables (N-queens: 2997 records each): the adjacency lists are walked in pieces of 4 x 64 entries,
+        // one item per lane and u — the index / payload loads are coalesced and all four are in flight together.
         const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
         constexpr int U = 4;
-        // every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its list: a round with a
-        // single changed variable (the tail of a long cascade) is spread over the whole workgroup, not run by one wave
-        // With at least one pair per wavefront each wavefront takes whole pairs; with fewer (the tail of a long cascade:
-        // one changed variable) every wavefront visits every pair and takes the 256-entry pieces wv, wv+nwv, ... of its
-        // list, so that the round is spread over the whole workgroup instead of being run by one wave.
         bool solo = false;
         // (compiled for packed tiles and one-node blocks only: with it the 32-bit tile kernels spill ~70 VGPRs for a case
         // — a lone straggler among the B nodes of such a tile — that their workloads hardly have)
         constexpr bool kSolo = !GLOBAL && PCP_SOLO && (PACKED || B == 1);
         if constexpr (kSolo) solo = a.solo && total == 1 && list_pre[0] <= nwv * 64 * U && C >= 192;
         {
-          // (c1) every piece of 4 x 64 entries is two stages: the coalesced streams (record ids, payloads) and what depends on
+          // every piece is two stages: the coalesced streams (record ids, payloads) and what depends on
           // them (live words, records without payloads).  The first stage of the NEXT piece is issued before the current one
           // is evaluated: at 16 wavefronts per CU nothing else hides the ~2 us those loads take, and a round of a few dozen
           // changed variables is a chain of ~40 pieces per wavefront.
