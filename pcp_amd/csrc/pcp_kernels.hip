@@ -2104,7 +2104,9 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
   // Every wave drains its own global stores (live words) before the barrier: a later atomicAnd on the same
   // word, or the team's release fence, must not be overtaken by them (cdna_hip_programming.md G16, R1).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // (the barrier also answers "did the sweep narrow anything in this tile?": if not, no variable is marked and the rounds —
+  // their compaction pass, barrier and the registers spilled around them — are skipped altogether)
+  const bool sweep_narrowed = __syncthreads_or(ctr.narrow != 0) != 0;
 
   // ---- phase 2 (team mode): merge this slice into the node's global arrays; the last arriver continues ---
   if constexpr (!PACKED) if (team > 1) {  // (packed tiles never run as a team: B >= 8)
@@ -2190,6 +2192,8 @@ __global__ void __launch_bounds__(1024) fixpoint_kernel(const LaunchArgs a_in) {
   unsigned long long dbg_t[5] = {0, 0, 0, 0, 0}, dbg_t0 = 0;  // and their time (100 MHz ticks)
   uint32_t dbg_class = 0;
   unsigned long long dbg_slow = 0;  // slowest round: ticks << 40 | pairs << 28 | items
+  if (team == 1 && !sweep_narrowed && misc[M_FAIL] == 0) tile_clean = true;
+  else
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_total = (round & 1u) ? M_TOTAL2 : M_TOTAL, m_items = (round & 1u) ? M_ITEMS2 : M_ITEMS, m_mask = (round & 1u) ? M_ROUNDMASK2 : M_ROUNDMASK;
     // (a) compact the changed pairs of the live nodes: (node, var), the variable's adjacency offset and its degree
