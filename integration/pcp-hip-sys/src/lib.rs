@@ -1,9 +1,9 @@
-//! Raw bindings of `include/pcp_hip.h` (ABI v3): one line per exported symbol, `#[repr(C)]` mirrors of its structs.
+//! Raw bindings of `include/pcp_hip.h` (ABI v4): one line per exported symbol, `#[repr(C)]` mirrors of its structs.
 //! Every entry point cites the libpcp item it replaces in the header; the safe layer is `pcp-gpu-cstore`.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PCP_ABI_VERSION: u32 = 3;
+pub const PCP_ABI_VERSION: u32 = 4;
 pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
 pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
 pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
@@ -83,6 +83,7 @@ pub struct pcp_plan {
     pub block: u32,
     pub lds_bytes: u32,
     pub list_cap: u32,
+    pub path: u32, // 0 generic sweep kernels, 1 assignment-driven all-XNeqY kernel
 }
 
 /// The device-resident DFS of `pcp_dfs_device`: a LIFO stack of implicit-active nodes and its 8 bytes of state.

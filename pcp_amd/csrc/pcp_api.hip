@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "pcp_internal.h"
+#include "pcp_neq.h"
 
 using namespace pcp;
 
@@ -40,6 +41,8 @@ struct pcp_ctx {
   uint32_t* d_adj = nullptr;
   uint2* d_adjp = nullptr; size_t cap_adjp = 0; bool have_adjp = false;
   int32_t* d_const = nullptr;
+  uint32_t* d_seed_always = nullptr; size_t cap_seed_always = 0; bool have_seed_always = false;  // variables with a Constant neighbour (pcp_neq.hip)
+  bool neq_model = false;            // every record is an XNeqY with at least one variable operand, payload adjacency, slots < 65536
   uint32_t* d_rec_unit = nullptr;    // grouped models only: unit of each record
   uint32_t* d_unit_first = nullptr;  // grouped models only: first record of each unit (+ sentinel)
   size_t cap_rec_unit = 0, cap_unit_first = 0;
@@ -84,6 +87,8 @@ struct pcp_ctx {
   int64_t opt_dom10 = 1;            // 1 = variable stores larger than LDS use 10-bit LDS cells when the declared hull allows
   int64_t opt_group_level = 1;      // 1 = implicit nodes test whole groups of 64 words first (needs word descriptors)
   int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
+  int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
+  int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
 };
 
 namespace {
@@ -253,6 +258,26 @@ int32_t finalize_model(pcp_ctx* c) {
     c->have_adjp = true;
   }
   if (!consts.empty()) HIP_TRY(c, hipMemcpy(c->d_const, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+  // assignment-driven path (pcp_neq.hip): all-XNeqY models.  A record over two constants has no variable whose list would
+  // run it: such (degenerate) models keep the generic kernels.  Variables with a Constant neighbour are walked in round 0
+  // whatever their domain — the constant is a singleton without a list of its own.
+  c->neq_model = c->uniform_kind == PCP_NEQ && c->have_adjp && n_slots < 65536u;
+  c->have_seed_always = false;
+  if (c->neq_model) {
+    std::vector<uint32_t> seed((n_slots + 31) / 32, 0u);
+    bool any = false;
+    for (size_t r = 0; r < P && c->neq_model; ++r) {
+      const uint32_t x = recs[r].xk & kSlotMask, y = recs[r].y;
+      if (x >= c->n_vars && y >= c->n_vars) c->neq_model = false;
+      else if (x >= c->n_vars) { seed[y >> 5] |= 1u << (y & 31); any = true; }
+      else if (y >= c->n_vars) { seed[x >> 5] |= 1u << (x & 31); any = true; }
+    }
+    if (c->neq_model && any) {
+      if ((rc = ensure(c, c->d_seed_always, c->cap_seed_always, seed.size()))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_seed_always, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
+      c->have_seed_always = true;
+    }
+  }
   if (!mul_off.empty()) {
     if ((rc = ensure(c, c->d_mul_off, c->cap_mul_off, mul_off.size()))) return rc;
     HIP_TRY(c, hipMemcpy(c->d_mul_off, mul_off.data(), mul_off.size() * 4, hipMemcpyHostToDevice));
@@ -406,7 +431,7 @@ int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
     live_in = bt->active_in; live = c->d_live;
   }
-  c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, implicit ? 1u : 0u, 1u, n_nodes, 1024u, (uint32_t)lds, cap};
+  c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, implicit ? 1u : 0u, 1u, n_nodes, 1024u, (uint32_t)lds, cap, 0u};
   HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_setfix(m, n_nodes, c->set_words, c->hull_lo, cap, bt->bits_in, bt->bits_out, bt->lb_out, bt->ub_out, live_in, live, bt->status,
                            c->d_stats, derive, stream));
@@ -414,6 +439,66 @@ int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (c->has_groups && bt->active_out && P)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
   c->ev_valid = true;
+  return PCP_OK;
+}
+
+// All-XNeqY models, implicit-active nodes: the assignment-driven kernel (pcp_neq.hip).  Returns 1 when the variable store does
+// not fit LDS even with one node per workgroup (the caller falls through to the generic kernels).
+int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batch* bt, hipStream_t stream) {
+  const uint32_t S = c->n_slots, V = c->n_vars, P = (uint32_t)c->props.size();
+  const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
+  const bool packed = hull_fits16 && c->consts_fit16 && c->opt_packed;
+  // nodes per workgroup: enough tiles for two resident workgroups per CU, as large as that allows (a round's list walk decodes an
+  // entry once for all the nodes of the tile in which the variable changed)
+  uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, n_nodes / (2u * (uint32_t)c->num_cu));
+  want = std::min<uint32_t>(want, 16);
+  uint32_t B = 0;
+  bool adj_cache = true;
+  for (uint32_t t : {16u, 8u, 4u, 2u, 1u}) {
+    if (t > want) continue;
+    size_t need = lds_bytes_neq(S, V, t, packed, true);
+    if (need && need <= c->lds_max) { B = t; adj_cache = true; break; }
+    need = lds_bytes_neq(S, V, t, packed, false);
+    if (need && need <= c->lds_max) { B = t; adj_cache = false; break; }
+  }
+  if (!B) return 1;
+  LaunchPlan plan;
+  plan.grid = (n_nodes + B - 1) / B;
+  plan.lds_bytes = lds_bytes_neq(S, V, B, packed, adj_cache);
+  // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
+  // staging overlaps the other's list walk
+  plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
+  NeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
+  a.m.n_recs = P; a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
+  a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
+  a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u; a.adj_cache = adj_cache ? 1u : 0u;
+  a.violation = c->d_retry + 1;
+  a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
+  a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
+  a.status = bt->status;
+  a.stats = c->d_stats;
+  c->dfs_team_words = 0;
+  c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
+  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  HIP_TRY(c, launch_neqfix(a, plan, stream));
+  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (bt->active_out && P) {
+    // the `active` rows on request: record r is live iff it is not entailed under the final domains
+    ModelDev m = a.m;
+    m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
+    int32_t rc;
+    const uint32_t words = (P + 63) / 64;
+    if (c->has_groups) {
+      if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+      HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, c->d_live, n_nodes, stream));
+      HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
+    } else {
+      HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, bt->active_out, n_nodes, stream));
+    }
+  }
+  c->ev_valid = !c->dfs_sp;
   return PCP_OK;
 }
 
@@ -468,7 +553,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -596,6 +681,12 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "implicit_active") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "implicit_active must be 0 or 1");
     c->opt_implicit = value;
+  } else if (k == "neq_path") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_path must be 0 or 1");
+    c->opt_neq_path = value;
+  } else if (k == "neq_block") {
+    if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, PCP_ERR_ARG, "neq_block must be 0, 256, 512 or 1024");
+    c->opt_neq_block = value;
   } else if (k == "list_cap") {
     if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
     c->opt_list_cap = value;
@@ -624,6 +715,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const uint32_t list_cap = (uint32_t)c->opt_list_cap;
 
   const bool implicit = bt->active_in == nullptr && c->opt_implicit;  // see below (a.live == nullptr)
+  if (implicit && c->neq_model && c->opt_neq_path && c->opt_force_path != 2 && !c->opt_global_dom) {
+    int32_t rcn = propagate_neq_device(c, n_nodes, bt, stream);
+    if (rcn != 1) return rcn;  // 1 = the store does not fit LDS: the generic kernels (HBM-resident domains) take it
+  }
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
   // tile sizes the kernel is instantiated for (pcp_kernels.hip launch_fixpoint)
   static const uint32_t kTiles[] = {16, 12, 8, 4, 2, 1};
@@ -783,7 +878,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipMemcpyAsync(bt->lb_out, bt->lb_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
-  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, dom10 ? 2u : a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used};
+  c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, dom10 ? 2u : a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used, 0u};
   if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation (d_retry[1])

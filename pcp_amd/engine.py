@@ -38,7 +38,7 @@ class PcpStats(C.Structure):
 
 class PcpPlan(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "compact", "implicit_active", "set_mode",
-                                          "grid", "block", "lds_bytes", "list_cap")]
+                                          "grid", "block", "lds_bytes", "list_cap", "path")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

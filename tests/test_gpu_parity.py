@@ -42,6 +42,13 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     got_i = ctx.propagate_implicit(lb, ub)
     assert ctx.last_plan()["implicit_active"] == 1
     assert_parity(ref_i[:4], got_i[:4], what + " [implicit]")
+    if ctx.last_plan()["path"] == 1:
+        # an all-XNeqY model took the assignment-driven kernel (pcp_neq.hip): the generic implicit kernels under the same options too
+        ctx.set_option("neq_path", 0)
+        got_g = ctx.propagate_implicit(lb, ub)
+        ctx.set_option("neq_path", 1)
+        assert ctx.last_plan()["path"] == 0
+        assert_parity(ref_i[:4], got_g[:4], what + " [implicit, generic kernels]")
     return ref, got
 
 

@@ -34,10 +34,13 @@ def _headline_opts(ctx):
         ctx.set_option(k, v)
 
 
-def _assert_headline_plan(ctx, implicit):
+def _assert_headline_plan(ctx, implicit, neq_path=False):
     pl = ctx.last_plan()
+    if neq_path:  # what bench.py's headline runs since round 3: the assignment-driven kernel, 16-node tiles of 16-bit cells
+        assert (pl["path"], pl["nodes_per_block"], pl["packed"], pl["team"], pl["implicit_active"]) == (1, 16, 1, 1, 1), pl
+        return
     assert (pl["nodes_per_block"], pl["packed"], pl["team"], pl["global_dom"], pl["compact"], pl["block"]) == (16, 1, 1, 0, 1, 1024), pl
-    assert pl["word_level"] >= 1 and pl["implicit_active"] == int(implicit), pl
+    assert pl["word_level"] >= 1 and pl["implicit_active"] == int(implicit) and pl["path"] == 0, pl
 
 
 def _launch_in_place(ctx, torch, L, U, A):
@@ -54,17 +57,22 @@ def _launch_in_place(ctx, torch, L, U, A):
     return t_lb.cpu().numpy(), t_ub.cpu().numpy(), act, t_st.cpu().numpy(), st
 
 
-@pytest.mark.parametrize("implicit", [False, True])
-def test_bench_frontier_nodes(env, implicit):
+@pytest.mark.parametrize("implicit,neq", [(False, False), (True, False), (True, True)])
+def test_bench_frontier_nodes(env, implicit, neq):
     """The bench batch itself (share 0, 16384 open nodes, one launch, in place); 64 of its nodes — spread over the
-    batch so that every region of the tree and 64 different tiles are sampled — against the oracle."""
+    batch so that every region of the tree and 64 different tiles are sampled — against the oracle.  neq: the assignment-driven
+    kernel (bench.py's headline), else the generic kernels on the same batch."""
     ctx, om, torch = env
     _headline_opts(ctx)
+    ctx.set_option("neq_path", int(neq))
     nodes = 16384
     L, U, A = W.nqueens_frontier(ctx, N, nodes, share=0, shares=8, implicit=implicit)
     _headline_opts(ctx)
+    if neq:
+        ctx.set_option("nodes_per_block", 0)  # bench.py's default policy
     glb, gub, gact, gst, st = _launch_in_place(ctx, torch, L, U, A)
-    _assert_headline_plan(ctx, implicit)
+    _assert_headline_plan(ctx, implicit, neq)
+    ctx.set_option("neq_path", 1)
     assert st["nodes"] == nodes and st["steps"] >= nodes * (om.n_units // 2)
     assert 0 < st["evaluated"] < st["steps"] and st["full_evals"] <= st["evaluated"]
     pick = np.arange(0, nodes, nodes // 64)[:64] + (np.arange(64) % 16)  # every tile position 0..15 appears
@@ -74,8 +82,8 @@ def test_bench_frontier_nodes(env, implicit):
 
 
 @pytest.mark.parametrize("dive", [500, 3000])
-@pytest.mark.parametrize("implicit", [False, True])
-def test_deep_dive_nodes(env, dive, implicit):
+@pytest.mark.parametrize("implicit,neq", [(False, False), (True, False), (True, True)])
+def test_deep_dive_nodes(env, dive, implicit, neq):
     """4096 open nodes from `dive` nodes down a left-first DFS (37 / 170 queens assigned: the deep-tile switch, long
     wake-up cascades), launched as one batch on the headline geometry; 64 of them against the oracle."""
     ctx, om, torch = env
@@ -86,8 +94,10 @@ def test_deep_dive_nodes(env, dive, implicit):
     A = None if act is None else act.cpu().numpy().view(np.uint64)
     assert L.shape[0] >= 1024
     _headline_opts(ctx)
+    ctx.set_option("neq_path", int(neq))
     glb, gub, gact, gst, st = _launch_in_place(ctx, torch, L, U, A)
-    _assert_headline_plan(ctx, implicit)
+    _assert_headline_plan(ctx, implicit, neq)
+    ctx.set_option("neq_path", 1)
     n = L.shape[0]
     pick = (np.arange(64) * (n // 64) + (np.arange(64) % 16)) % n
     ref = om.consistency(L[pick], U[pick], None if A is None else A[pick], check_dup=False)
