@@ -41,6 +41,7 @@ struct pcp_ctx {
   uint32_t* d_adj = nullptr;
   uint2* d_adjp = nullptr; size_t cap_adjp = 0; bool have_adjp = false;
   int32_t* d_const = nullptr;
+  uint32_t* d_adjp4 = nullptr; size_t cap_adjp4 = 0; bool have_adjp4 = false;  // 4-byte adjacency payloads (pcp_neq.hip)
   uint32_t* d_seed_always = nullptr; size_t cap_seed_always = 0; bool have_seed_always = false;  // variables with a Constant neighbour (pcp_neq.hip)
   bool neq_model = false;            // every record is an XNeqY with at least one variable operand, payload adjacency, slots < 65536
   uint32_t* d_rec_unit = nullptr;    // grouped models only: unit of each record
@@ -89,6 +90,7 @@ struct pcp_ctx {
   int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
   int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
+  int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
 };
 
 namespace {
@@ -272,6 +274,24 @@ int32_t finalize_model(pcp_ctx* c) {
       else if (x >= c->n_vars) { seed[y >> 5] |= 1u << (y & 31); any = true; }
       else if (y >= c->n_vars) { seed[x >> 5] |= 1u << (x & 31); any = true; }
     }
+    c->have_adjp4 = false;
+    if (c->neq_model && n_slots <= 32768u) {
+      bool fits = true;
+      for (size_t r = 0; r < P && fits; ++r) fits = recs[r].d >= -32767 && recs[r].d <= 32767;
+      if (fits) {
+        std::vector<uint32_t> p4(adj.size());
+        std::vector<uint32_t> fill(adj_off.begin(), adj_off.end() - 1);
+        for (size_t r = 0; r < P; ++r) {
+          const uint32_t x = recs[r].xk & kSlotMask, y = recs[r].y;
+          const int32_t d = recs[r].d;
+          if (x < c->n_vars) p4[fill[x]++] = y | ((uint32_t)(uint16_t)(int16_t)(-d) << 16);
+          if (y < c->n_vars) p4[fill[y]++] = x | (1u << 15) | ((uint32_t)(uint16_t)(int16_t)d << 16);
+        }
+        if ((rc = ensure(c, c->d_adjp4, c->cap_adjp4, p4.size()))) return rc;
+        HIP_TRY(c, hipMemcpy(c->d_adjp4, p4.data(), p4.size() * 4, hipMemcpyHostToDevice));
+        c->have_adjp4 = true;
+      }
+    }
     if (c->neq_model && any) {
       if ((rc = ensure(c, c->d_seed_always, c->cap_seed_always, seed.size()))) return rc;
       HIP_TRY(c, hipMemcpy(c->d_seed_always, seed.data(), seed.size() * 4, hipMemcpyHostToDevice));
@@ -453,18 +473,15 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, n_nodes / (2u * (uint32_t)c->num_cu));
   want = std::min<uint32_t>(want, 16);
   uint32_t B = 0;
-  bool adj_cache = true;
   for (uint32_t t : {16u, 8u, 4u, 2u, 1u}) {
     if (t > want) continue;
-    size_t need = lds_bytes_neq(S, V, t, packed, true);
-    if (need && need <= c->lds_max) { B = t; adj_cache = true; break; }
-    need = lds_bytes_neq(S, V, t, packed, false);
-    if (need && need <= c->lds_max) { B = t; adj_cache = false; break; }
+    const size_t need = lds_bytes_neq(S, V, t, packed);
+    if (need && need <= c->lds_max) { B = t; break; }
   }
   if (!B) return 1;
   LaunchPlan plan;
   plan.grid = (n_nodes + B - 1) / B;
-  plan.lds_bytes = lds_bytes_neq(S, V, B, packed, adj_cache);
+  plan.lds_bytes = lds_bytes_neq(S, V, B, packed);
   // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
   // staging overlaps the other's list walk
   plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
@@ -473,8 +490,10 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
   a.m.n_recs = P; a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
   a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
-  a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u; a.adj_cache = adj_cache ? 1u : 0u;
+  a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
+  a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u;
   a.violation = c->d_retry + 1;
+  a.debug = (uint32_t)c->opt_neq_debug;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
@@ -553,7 +572,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -684,8 +703,10 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_path must be 0 or 1");
     c->opt_neq_path = value;
+  } else if (k == "neq_debug") {
+    c->opt_neq_debug = value;
   } else if (k == "neq_block") {
-    if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(c, PCP_ERR_ARG, "neq_block must be 0, 256, 512 or 1024");
+    if (value < 0 || value > 1024 || (value & 63)) return fail(c, PCP_ERR_ARG, "neq_block must be 0 or a multiple of 64 up to 1024");
     c->opt_neq_block = value;
   } else if (k == "list_cap") {
     if (value < 64 || value > 16384) return fail(c, PCP_ERR_ARG, "list_cap must be in [64,16384]");
@@ -935,7 +956,11 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   // HIP graphs was built and measured: no faster (a step is bound by its kernels, ~55 us of fixpoint at this depth, not by the
   // host's enqueue rate) and not reliable across re-used buffers on this ROCm — dropped.
   const int64_t keep_path = c->opt_force_path;
-  if (!keep_path) c->opt_force_path = 2;  // one node per step: the team geometry unless the caller forced a path
+  HIP_TRY(c, hipSetDevice(c->device));
+  { const int32_t rcf = finalize_model(c); if (rcf) return rcf; }
+  // one node per step: the team geometry unless the caller forced a path — or the model takes the assignment-driven kernel, which
+  // has no sweep to share out (a node is one workgroup: its assigned variables' lists)
+  if (!keep_path && !(c->neq_model && c->opt_neq_path)) c->opt_force_path = 2;
   c->dfs_sp = st->sp; c->dfs_stop = st->stop; c->dfs_team_words = 0;
   const int32_t rc = dfs_enqueue_steps(c, st, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
   c->dfs_sp = nullptr; c->dfs_stop = nullptr; c->dfs_team_words = 0;

@@ -8,11 +8,12 @@ namespace pcp {
 // walks the adjacency lists of the variables that are singletons in the staged domains.
 struct NeqArgs {
   ModelDev m;                   // needs adj_off, adjp, const_val, n_vars, n_slots (< 65536), n_recs, max_deg
+  const uint32_t* adjp4;        // [adj_off[n_vars]] 4-byte payloads (other | is_y << 15 | t << 16) when slots < 32768 and |offsets| < 32768, else null
   const uint32_t* seed_always;  // [ceil(n_slots/32)] bit v = variable v has a Constant neighbour (walked in round 0 whatever its domain), or null
   uint32_t n_nodes;
   uint32_t nodes_per_block;     // B <= 16 nodes per workgroup, domains in LDS node-major
   uint32_t packed;              // 1 = 16-bit (-lb, ub) cells (declared hull within +-kPackedMax), 0 = int2 cells
-  uint32_t adj_cache;           // 1 = LDS copy of m.adj_off
+  uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL
   const uint32_t* sp_ptr;       // device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
   const uint32_t* stop_ptr;
@@ -23,7 +24,7 @@ struct NeqArgs {
   uint8_t* status;
   pcp_stats* stats;
 };
-size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, bool adj_cache);
+size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
 
 }  // namespace pcp

@@ -16,18 +16,24 @@
 // N-queens-1000 near the root: 1-2 assigned queens per node => ~3-6 thousand item tests instead of 1.5 million records.
 //
 // MI355X mapping
-//  * one workgroup = a tile of B nodes; their domains sit in LDS NODE-MAJOR (dom[b][slot]: the items of a list touch
-//    consecutive slots of ONE node: consecutive banks), as 16-bit packed (-lb, ub) cells under a declared hull within
-//    +-16383 (LdsDom16), else as int2 (-lb, ub) (LdsDom); B * S * 4 bytes: two tiles of 16 nodes of N-queens-1000 per CU;
+//  * one workgroup = a tile of B nodes; their domains sit in LDS NODE-MINOR (the B cells of a slot are adjacent: one
+//    ds_read_b128 fetches a slot's cells of FOUR nodes), as 16-bit packed (-lb, ub) cells under a declared hull within +-16383,
+//    else as int2 (-lb, ub); 16 bytes of padding after every 256 bytes of rows put the 16 lanes of a ds_read_b128 group, which
+//    read 16 consecutive slots, on 16 distinct 4-bank groups; B * S * 4 bytes * 1.06: two tiles of 16 nodes of N-queens-1000 per CU;
 //  * staging is the only HBM traffic: 16-byte row loads, four in flight per lane; a tile that narrows nothing writes
 //    nothing back when the call is in place (Store::consistency(&mut vstore) works in place);
 //  * a round is VARIABLE-major: the changed / assigned variables of all B nodes are compacted into one list of
 //    (variable, node mask) entries; a list is walked in pieces of 4 x 64 entries, payload loads (8 B per entry: other slot,
 //    offset) coalesced and issued one piece ahead; each piece decodes its entries ONCE and tests them against every node
-//    of the mask: per (entry, node) one ds_read_b32, two v_pk_add_u16 and a v_pk_min_u16 — the filter can act iff
+//    of the mask: per (entry, node) a quarter of a ds_read_b128, two v_pk_add_u16 and a v_pk_min_u16 — the filter can act iff
 //    lb(v) + t == ub(o) or ub(v) + t == lb(o) (fast_flag's condition, pcp_kernels.hip), i.e. iff a 16-bit half of
 //    cell(v) + swap(cell(o)) + (-t, t) is zero; the running unsigned minimum over the nodes is tested once per entry and
 //    only flagged entries run the full filter (eval_record: propagate() + is_subsumed() literally, LDS atomics);
+//  * chains: x != y + c removes a value only at a bound, so a bound that runs into values forbidden by assigned neighbours moves one
+//    value per round in the reference (one wake-up each).  A list walked for one or two nodes (the tail of a cascade) also marks,
+//    for every ASSIGNED neighbour, the value it forbids in a 64-bit window above lb(v) / below ub(v) (LDS atomics); after the
+//    round's barrier the bound jumps to the first unmarked value.  Every skipped value is one the filter would remove at the
+//    bound, so the (unique) fixpoint is unchanged — the argument of the generic kernel's solo cascade;
 //  * status (store.rs:250-256: True iff no subscription remains): at the fixpoint every record of an assigned variable has
 //    been run after that variable's last change, so only records of UNASSIGNED variables can be open: one wavefront per
 //    node walks them with early exit (an Unknown node shows an open record in its first 64 entries).
@@ -43,23 +49,43 @@ namespace pcp {
 namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
-       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WORDS = 16 };
+       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_WORDS = 18 };
+
+constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
+constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
+constexpr uint32_t kNoWin = 0xFFFFu;
+
+// A jump window: the values of variable v (node b) that assigned neighbours forbid, as bits above lb0 / below ub0.
+struct __attribute__((aligned(16))) Win {
+  uint32_t lo[2], hi[2];
+  int lb0, ub0;
+  uint32_t vb;  // v | b << 16
+  uint32_t pad;
+};
+static_assert(sizeof(Win) == 32, "Win must be 32 bytes");
 
 struct NeqCarve {
-  size_t dom, chg, list, adj, misc, total;
-  uint32_t SP;
+  size_t dom, chg, list, adj, win, misc, total;
+  uint32_t sh;    // log2 of the rows between two paddings
+  uint32_t wcap;  // jump windows that fit
 };
-__host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B, bool packed, bool adj_cache) {
+// cell index of (slot, node 0): rows of B cells, four cells of padding after every 2^sh rows (2^sh rows of packed cells = 256 bytes)
+__host__ __device__ inline uint32_t neq_row(uint32_t slot, uint32_t B, uint32_t sh) { return slot * B + ((slot >> sh) << 2); }
+__host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B, bool packed) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   NeqCarve c;
-  c.SP = (S + 3u) & ~3u;  // rows of whole 16-byte groups
+  c.sh = B >= 16 ? 2u : B >= 8 ? 3u : B >= 4 ? 4u : B >= 2 ? 5u : 6u;
   const size_t Wv = (S + 31) / 32;
   size_t o = 0;
-  c.dom = o; o = up(o + (size_t)B * c.SP * (packed ? 4 : 8));
+  c.dom = o; o = up(o + ((size_t)neq_row(S, B, c.sh) + 4) * (packed ? 4 : 8));
   c.chg = o; o = up(o + (size_t)B * Wv * 4);
-  c.list = o; o = up(o + (size_t)S * 4);
-  c.adj = o; o = up(o + (adj_cache ? ((size_t)V + 1) * 4 : 0));
+  c.list = o; o = up(o + (size_t)kListCap * 16);
+  c.adj = o; o = up(o + ((size_t)V + 1) * 4);
   c.misc = o; o = up(o + 32 * 4);
+  // the windows take what is left of HALF a CU's LDS (two workgroups per CU), of all of it when the tile needs more than half
+  const size_t budget = o <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+  c.wcap = (uint32_t)std::min<size_t>(kWinCap, o < budget ? (budget - o) / sizeof(Win) : 0);
+  c.win = o; o = up(o + (size_t)c.wcap * sizeof(Win));
   c.total = o;
   return c;
 }
@@ -88,15 +114,89 @@ __device__ __forceinline__ uint32_t pack_mt(int t) {
 template <bool PACKED> struct NeqCell { using type = int2; };
 template <> struct NeqCell<true> { using type = uint32_t; };
 
+// Adjacency payloads: 8 bytes per entry (ModelDev::adjp: other | kind << 28 | is_y << 31, d), or — when every slot fits 15 bits and
+// every offset 16 — 4 bytes: other | is_y << 15 | t << 16 with t = d for the record's y side, -d for its x side (half the stream).
+__device__ __forceinline__ uint32_t pay_other(const uint2 q) { return q.x & kSlotMask; }
+__device__ __forceinline__ bool pay_is_y(const uint2 q) { return (q.x >> 31) != 0; }
+__device__ __forceinline__ int pay_t(const uint2 q) { const int d = (int32_t)q.y; return (q.x >> 31) ? d : -d; }
+__device__ __forceinline__ uint32_t pay_other(const uint32_t q) { return q & 0x7fffu; }
+__device__ __forceinline__ bool pay_is_y(const uint32_t q) { return ((q >> 15) & 1u) != 0; }
+__device__ __forceinline__ int pay_t(const uint32_t q) { return (int32_t)q >> 16; }
+
 template <bool PACKED>
 __device__ __forceinline__ int2 cell_bounds(const typename NeqCell<PACKED>::type c) {  // (lb, ub)
   if constexpr (PACKED) return unpack16(c);
   else return make_int2(-c.x, c.y);
 }
 
+// variable::Store::update (variable/store.rs:151-166) on the tile's cells: LdsDom16 / LdsDom (pcp_device.hpp) with the padded
+// node-minor index.  `dom` points at node b's cell of slot 0.  A narrowing marks the variable changed and the node dirty.
+struct TileDom16 {
+  uint32_t* dom;
+  uint32_t B, sh;
+  uint32_t* chg;
+  uint32_t* misc;
+  uint32_t fbit;
+  Ctr* c;
+  __device__ __forceinline__ bool any_sums() const { return false; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return nullptr; }
+  __device__ __forceinline__ uint32_t* cell(uint32_t v) const { return dom + neq_row(v, B, sh); }
+  __device__ __forceinline__ int2 load(uint32_t v) const { return unpack16(*cell(v)); }
+  __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); atomicOr(&misc[N_DIRTY], fbit); }
+  __device__ __forceinline__ void set_fail() const { atomicOr(&misc[N_FAIL], fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    uint32_t* p = cell(v);
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nlb <= d.x) return;  // somebody else got there first
+      const uint32_t prev = atomicCAS(p, old, pack16(min(nlb, d.y + 1), d.y));
+      if (prev == old) { ++c->narrow; mark(v); if (nlb > d.y) set_fail(); return; }
+      old = prev;
+    }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    uint32_t* p = cell(v);
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nub >= d.y) return;
+      const uint32_t prev = atomicCAS(p, old, pack16(d.x, max(nub, d.x - 1)));
+      if (prev == old) { ++c->narrow; mark(v); if (nub < d.x) set_fail(); return; }
+      old = prev;
+    }
+  }
+};
+struct TileDom32 {
+  int2* dom;
+  uint32_t B, sh;
+  uint32_t* chg;
+  uint32_t* misc;
+  uint32_t fbit;
+  Ctr* c;
+  __device__ __forceinline__ bool any_sums() const { return false; }
+  __device__ __forceinline__ const int32_t* mul_offsets() const { return nullptr; }
+  __device__ __forceinline__ int2* cell(uint32_t v) const { return dom + neq_row(v, B, sh); }
+  __device__ __forceinline__ int2 load(uint32_t v) const { const int2 d = *cell(v); return make_int2(-d.x, d.y); }
+  __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); atomicOr(&misc[N_DIRTY], fbit); }
+  __device__ __forceinline__ void set_fail() const { atomicOr(&misc[N_FAIL], fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    int2* p = cell(v);
+    const int old = atomicMin(&p->x, -nlb);
+    if (old > -nlb) { ++c->narrow; mark(v); if (nlb > __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) set_fail(); }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    int2* p = cell(v);
+    const int old = atomicMin(&p->y, nub);
+    if (old > nub) { ++c->narrow; mark(v); if (-__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > nub) set_fail(); }
+  }
+};
+template <bool PACKED> struct TileDomOf { using type = TileDom32; };
+template <> struct TileDomOf<true> { using type = TileDom16; };
+
 }  // namespace
 
-template <bool PACKED>
+template <bool PACKED, bool PAY4>
 __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
@@ -107,25 +207,29 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
     a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
   }
   using Cell = typename NeqCell<PACKED>::type;
+  using TDom = typename TileDomOf<PACKED>::type;
+  using Pay = typename std::conditional<PAY4, uint32_t, uint2>::type;
+  const Pay* pay;
+  if constexpr (PAY4) pay = a.adjp4; else pay = a.m.adjp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = a.nodes_per_block;
-  const NeqCarve cv = neq_carve(S, V, B, PACKED, a.adj_cache != 0);
-  const uint32_t SP = cv.SP;
+  const NeqCarve cv = neq_carve(S, V, B, PACKED);
+  const uint32_t sh = cv.sh, wcap = cv.wcap;
+  auto rowof = [&](uint32_t slot) { return neq_row(slot, B, sh); };  // index of node 0's cell of a slot
   Cell* const dom = reinterpret_cast<Cell*>(smem + cv.dom);
   uint32_t* const chg = reinterpret_cast<uint32_t*>(smem + cv.chg);
-  uint32_t* const list = reinterpret_cast<uint32_t*>(smem + cv.list);
+  uint4* const list = reinterpret_cast<uint4*>(smem + cv.list);  // (v | M << 16, list offset, degree, windows w0 | w1 << 16)
+  Win* const win = reinterpret_cast<Win*>(smem + cv.win);
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
   const uint32_t node0 = blockIdx.x * B, nb = min(B, a.n_nodes - node0);
+  auto dom_of = [&](uint32_t b, Ctr* c) { return TDom{dom + b, B, sh, chg + (size_t)b * Wv, misc, 1u << b, c}; };
 
   // ---- phase 0: stage the domains (16-byte row loads), find the assigned variables ------------------------------------------
-  const uint32_t* adjo = a.m.adj_off;
-  if (a.adj_cache) {
-    uint32_t* adj_lds = reinterpret_cast<uint32_t*>(smem + cv.adj);
-    for (uint32_t v = tid; v <= V; v += nth) adj_lds[v] = a.m.adj_off[v];
-    adjo = adj_lds;
-  }
+  // the lists' offsets: an LDS copy (the build pass of a round then has no global load in its chain)
+  uint32_t* const adjo = reinterpret_cast<uint32_t*>(smem + cv.adj);
+  for (uint32_t v = tid; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   __syncthreads();
@@ -145,15 +249,9 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
         nib |= (on && l[i] == u[i]) ? 1u << i : 0u;
         if constexpr (PACKED) cl[i] = pack16(l[i], u[i]); else cl[i] = make_int2(-l[i], u[i]);
       }
-      Cell* row = dom + (size_t)b * SP + v0;
-      if (cnt == 4) {
-        if constexpr (PACKED) *reinterpret_cast<uint4*>(row) = make_uint4(cl[0], cl[1], cl[2], cl[3]);
-        else { reinterpret_cast<int4*>(row)[0] = make_int4(cl[0].x, cl[0].y, cl[1].x, cl[1].y); reinterpret_cast<int4*>(row)[1] = make_int4(cl[2].x, cl[2].y, cl[3].x, cl[3].y); }
-      } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if ((uint32_t)i < cnt) row[i] = cl[i];
-      }
+      for (int i = 0; i < 4; ++i)
+        if ((uint32_t)i < cnt) dom[rowof(v0 + i) + b] = cl[i];
       if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
       if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
       if (bad) badm |= 1u << b;
@@ -195,7 +293,7 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
     for (uint32_t t = tid; t < nb * (S - V); t += nth) {
       const uint32_t b = t / (S - V), s = V + (t - b * (S - V));
       const int c = a.m.const_val[s - V];
-      if constexpr (PACKED) dom[(size_t)b * SP + s] = pack16(c, c); else dom[(size_t)b * SP + s] = make_int2(-c, c);
+      if constexpr (PACKED) dom[rowof(s) + b] = pack16(c, c); else dom[rowof(s) + b] = make_int2(-c, c);
     }
     if (badm) atomicOr(&misc[N_FAIL], badm);
     if (oobm) atomicOr(&misc[N_OOB], oobm);
@@ -209,92 +307,208 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
   const uint32_t U4 = 4;
   const bool one_piece = a.m.max_deg <= 64u * U4;
   for (uint32_t round = 0;; ++round) {
-    const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0;
+    const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
-    // (a) one list for the tile: (variable, mask of the nodes in which it changed); the masks are consumed (zeroed) here,
-    // the narrowings of this round mark the same words again behind the barrier
+    // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
+    // here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
+    // marks and are listed by the next round.
     {
       uint32_t rm = 0;
       for (uint32_t w = tid; w < Wv; w += nth) {
         uint32_t uni = 0;
-        for (uint32_t b = 0; b < nb; ++b) uni |= ((inert >> b) & 1u) ? 0u : chg[b * Wv + w];
-        if (uni) {
-          uint32_t pos = atomicAdd(&misc[m_count], (uint32_t)__popc(uni));
-          uint32_t bits = uni;
-          while (bits) {
-            const uint32_t i = __builtin_ctz(bits);
-            bits &= bits - 1;
-            uint32_t M = 0;
-            for (uint32_t b = 0; b < nb; ++b) M |= (((chg[b * Wv + w] >> i) & 1u) & ~(inert >> b)) << b;
-            list[pos++] = ((w << 5) + i) | (M << 16);
-            rm |= M;
-          }
+        for (uint32_t b = 0; b < nb; ++b) {
+          if ((inert >> b) & 1u) chg[b * Wv + w] = 0;  // a failed or refused node is inert
+          else uni |= chg[b * Wv + w];
         }
-        for (uint32_t b = 0; b < nb; ++b) chg[b * Wv + w] = 0;
+        if (!uni) continue;
+        const uint32_t pos0 = atomicAdd(&misc[m_count], (uint32_t)__popc(uni));
+        uint32_t bits = uni, pos = pos0, taken = 0;
+        while (bits && pos < kListCap) {
+          const uint32_t i = __builtin_ctz(bits);
+          bits &= bits - 1;
+          taken |= 1u << i;
+          const uint32_t v = (w << 5) + i;
+          uint32_t M = 0;
+          for (uint32_t b = 0; b < nb; ++b) M |= ((chg[b * Wv + w] >> i) & 1u) << b;
+          const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
+          // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
+          uint32_t wsel = kNoWin | (kNoWin << 16);
+          if (round && wcap && __popc(M) <= 2) {
+            uint32_t k = 0;
+            for (uint32_t m = M; m; m &= m - 1, ++k) {
+              const uint32_t b = (uint32_t)__builtin_ctz(m);
+              const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
+              if (d.x >= d.y) continue;
+              const uint32_t wi = atomicAdd(&misc[m_win], 1u);
+              if (wi >= wcap) continue;
+              Win nw;
+              nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
+              win[wi] = nw;
+              wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
+            }
+          }
+          list[pos++] = make_uint4(v | (M << 16), o0, dg, wsel);
+          rm |= M;
+        }
+        for (uint32_t b = 0; b < nb; ++b) chg[b * Wv + w] &= ~taken;
       }
       if (rm) atomicOr(&misc[m_rmask], rm);
     }
     __syncthreads();
-    const uint32_t total = misc[m_count];
-    if (total == 0) break;
+    const uint32_t total = min(misc[m_count], kListCap);
+    const uint32_t nwin = min(misc[m_win], wcap);
+    if (total == 0 || (a.debug & 1u) || ((a.debug & 4u) && round == 1)) break;
     if (tid == 0) {  // the other slots: last read before this round's barrier
-      if (round) { misc[N_WAVES] += __popc(misc[m_rmask]); misc[N_DIRTY] |= misc[m_rmask]; }
-      misc[(round & 1u) ? N_COUNT0 : N_COUNT1] = 0; misc[(round & 1u) ? N_RMASK0 : N_RMASK1] = 0;
+      if (round) misc[N_WAVES] += __popc(misc[m_rmask]);
+      misc[(round & 1u) ? N_COUNT0 : N_COUNT1] = 0; misc[(round & 1u) ? N_RMASK0 : N_RMASK1] = 0; misc[(round & 1u) ? N_WIN0 : N_WIN1] = 0;
     }
     // (b) walk the lists.  Piece p (4 x 64 entries) of list e goes to wavefront (p + e) mod nwv: one long list is spread over
-    // the workgroup, many lists are balanced to within a piece.
+    // the workgroup, many lists are balanced to within a piece.  The payload loads of the next TWO pieces are in flight while a
+    // piece is tested: three register stages in rotation, the loop unrolled three times so that no stage is ever copied (a copy
+    // would wait for the load it copies).
     {
-      struct Piece { uint32_t v, M, aoff, deg, k0; };
-      auto piece_at = [&](uint32_t e_, uint32_t k_) {
-        const uint32_t ent = __builtin_amdgcn_readfirstlane(list[e_]), v = ent & 0xffffu;  // wave-uniform: keeps the loop control scalar
-        const uint32_t o0 = __builtin_amdgcn_readfirstlane(adjo[v]), o1 = __builtin_amdgcn_readfirstlane(adjo[v + 1]);
-        return Piece{v, ent >> 16, o0, o1 - o0, k_};
+      struct Piece { uint32_t v, M, aoff, deg, k0, wsel; };
+      const uint32_t k_step = nwv * 64 * U4;
+      const uint32_t e_step = one_piece ? nwv : 1u;
+      auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U4; };
+      uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
+      // the next piece of this wavefront (deg == 0: none left; its loads then read entry 0 of list 0 and are ignored)
+      auto next_piece = [&]() -> Piece {
+        while (e < total) {
+          const uint4 ent = list[e];
+          const uint32_t dg = __builtin_amdgcn_readfirstlane(ent.z);  // wave-uniform: keeps the loop control scalar
+          if (k0 < dg) {
+            const uint32_t vm = __builtin_amdgcn_readfirstlane(ent.x);
+            const Piece pc{vm & 0xffffu, vm >> 16, (uint32_t)__builtin_amdgcn_readfirstlane(ent.y), dg, k0, (uint32_t)__builtin_amdgcn_readfirstlane(ent.w)};
+            k0 += k_step;
+            return pc;
+          }
+          e += e_step; k0 = k_first(e);
+        }
+        return Piece{0u, 0u, 0u, 0u, 0u, 0u};
       };
-      auto load = [&](const Piece& pc, uint2 (&q)[4]) {
+      auto load = [&](const Piece& pc, Pay (&q)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint32_t idx = pc.k0 + u * 64 + lane;
-          q[u] = a.m.adjp[pc.aoff + (idx < pc.deg ? idx : 0u)];
+          q[u] = pay[pc.aoff + (idx < pc.deg ? idx : 0u)];
         }
       };
       uint32_t my_ev = 0;
-      auto process = [&](const Piece& pc, const uint2 (&q)[4]) {
+      const bool timing = (a.debug & 8u) != 0;  // profiling: s_memtime ticks of the walk / of the node loops, pieces (counters overloaded)
+      uint64_t t_walk0 = 0, t_inner = 0, n_pieces = 0;
+      if (timing) t_walk0 = __builtin_amdgcn_s_memtime();
+      auto process = [&](const Piece& pc, const Pay (&q)[4]) {
         uint32_t other[4];
         int t[4];
         bool valid[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           valid[u] = pc.k0 + u * 64 + lane < pc.deg;
-          other[u] = q[u].x & kSlotMask;
-          const int d = (int32_t)q[u].y;
-          t[u] = (q[u].x >> 31) ? d : -d;  // v is the record's y: x != v + d  <=>  o != v + d;  v is x: o != v - d
+          other[u] = pay_other(q[u]);
+          t[u] = pay_t(q[u]);  // v is the record's y: x != v + d  <=>  o != v + d (t = d);  v is x: o != v - d (t = -d)
         }
         bool hit[4] = {false, false, false, false};
+        uint64_t ti0 = 0;
+        if (timing) { ti0 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(other[0] ^ other[3] ^ (uint32_t)t[1]) & 0u); ++n_pieces; }
+        const uint32_t rv = rowof(pc.v);
+        uint32_t ro[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ro[u] = rowof(other[u]);
         if constexpr (PACKED) {
           uint32_t K[4], acc[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) { K[u] = pack_mt(t[u]); acc[u] = 0xffffffffu; }
-          for (uint32_t m = pc.M; m; m &= m - 1) {
-            const Cell* row = dom + (size_t)__builtin_ctz(m) * SP;
-            const uint32_t cvv = row[pc.v];
+          if (B >= 4 && __popc(pc.M) > 2) {
+            // a quad of nodes per ds_read_b128, two quads per step (ten reads in flight); nodes of a quad outside the mask are
+            // tested along: they can only raise a flag that the full-filter pass below, which walks the mask, ignores
+            uint32_t qm = 0;
+            for (uint32_t g = 0; g < (B >> 2); ++g) qm |= ((pc.M >> (4 * g)) & 0xFu) ? 1u << g : 0u;
+            if (__popc(qm) & 1) {  // an odd quad out, by itself
+              const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+              qm &= qm - 1;
+              const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0);
+              uint4 o0[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = pk_min_u16(acc[u], neq_terms16(cvv, row[other[u]], K[u]));
+              for (int u = 0; u < 4; ++u) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
+                uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
+                acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
+              }
+            }
+            while (qm) {
+              const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+              qm &= qm - 1;
+              const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
+              qm &= qm - 1;
+              const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0), c1 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g1);
+              uint4 o0[4], o1[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
+                uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
+                uint32_t m2 = pk_min_u16(neq_terms16(c1.x, o1[u].x, K[u]), neq_terms16(c1.y, o1[u].y, K[u]));
+                uint32_t m3 = pk_min_u16(neq_terms16(c1.z, o1[u].z, K[u]), neq_terms16(c1.w, o1[u].w, K[u]));
+                acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(m0, m1), pk_min_u16(m2, m3)));
+              }
+            }
+          } else {
+            uint32_t k = 0;
+            for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
+              const uint32_t b = (uint32_t)__builtin_ctz(m);
+              const uint32_t c0 = dom[rv + b];
+              uint32_t oc[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) { oc[u] = dom[ro[u] + b]; acc[u] = pk_min_u16(acc[u], neq_terms16(c0, oc[u], K[u])); }
+              const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
+              if (wi != kNoWin) {
+                // the values assigned neighbours forbid for v, near its bounds (the bounds the window was opened with)
+                Win* wp = win + wi;
+                const int lb0 = wp->lb0, ub0 = wp->ub0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const int2 O = unpack16(oc[u]);
+                  if (valid[u] && O.x == O.y) {
+                    const int f = O.x - t[u];  // lb(v) + t == O  <=>  lb(v) == f
+                    const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
+                    if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
+                    if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
+                  }
+                }
+              }
+            }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) hit[u] = valid[u] && zero_half(acc[u]);
         } else {
-          for (uint32_t m = pc.M; m; m &= m - 1) {
-            const Cell* row = dom + (size_t)__builtin_ctz(m) * SP;
-            const int2 cvv = row[pc.v];
+          uint32_t k = 0;
+          for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
+            const uint32_t b = (uint32_t)__builtin_ctz(m);
+            const int2 c0 = dom[rv + b];
+            const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
+            Win* wp = win + (wi != kNoWin ? wi : 0u);
+            int lb0 = 0, ub0 = 0;
+            if (wi != kNoWin) { lb0 = wp->lb0; ub0 = wp->ub0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const int2 co = row[other[u]];
-              hit[u] |= (cvv.x + co.y == t[u]) | (cvv.y + co.x == -t[u]);  // lb(v) + t == ub(o)  |  ub(v) + t == lb(o)
+            for (int u = 0; u < 4; ++u) {  // lb(v) + t == ub(o)  |  ub(v) + t == lb(o)
+              const int2 o = dom[ro[u] + b];
+              hit[u] |= (c0.x + o.y == t[u]) | (c0.y + o.x == -t[u]);
+              if (wi != kNoWin && valid[u] && -o.x == o.y) {
+                const int f = o.y - t[u];
+                const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
+                if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
+                if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
+              }
             }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) hit[u] = hit[u] && valid[u];
         }
+        if (timing) t_inner += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)hit[0] | (uint32_t)hit[3]) & 0u) - ti0;
         const uint32_t nm = (uint32_t)__popc(pc.M);
 #pragma unroll
         for (int u = 0; u < 4; ++u) my_ev += valid[u] ? nm : 0u;
@@ -303,55 +517,74 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             if (!hit[u]) continue;
-            const bool is_y = (q[u].x >> 31) != 0;
+            const bool is_y = pay_is_y(q[u]);
             Rec rec;
             rec.xk = (is_y ? other[u] : pc.v) | ((uint32_t)PCP_NEQ << 28);
             rec.y = is_y ? pc.v : other[u];
             rec.z = 0;
-            rec.d = (int32_t)q[u].y;
+            rec.d = is_y ? t[u] : -t[u];
             for (uint32_t m = pc.M; m; m &= m - 1) {
               const uint32_t b = (uint32_t)__builtin_ctz(m);
-              const Cell* row = dom + (size_t)b * SP;
-              const int2 Vd = cell_bounds<PACKED>(row[pc.v]), O = cell_bounds<PACKED>(row[other[u]]);
+              const int2 Vd = cell_bounds<PACKED>(dom[rv + b]), O = cell_bounds<PACKED>(dom[ro[u] + b]);
               if (Vd.x + t[u] != O.y && Vd.y + t[u] != O.x) continue;
               ++ctr.full;
-              if constexpr (PACKED) eval_record(rec, LdsDom16{dom + (size_t)b * SP, 1u, chg + (size_t)b * Wv, &misc[N_FAIL], 1u << b, &ctr});
-              else eval_record(rec, LdsDom{dom + (size_t)b * SP, 1u, chg + (size_t)b * Wv, &misc[N_FAIL], 1u << b, &ctr, SumTab{nullptr, nullptr, 0u, 0u, nullptr}});
+              eval_record(rec, dom_of(b, &ctr));
             }
           }
         }
       };
-      const uint32_t k_step = nwv * 64 * U4;
-      const uint32_t e_step = one_piece ? nwv : 1u;
-      auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U4; };
-      auto deg_of = [&](uint32_t e_) { const uint32_t v = __builtin_amdgcn_readfirstlane(list[e_]) & 0xffffu; return __builtin_amdgcn_readfirstlane(adjo[v + 1] - adjo[v]); };
-      uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
-      auto settle = [&]() { while (e < total && k0 >= deg_of(e)) { e += e_step; k0 = k_first(e); } };
-      settle();
-      bool have = e < total;
-      Piece pa{0, 0, 0, 0, 0};
-      uint2 qA[4];
-      if (have) { pa = piece_at(e, k0); load(pa, qA); }
-      while (have) {
-        k0 += k_step;
-        if (k0 >= pa.deg) { e += e_step; k0 = k_first(e); }
-        settle();
-        const bool have_n = e < total;
-        Piece pb = pa;
-        uint2 qB[4];
-        if (have_n) { pb = piece_at(e, k0); load(pb, qB); }  // the next piece's stream is in flight across this piece's tests
+      Piece pa = next_piece(), pb, pc3;
+      Pay qA[4], qB[4], qC[4];
+      load(pa, qA);
+      pb = next_piece(); load(pb, qB);
+      while (pa.deg) {
+        pc3 = next_piece(); load(pc3, qC);
         process(pa, qA);
-        if (have_n) {
-          pa = pb;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) qA[u] = qB[u];
-        }
-        have = have_n;
+        if (!pb.deg) break;
+        pa = next_piece(); load(pa, qA);
+        process(pb, qB);
+        if (!pc3.deg) break;
+        pb = next_piece(); load(pb, qB);
+        process(pc3, qC);
+      }
+      if (timing && lane == 0 && round == 0) {
+        atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_walk0));
+        atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)t_inner);
+        atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)n_pieces);
       }
       if (round == 0) ev0 += my_ev;
       ctr.ev += my_ev;
     }
     __syncthreads();
+    // (c) the jumps: each window's bound moves to the first value no assigned neighbour forbids
+    if (nwin) {
+      for (uint32_t wi = tid; wi < nwin; wi += nth) {
+        const Win w = win[wi];
+        const uint32_t v = w.vb & 0xffffu, b = w.vb >> 16;
+        if ((misc[N_FAIL] >> b) & 1u) continue;
+        const TDom dm = dom_of(b, &ctr);
+        const int2 d = dm.load(v);
+        if (d.x > d.y) continue;
+        const unsigned long long Lm = ((unsigned long long)w.lo[1] << 32) | w.lo[0], Hm = ((unsigned long long)w.hi[1] << 32) | w.hi[0];
+        {
+          const uint32_t off = (uint32_t)(d.x - w.lb0);  // the bound may have moved during the walk
+          if (off < 64u) {
+            const unsigned long long m = Lm | ((1ull << off) - 1ull);
+            const int nl = w.lb0 + (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
+            if (nl > d.x) dm.raise_lb(v, nl);
+          }
+        }
+        {
+          const uint32_t off = (uint32_t)(w.ub0 - d.y);
+          if (off < 64u) {
+            const unsigned long long m = Hm | ((1ull << off) - 1ull);
+            const int nu = w.ub0 - (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
+            if (nu < d.y) dm.lower_ub(v, nu);
+          }
+        }
+      }
+      __syncthreads();
+    }
   }
 
   // ---- status: is any record NOT entailed under the final domains? (store.rs:250-256) ------------------------
@@ -361,25 +594,25 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
   {
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
     for (uint32_t b = wv; b < nb; b += nwv) {
-      if ((inert >> b) & 1u) continue;
-      const Cell* row = dom + (size_t)b * SP;
+      if (((inert >> b) & 1u) || (a.debug & 2u)) continue;
+      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
       bool open = false;
       for (uint32_t base = 0; base < V && !open; base += 64) {
         const uint32_t vv = base + lane;
         bool wide = false;
-        if (vv < V) { const int2 d = cell_bounds<PACKED>(row[vv]); wide = d.x < d.y; }
+        if (vv < V) { const int2 d = cellb(vv); wide = d.x < d.y; }
         uint64_t bal = __ballot(wide);
         while (bal && !open) {
           const uint32_t u = base + (uint32_t)__builtin_ctzll(bal);
           bal &= bal - 1;
-          const int2 Ud = cell_bounds<PACKED>(row[u]);
+          const int2 Ud = cellb(u);
           const uint32_t o0 = adjo[u], deg = adjo[u + 1] - o0;
           for (uint32_t k = 0; k < deg && !open; k += 64) {
             bool op = false;
             if (k + lane < deg) {
-              const uint2 q = a.m.adjp[o0 + k + lane];
-              const int d = (int32_t)q.y, t = (q.x >> 31) ? d : -d;
-              const int2 O = cell_bounds<PACKED>(row[q.x & kSlotMask]);
+              const Pay q = pay[o0 + k + lane];
+              const int t = pay_t(q);
+              const int2 O = cellb(pay_other(q));
               op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));  // not disjoint
             }
             open = __ballot(op) != 0;
@@ -400,7 +633,7 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
     for (uint32_t b = 0; b < nb; ++b) {
       if ((refused >> b) & 1u) continue;                   // a refused node's outputs are left alone
       if (in_place && !((dirty >> b) & 1u)) continue;      // the rows in HBM already hold the result
-      const Cell* row = dom + (size_t)b * SP;
+      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
       int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
       int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
       bool bad = false;
@@ -408,12 +641,12 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
         for (uint32_t q = tid; q < (V >> 2); q += nth) {
           int l[4], u[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { const int2 d = cell_bounds<PACKED>(row[4 * q + i]); l[i] = d.x; u[i] = d.y; bad |= d.x > d.y; }
+          for (int i = 0; i < 4; ++i) { const int2 d = cellb(4 * q + i); l[i] = d.x; u[i] = d.y; bad |= d.x > d.y; }
           reinterpret_cast<int4*>(lbp)[q] = make_int4(l[0], l[1], l[2], l[3]);
           reinterpret_cast<int4*>(ubp)[q] = make_int4(u[0], u[1], u[2], u[3]);
         }
       } else {
-        for (uint32_t v = tid; v < V; v += nth) { const int2 d = cell_bounds<PACKED>(row[v]); bad |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
+        for (uint32_t v = tid; v < V; v += nth) { const int2 d = cellb(v); bad |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
       }
       if (bad) badm |= 1u << b;
     }
@@ -441,34 +674,32 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
     const unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[N_EV]), sfu = *reinterpret_cast<unsigned long long*>(&misc[N_FULL]);
     if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
     if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
-    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
+    if (!(a.debug & 8u)) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
     atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[N_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)));
-    if (nf) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    if (nf && !(a.debug & 8u)) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
   }
 }
 
-size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, bool adj_cache) {
-  const NeqCarve c = neq_carve(n_slots, n_vars, nodes_per_block, packed, adj_cache);
+size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed) {
+  const NeqCarve c = neq_carve(n_slots, n_vars, nodes_per_block, packed);
   return c.total <= 160 * 1024 ? c.total : 0;
+}
+
+template <bool PACKED, bool PAY4>
+static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (p.lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.nodes_per_block == 0 || a.nodes_per_block > 16 || a.m.n_slots >= 65536u || !a.m.adjp) return hipErrorInvalidValue;
-  if (a.packed) {
-    if (p.lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(neqfix_kernel<true>, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
-  } else {
-    if (p.lds_bytes > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(neqfix_kernel<false>, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
-  }
-  return hipGetLastError();
+  if (a.adjp4) return a.packed ? launch_neq_k<true, true>(a, p, stream) : launch_neq_k<false, true>(a, p, stream);
+  return a.packed ? launch_neq_k<true, false>(a, p, stream) : launch_neq_k<false, false>(a, p, stream);
 }
 
 }  // namespace pcp
