@@ -98,6 +98,11 @@ class Leg:
         self.bytes = compulsory_bytes
         self.status = torch.zeros(self.n, dtype=torch.uint8, device=lb.device)
 
+    def out_bytes(self, per):
+        """Compulsory HBM WRITE bytes per launch: the bounds rows (8 B per variable) of the nodes that changed, once — in place an
+        unchanged node is not written.  The counters do not say how many nodes changed: at most min(nodes, narrowings)."""
+        return 8 * self.lb.shape[1] * min(self.n, per["narrowings"])
+
     def run(self, launches=5, warmup=1):
         ctx, torch = self.ctx, self.torch
         stream = torch.cuda.current_stream().cuda_stream
@@ -123,8 +128,8 @@ class Leg:
             "narrowings_per_launch": per["narrowings"], "waves_per_node": per["waves"] / self.n,
             "steps_per_s": steps / (med * 1e-3), "evaluated_per_s": per["evaluated"] / (med * 1e-3),
             "nodes_per_s": self.n / (med * 1e-3),
-            "compulsory_bytes_per_launch": self.bytes + 8 * per["narrowings"],
-            "hbm_frac": (self.bytes + 8 * per["narrowings"]) / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "compulsory_bytes_per_launch": self.bytes + self.out_bytes(per),
+            "hbm_frac": (self.bytes + self.out_bytes(per)) / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "status_false_true_unknown": np.bincount(self.status.cpu().numpy(), minlength=3)[:3].tolist(),
             "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "word_level", "global_dom", "implicit_active", "grid")},
         }

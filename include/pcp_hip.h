@@ -257,7 +257,8 @@ typedef struct {
   uint32_t grid, block, lds_bytes, list_cap;
   uint32_t path;            /* 0 = the generic kernels (every propagator tested in the initial sweep, in bulk where range tests allow);
                                1 = the assignment-driven kernel of all-XNeqY models over implicit nodes: the sweep is the adjacency
-                               lists of the assigned variables (an XNeqY between two unassigned variables is a no-op, x_neq_y.rs:82-93) */
+                               lists of the assigned variables (an XNeqY between two unassigned variables is a no-op, x_neq_y.rs:82-93);
+                               2 = the 10-bit-cell kernel of binary models whose store does not fit LDS as pairs (implicit nodes, declared hull) */
 } pcp_plan;
 int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
 
@@ -268,7 +269,7 @@ int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
  *   "word_level" 0 = never use the word-group sweep, "solo_cascade" 0 = a wake-up round with one changed variable is an ordinary round
  *   (1, the default: its records are re-run in place and a bound jumps over the values assigned neighbours forbid), "branch_reverse" 1 = pcp_branch_device writes child k of the batch
  *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
- * "neq_path" 0 = all-XNeqY models use the generic kernels too (1, the default: the assignment-driven kernel when the nodes are implicit), "neq_block" threads
+ * "big_path" 0 = never use the 10-bit-cell kernel (path 2), "neq_path" 0 = all-XNeqY models use the generic kernels too (1, the default: the assignment-driven kernel when the nodes are implicit), "neq_block" threads
  *   per workgroup of that kernel (0 = auto).
  * Unknown key -> PCP_ERR_ARG. */
 int32_t pcp_set_option(pcp_ctx* ctx, const char* key, int64_t value);

@@ -41,6 +41,7 @@ struct pcp_ctx {
   uint32_t* d_adj = nullptr;
   uint2* d_adjp = nullptr; size_t cap_adjp = 0; bool have_adjp = false;
   int32_t* d_const = nullptr;
+  Rec* d_recs_by_kind = nullptr; size_t cap_recs_by_kind = 0; bool recs_by_kind_valid = false;  // pcp_big.hip: the record table sorted by kind
   uint32_t* d_adjp4 = nullptr; size_t cap_adjp4 = 0; bool have_adjp4 = false;  // 4-byte adjacency payloads (pcp_neq.hip)
   uint32_t* d_seed_always = nullptr; size_t cap_seed_always = 0; bool have_seed_always = false;  // variables with a Constant neighbour (pcp_neq.hip)
   bool neq_model = false;            // every record is an XNeqY with at least one variable operand, payload adjacency, slots < 65536
@@ -91,6 +92,7 @@ struct pcp_ctx {
   int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
+  int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
 
 namespace {
@@ -412,6 +414,7 @@ int32_t finalize_model(pcp_ctx* c) {
   }
   c->n_slots = n_slots;
   c->has_ternary = tern;
+  c->recs_by_kind_valid = false;
   c->dirty = false;
   return PCP_OK;
 }
@@ -572,7 +575,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -703,6 +706,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_path must be 0 or 1");
     c->opt_neq_path = value;
+  } else if (k == "big_path") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
+    c->opt_big_path = value;
   } else if (k == "neq_debug") {
     c->opt_neq_debug = value;
   } else if (k == "neq_block") {
@@ -739,6 +745,47 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (implicit && c->neq_model && c->opt_neq_path && c->opt_force_path != 2 && !c->opt_global_dom) {
     int32_t rcn = propagate_neq_device(c, n_nodes, bt, stream);
     if (rcn != 1) return rcn;  // 1 = the store does not fit LDS: the generic kernels (HBM-resident domains) take it
+  }
+  // a store too large for (lb, ub) pairs in LDS, binary records only, a declared hull of at most 1024 values, implicit nodes, enough
+  // nodes to give every CU one: the 10-bit-cell kernel (pcp_big.hip)
+  if (implicit && c->opt_big_path && c->opt_dom10 && c->opt_global_dom != 1 && c->opt_force_path != 2 && c->have_adjp && !c->n_sum_slots && c->hull_set &&
+      (int64_t)c->hull_hi - c->hull_lo <= 1023 && (c->opt_global_dom == 2 || !lds_bytes_for(S, 1, 256, block)) && lds_bytes_big(c->n_vars, S) &&
+      lds_bytes_big(c->n_vars, S) <= c->lds_max && (c->opt_global_dom == 2 || n_nodes * 2 > (uint32_t)c->num_cu || words < 64)) {
+    if (!c->recs_by_kind_valid) {  // built on first use: only stores that take this path need it
+      std::vector<Rec> all((size_t)P ? ((size_t)P + 255) / 256 * 256 + kStreamPadRecs : 0);
+      HIP_TRY(c, hipMemcpy(all.data(), c->d_recs, all.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+      std::stable_sort(all.begin(), all.begin() + P, [](const Rec& p, const Rec& q) { return (p.xk >> 28) < (q.xk >> 28); });
+      for (size_t r = P; r < all.size(); ++r) all[r] = all[P - 1];
+      if ((rc = ensure(c, c->d_recs_by_kind, c->cap_recs_by_kind, all.size()))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_recs_by_kind, all.data(), all.size() * sizeof(Rec), hipMemcpyHostToDevice));
+      c->recs_by_kind_valid = true;
+    }
+    BigArgs a;
+    memset(&a, 0, sizeof(a));
+    a.recs_by_kind = c->d_recs_by_kind;
+    a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
+    a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
+    a.n_nodes = n_nodes; a.lo10 = c->hull_lo; a.violation = c->d_retry + 1;
+    a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out; a.status = bt->status; a.stats = c->d_stats;
+    LaunchPlan plan;
+    plan.grid = n_nodes; plan.block = 1024; plan.lds_bytes = lds_bytes_big(c->n_vars, S);
+    c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 2u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 2u};
+    HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+    HIP_TRY(c, launch_bigfix(a, plan, stream));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+    if (bt->active_out && P) {  // the `active` rows on request: record r is live iff it is not entailed under the final domains
+      ModelDev m = a.m;
+      m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
+      if (c->has_groups) {
+        if ((rc = ensure(c, c->d_live, c->cap_live, (size_t)n_nodes * std::max<uint32_t>(words, 1)))) return rc;
+        HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, c->d_live, n_nodes, stream));
+        HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
+      } else {
+        HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, bt->active_out, n_nodes, stream));
+      }
+    }
+    c->ev_valid = true;
+    return PCP_OK;
   }
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
   // tile sizes the kernel is instantiated for (pcp_kernels.hip launch_fixpoint)

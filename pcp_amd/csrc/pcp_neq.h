@@ -1,4 +1,5 @@
-// pcp_neq.h — launch interface of the assignment-driven all-XNeqY kernel (pcp_neq.hip), shared with the C-ABI host code.
+// pcp_neq.h — launch interfaces of the specialised fixpoint kernels (pcp_neq.hip: all-XNeqY models, assignment-driven;
+// pcp_big.hip: binary models on 10-bit LDS cells), shared with the C-ABI host code.
 #pragma once
 #include "pcp_internal.h"
 
@@ -26,5 +27,23 @@ struct NeqArgs {
 };
 size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
+
+// Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
+// per workgroup (pcp_big.hip).
+struct BigArgs {
+  ModelDev m;          // needs recs (padded), adj_off, adjp, const_val, n_recs, n_vars, n_slots
+  const Rec* recs_by_kind;  // [padded like m.recs] the records sorted by kind (stable)
+  uint32_t n_nodes;
+  int32_t lo10;        // the hull's lower bound
+  uint32_t* violation; // sticky device word: a node was refused with PCP_STATUS_HULL
+  const int32_t* lb_in;
+  const int32_t* ub_in;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  uint8_t* status;
+  pcp_stats* stats;
+};
+size_t lds_bytes_big(uint32_t n_vars, uint32_t n_slots);
+hipError_t launch_bigfix(const BigArgs& a, const LaunchPlan& p, hipStream_t stream);
 
 }  // namespace pcp
