@@ -7,12 +7,14 @@ to its propagation fixpoint (one kernel launch, inputs and outputs resident in H
 search tree on N-queens n=1000 (FirstSmallestVar / MiddleVal / BinarySplit), `--nodes` open nodes per GPU: per-GPU work
 is fixed as N grows (weak scaling); nodes are independent, so there is no collective in the data path.
 
-What `value` is: REFERENCE-EQUIVALENT filter steps per second — every (propagator, node) pair the reference's scheduler
-would pop to reach the same fixpoints (each propagator of each node once in the initial sweep, store.rs:144-149, plus
-every wake-up), divided by the max-over-ranks wall time of the K timed steps.  The engine proves most of those pairs
-no-ops in bulk; `config.steps_evaluated_per_s` is the rate of pairs it actually tested one by one and
-`config.full_filter_evals_per_s` the rate of full propagate()+is_subsumed() runs.  `roofline` is PHYSICAL: the bytes the
-ABI contract forces across HBM per launch (every node's rows in once, out once) / kernel time / 8 TB/s — always <= 1.
+What `value` is: filter steps EXECUTED per second — the (propagator, node) pairs the engine tested one by one on the node's own
+domains (pcp_stats.evaluated), all ranks, divided by the max-over-ranks wall time of the K timed steps.  An all-XNeqY model
+needs few of them: an XNeqY between two unassigned variables is a no-op (x_neq_y.rs:82-93), so the initial sweep of a node is
+the adjacency lists of its assigned variables (pcp_neq.hip).  `config.steps_reference_equivalent_per_s` is the rate of pairs the
+REFERENCE's scheduler would pop to reach the same fixpoints (every propagator of every node once, store.rs:144-149, plus every
+wake-up) — a bookkeeping figure, not work done; `config.nodes_per_s` and `config.time_to_fixpoint_vs_cpu` compare time to the
+same bit-identical fixpoints.  `roofline` is PHYSICAL: the bytes the ABI contract forces across HBM per launch (every node's
+rows in once, the rows of changed nodes out once) / kernel time / 8 TB/s — always <= 1.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under torch.distributed.run
 (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.  `--mode search` runs BASELINE config 5 instead (the sharded
@@ -29,7 +31,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_BINARY, BYTES_TERNARY, BYTES_NARROWING = 28, 40, 8  # SURVEY.md §8d algorithmic bytes per filter step (side field only)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E vendor peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -58,7 +59,7 @@ def cpu_baseline(n, props, lb, ub, act, budget_s):
             steps += r[4]["steps"]
             nodes += 1
         dt = time.perf_counter() - t0
-        out[label] = {"steps_per_s": steps / dt, "nodes": nodes, "seconds": dt}
+        out[label] = {"steps_per_s": steps / dt, "nodes": nodes, "seconds": dt, "nodes_per_s": nodes / dt}
         if not check:
             keep = res
     main = out["libpcp-restatement"]
@@ -68,6 +69,7 @@ def cpu_baseline(n, props, lb, ub, act, budget_s):
                   f"of libpcp incl. the duplicate-subscription assert; without that assert: {out['restatement-noassert']['steps_per_s']:.3e} steps/s "
                   f"over {out['restatement-noassert']['nodes']} nodes",
         "host_cpu": _cpu_name(),
+        "nodes_per_s": main["nodes_per_s"], "nodes_per_s_noassert": out["restatement-noassert"]["nodes_per_s"],
     }
     return obj, keep
 
@@ -339,13 +341,12 @@ def main():
     status = t_status.cpu().numpy()
     if rank == 0:
         k_ms = float(np.median(kernel_ms))
-        compulsory = args.nodes * node_bytes(V, words, not implicit) + 8 * per_step["narrowings"]
-        alg_bytes = BYTES_BINARY * per_step["steps"] + BYTES_TERNARY * per_step["steps3"] + BYTES_NARROWING * per_step["narrowings"]
+        compulsory = args.nodes * node_bytes(V, words, not implicit) + 8 * V * min(args.nodes, per_step["narrowings"])
         tr = profiled_traffic({"n": n, "nodes_per_launch": args.nodes, "active": args.active})
         achieved = compulsory / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000",
-            "value": steps_all / dt_max,
+            "value": eval_all / dt_max,
             "unit": "filter-steps/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -360,8 +361,9 @@ def main():
                 "workload": f"N-queens n={n} (V={n}, P={len(props)} XNeqY), Interval<i32> domains (not the reference's default IntervalSet mode: see legs), "
                             f"{args.nodes} open nodes per GPU per step = this rank's share of the BFS frontier, 1 launch per step, in place on a fresh copy; "
                             + ("implicit-active nodes (domains only)" if implicit else "explicit `active` rows (183 KB per node)"),
-                "value_is": "reference-equivalent filter steps/s: the (propagator, node) pairs the reference's scheduler would pop; most are proven no-ops in bulk "
-                            "(steps_evaluated_per_s = pairs tested one by one)",
+                "value_is": "filter steps EXECUTED per second: (propagator, node) pairs tested one by one on the node's own domains (pcp_stats.evaluated); "
+                            "steps_reference_equivalent_per_s = pairs the reference's scheduler would pop for the same fixpoints (bookkeeping, not work)",
+                "steps_reference_equivalent_per_s": steps_all / dt_max,
                 "steps_evaluated_per_s": eval_all / dt_max,
                 "full_filter_evals_per_s": full_all / dt_max,
                 "nodes_per_s": args.nodes * world * args.steps / dt_max,
@@ -383,14 +385,13 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (tr or {}).get("traffic_bytes"),
                 "traffic_source": (tr or {}).get("source"),
-                "kernel": "pcp::fixpoint_kernel", "kernel_ms": k_ms,
+                "kernel": "pcp::neqfix_kernel" if plan.get("path") == 1 else "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "compulsory_bytes_per_launch": compulsory,
                 "model": "achieved = compulsory HBM bytes per launch (every node's lb/ub rows read once"
                          + ("" if implicit else " + its `active` row")
-                         + ", 8 B written per narrowing) / median HIP-event kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, per launch",
-                "algorithmic_bytes_per_launch_survey_8d": alg_bytes,
-                "algorithmic_frac_survey_8d": alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "algorithmic_note": "SURVEY.md §8d's 28 B per reference-equivalent step: never moved (LDS-resident domains, bulk range tests) - a side figure, not the roofline",
+                         + ", the rows of changed nodes written once) / median HIP-event kernel time; traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, per launch",
+                "algorithmic_note": "SURVEY.md 8d prices a filter step at 28 B (12 B descriptor + two 8 B domains): those bytes are LDS reads here (the domains of a tile "
+                                    "stay in LDS for the whole fixpoint), not HBM traffic; the roofline is the bytes the contract forces across HBM",
             },
         }
         legs_req = args.legs
@@ -412,6 +413,13 @@ def main():
                 if int(r_st[0]) != 0 and not (np.array_equal(r_lb[0], g_lb[i]) and np.array_equal(r_ub[0], g_ub[i]) and np.array_equal(r_act[0], g_act[i])):
                     raise SystemExit(f"PARITY FAILURE: node {i} differs from the oracle")
             out["config"]["parity_checked_nodes"] = k
+            cb = out["cpu_baseline"]
+            gpu_nps = out["config"]["nodes_per_s"]
+            out["config"]["time_to_fixpoint_vs_cpu"] = {
+                "gpu_nodes_per_s": gpu_nps, "cpu_nodes_per_s": cb["nodes_per_s"], "cpu_nodes_per_s_noassert": cb["nodes_per_s_noassert"],
+                "speedup": gpu_nps / cb["nodes_per_s"], "speedup_noassert": gpu_nps / cb["nodes_per_s_noassert"],
+                "note": "same nodes, bit-identical fixpoints (parity_checked_nodes): GPU nodes/s of the timed steps vs the single-thread restatement of libpcp on this host",
+            }
         if legs_req != "none":
             legs = side_legs(ctx, torch, dev, n, props, args, set(legs_req.split(",")), L, U)
         # the ONE JSON line stays short (the driver reads the tail of stdout): per leg its headline figures; everything else
@@ -427,6 +435,14 @@ def main():
                 b["hbm_frac"] = float(f"{l['hbm_frac']:.3g}")
             return b
         out["config"]["legs"] = [brief(l) for l in legs]
+        # the same figures as flat scalar keys (a nested list does not survive every JSON-line parser)
+        for l in legs:
+            key = "leg_" + l["name"].replace("-", "_")
+            if isinstance(l.get("kernel_ms"), dict):
+                out["config"][key + "_ms"] = round(l["kernel_ms"]["median"], 4)
+            for k2 in ("us_per_node", "nodes_per_s", "steps_per_s", "evaluated_per_s", "hbm_frac"):
+                if k2 in l:
+                    out["config"][f"{key}_{k2}"] = float(f"{l[k2]:.4g}")
         if legs:
             full = json.dumps({"legs": legs})
             print(full, file=sys.stderr, flush=True)

@@ -6,7 +6,7 @@ src = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 d = json.loads([l for l in src.strip().splitlines() if l.startswith("{")][-1])
 if "config" in d:
     c = d["config"]
-    print(f"headline: value={d['value']:.3e} steps/s  ms/step={d['ms_per_step']:.3f}  kernel_ms={c['kernel_ms_per_launch']}  evaluated/s={c['steps_evaluated_per_s']:.3e}  full/s={c['full_filter_evals_per_s']:.3e}  "
+    print(f"headline: value={d['value']:.3e} executed steps/s (reference-equivalent {c.get('steps_reference_equivalent_per_s', float('nan')):.3e})  nodes/s={c['nodes_per_s']:.3e}  ms/step={d['ms_per_step']:.3f}  kernel_ms={c['kernel_ms_per_launch']}  evaluated/s={c['steps_evaluated_per_s']:.3e}  full/s={c['full_filter_evals_per_s']:.3e}  "
           f"hbm_frac={d['roofline']['frac']:.3f}  eval/step={c['evaluated_per_step_per_gpu']:.3e} full/step={c['full_evals_per_step_per_gpu']:.3e} parity_nodes={c.get('parity_checked_nodes')}")
     legs = c.get("legs", [])
 else:
