@@ -218,7 +218,8 @@ int32_t pcp_branch_device_set(pcp_ctx* ctx, uint32_t n_nodes, const uint64_t* bi
  *   lb, ub           : [capacity][n_vars] device rows; rows [0, *sp) are the open nodes, row *sp - 1 the top
  *   sp, stop         : device uint32 each (the caller initialises *sp = 1 with the root in row 0, *stop = 0)
  *   status           : [capacity] device scratch
- *   counters         : device uint64[5] = { nodes, solutions, failed nodes, error (1 stack overflow, 2 hull violation), internal },
+ *   counters         : device uint64[5] = { nodes, solutions, failed nodes, error (1 stack overflow: the node stays on the stack, uncounted;
+ *                      2 hull violation; 3 an Unknown node without a variable to branch on — the reference panics, first_smallest_var.rs:36), internal },
  *                      accumulated (the caller zeroes them)
  *   first_solution   : [n_vars] device or NULL: the first solution found
  * Interval mode only. */
@@ -234,7 +235,8 @@ typedef struct {
 } pcp_dfs_state;
 int32_t pcp_dfs_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
 
-/* Counters accumulate on the device across pcp_propagate_device calls. */
+/* Counters accumulate on the device across pcp_propagate_device calls.  pcp_stats_reset also clears the sticky hull-violation word;
+ * pcp_stats_read is the only call that reports (and then clears) it. */
 int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
 int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */
 

@@ -20,7 +20,9 @@ pub struct GpuCStore<VStore> {
     cpu: CStoreFD<VStore>,  // the boxed propagators, `active`, label/restore
     ctx: *mut pcp_ctx,
     n_vars: usize,          // variables the device model was reset with
-    dev_units: Vec<usize>,  // host index of each device-side unit, ascending
+    dev_units: Vec<(usize, u64)>,  // (host index, allocation stamp) of each device-side unit, ascending
+    stamp_of: Vec<u64>,     // allocation stamp of each host unit: a restore followed by an alloc re-uses an INDEX, never a stamp
+    next_stamp: u64,
     cpu_only: bool,         // a propagator without a lowering: this space stays on the CPU path
 }
 
@@ -32,7 +34,7 @@ impl<VStore> GpuCStore<VStore> {
         let mut ctx = ptr::null_mut();
         let rc = unsafe { pcp_ctx_create(hip_device, &mut ctx) };
         assert!(rc == PCP_OK, "pcp_ctx_create: {} (the engine has no CPU path)", rc);
-        GpuCStore { cpu: CStoreFD::empty(), ctx, n_vars: usize::MAX, dev_units: vec![], cpu_only: false }
+        GpuCStore { cpu: CStoreFD::empty(), ctx, n_vars: usize::MAX, dev_units: vec![], stamp_of: vec![], next_stamp: 0, cpu_only: false }
     }
 
     fn check(&self, rc: i32) {
@@ -57,7 +59,10 @@ impl<VStore> GpuCStore<VStore> {
     }
 
     /// Brings the device model in line with `cpu.propagators` (append-only since the last call, or truncated by a restore:
-    /// store.rs:223-230, 319-323).  Unit u of the device is host unit dev_units[u].
+    /// store.rs:223-230, 319-323).  Unit u of the device is host unit dev_units[u].  The search loop restores to label L and then
+    /// allocs the right-branch constraint at the same index L where the left branch's was (branch.rs:51-55): an index alone does
+    /// not identify a unit, its allocation stamp does — a device unit is kept only while the host unit at its index still carries
+    /// the stamp it was sent with.
     fn sync_model(&mut self, n_vars: usize, hull: (i32, i32)) {
         if n_vars != self.n_vars {
             self.check(unsafe { pcp_model_reset(self.ctx, n_vars as u32, 0) });
@@ -66,18 +71,19 @@ impl<VStore> GpuCStore<VStore> {
             self.dev_units.clear();
         }
         let len = self.cpu.propagators_len();                 // accessor added by apply_lower_hook.sh
-        let keep = self.dev_units.iter().take_while(|&&u| u < len).count();
+        self.stamp_of.truncate(len);                          // a restore shortened the store since the last alloc
+        let keep = self.dev_units.iter().take_while(|&&(u, st)| u < len && self.stamp_of[u] == st).count();
         if keep < self.dev_units.len() {
             self.check(unsafe { pcp_model_truncate(self.ctx, keep as u32) });
             self.dev_units.truncate(keep);
         }
-        let first_new = self.dev_units.last().map_or(0, |u| u + 1);
+        let first_new = self.dev_units.last().map_or(0, |&(u, _)| u + 1);
         for u in first_new..len {
             match self.cpu.propagator(u).lower() {
                 Some(desc) => {
                     let rows = Self::rows_of(&desc, u as u32);
                     self.check(unsafe { pcp_model_push_props(self.ctx, rows.len() as u32, rows.as_ptr()) });
-                    self.dev_units.push(u);
+                    self.dev_units.push((u, self.stamp_of[u]));
                 }
                 None => { self.cpu_only = true; return; }
             }
@@ -106,7 +112,7 @@ where
         // node = (bounds of every variable, `active` of the device-side units as u64 words)
         let words = (self.dev_units.len() + 63) / 64;
         let mut active = vec![0u64; words];
-        for (k, &u) in self.dev_units.iter().enumerate() {
+        for (k, &(u, _)) in self.dev_units.iter().enumerate() {
             if self.cpu.is_active(u) { active[k >> 6] |= 1u64 << (k & 63); }
         }
         let mut status = 0u8;
@@ -123,7 +129,7 @@ where
                 debug_assert!(ok);
             }
             let _ = vstore.drain_delta().count();
-            for (k, &u) in self.dev_units.iter().enumerate() {
+            for (k, &(u, _)) in self.dev_units.iter().enumerate() {
                 if (active[k >> 6] >> (k & 63)) & 1 == 0 { self.cpu.deactivate(u); }
             }
         }
@@ -137,14 +143,27 @@ impl<VStore> AssociativeCollection for GpuCStore<VStore> where CStoreFD<VStore>:
     type Location = <CStoreFD<VStore> as AssociativeCollection>::Location;
 }
 impl<VStore> Alloc for GpuCStore<VStore> where CStoreFD<VStore>: Alloc {
-    fn alloc(&mut self, p: Self::Item) -> Self::Location { self.cpu.alloc(p) } // Store::alloc (store.rs:223-230)
+    fn alloc(&mut self, p: Self::Item) -> Self::Location {
+        // Store::alloc (store.rs:223-230) appends at index len; whatever the device holds at that index or beyond is stale
+        let idx = self.cpu.propagators_len();
+        self.stamp_of.truncate(idx);
+        self.stamp_of.push(self.next_stamp);
+        self.next_stamp += 1;
+        self.cpu.alloc(p)
+    }
 }
 impl<VStore> Empty for GpuCStore<VStore> where CStoreFD<VStore>: Empty {
     fn empty() -> Self { GpuCStore::new(0) }
 }
 // Clone (store.rs:260-272: deep-clones the propagators, drops reactor/scheduler): a fresh context, the model is re-sent lazily.
 impl<VStore> Clone for GpuCStore<VStore> where CStoreFD<VStore>: Clone + Empty {
-    fn clone(&self) -> Self { let mut c = GpuCStore::new(0); c.cpu = self.cpu.clone(); c }
+    fn clone(&self) -> Self {
+        let mut c = GpuCStore::new(0);
+        c.cpu = self.cpu.clone();
+        c.stamp_of = self.stamp_of.clone();
+        c.next_stamp = self.next_stamp;
+        c
+    }
 }
 // Freeze / Snapshot (store.rs:306-324): the label is the stock store's (propagators.len(), active.clone()); restoring truncates
 // `cpu.propagators`, and the next consistency() truncates the device model to match (sync_model).

@@ -213,9 +213,11 @@ struct SearchStats { uint64_t num_solution = 0, num_failed_node = 0, num_prune =
 // [3P-unverified]: every operation below is the SET-theoretic one — in particular `difference(&v)` removes an interior
 // value (splitting an interval), which is what makes XNeqY raise `Inner` events on VStoreSet (the FDSpace default,
 // variable/mod.rs:38, search/mod.rs:41-43; example/src/nqueens.rs:34 allocates IntervalSet::new(1, n)).
-// PARITY: unpinned beyond the search-level answers the reference's tests hold on FDSpace (solution counts
-// all_solution.rs:70, first-solution statuses one_solution.rs:121-128, StopNode stop_node.rs:83-104): no reference test
-// observes an IntervalSet domain after propagation.
+// PARITY: the REFERENCE pins this mode only at the search level (solution counts all_solution.rs:70, first-solution statuses
+// one_solution.rs:121-128, StopNode stop_node.rs:83-104): no reference test observes an IntervalSet domain after propagation,
+// and the crate is not in the tree.  Below that level the pin is an independent restatement: tests/test_intervalset_model.py
+// re-derives the algebra and the propagation fixpoint over plain Python sets from the reference's propagator sources and agrees
+// with this file on every random case (set algebra operation by operation, consistency over six propagator kinds).
 // ---------------------------------------------------------------------------------------------------
 struct IntervalSet {
   std::vector<Interval> iv;  // sorted by lb; iv[i].ub + 1 < iv[i+1].lb

@@ -1054,22 +1054,30 @@ int32_t pcp_stats_reset(pcp_ctx* c, void* hip_stream) {
   if (!c) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, kStatSlots * sizeof(pcp_stats), reinterpret_cast<hipStream_t>(hip_stream)));
+  HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));  // and the sticky hull-violation word
+  return PCP_OK;
+}
+
+// The counters, and whether the sticky hull-violation word is raised (left as it is: only pcp_stats_read consumes it).
+static int32_t read_counters(pcp_ctx* c, pcp_stats* out, uint32_t* flag, hipStream_t stream) {
+  pcp_stats slots[kStatSlots];
+  HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats, sizeof(slots), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(c, hipMemcpyAsync(flag, c->d_retry + 1, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(c, hipStreamSynchronize(stream));
+  static_assert(sizeof(pcp_stats) % sizeof(uint64_t) == 0, "pcp_stats is a struct of u64 counters");
+  memset(out, 0, sizeof(*out));
+  for (uint32_t s = 0; s < kStatSlots; ++s)
+    for (size_t i = 0; i < sizeof(pcp_stats) / sizeof(uint64_t); ++i)
+      reinterpret_cast<uint64_t*>(out)[i] += reinterpret_cast<const uint64_t*>(&slots[s])[i];
   return PCP_OK;
 }
 
 int32_t pcp_stats_read(pcp_ctx* c, pcp_stats* out, void* hip_stream) {
   if (!c || !out) return PCP_ERR_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
-  pcp_stats slots[kStatSlots];
-  HIP_TRY(c, hipMemcpyAsync(slots, c->d_stats, sizeof(slots), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
   uint32_t flag = 0;
-  HIP_TRY(c, hipMemcpyAsync(&flag, c->d_retry + 1, 4, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(hip_stream)));
-  HIP_TRY(c, hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
-  static_assert(sizeof(pcp_stats) % sizeof(uint64_t) == 0, "pcp_stats is a struct of u64 counters");
-  memset(out, 0, sizeof(*out));
-  for (uint32_t s = 0; s < kStatSlots; ++s)
-    for (size_t i = 0; i < sizeof(pcp_stats) / sizeof(uint64_t); ++i)
-      reinterpret_cast<uint64_t*>(out)[i] += reinterpret_cast<const uint64_t*>(&slots[s])[i];
+  const int32_t rcr = read_counters(c, out, &flag, reinterpret_cast<hipStream_t>(hip_stream));
+  if (rcr) return rcr;
   if (flag) {  // some launch since the last read met a node outside the declared hull
     HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));
     c->trusted_epoch = 0;
@@ -1145,7 +1153,8 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   if (bits_bytes) HIP_TRY(c, hipMemcpyAsync(base + o_bits, bits, bits_bytes, hipMemcpyHostToDevice, stream));
   if (active && act_bytes) HIP_TRY(c, hipMemcpyAsync(base + o_act, active, act_bytes, hipMemcpyHostToDevice, stream));
   pcp_stats before;
-  if (stats) { rc = pcp_stats_read(c, &before, stream); if (rc) return rc; }
+  uint32_t flag_before = 0;  // (a violation raised by an EARLIER device launch stays pending for its owner's pcp_stats_read)
+  if (stats) { rc = read_counters(c, &before, &flag_before, stream); if (rc) return rc; }
   pcp_device_batch bt;
   memset(&bt, 0, sizeof(bt));
   if (sw) { bt.bits_in = reinterpret_cast<uint64_t*>(base + o_bits); bt.bits_out = reinterpret_cast<uint64_t*>(base + o_bits); }
@@ -1166,7 +1175,8 @@ int32_t pcp_propagate(pcp_ctx* c, uint32_t n_nodes, int32_t* lb, int32_t* ub, ui
   HIP_TRY(c, hipStreamSynchronize(stream));
   if (stats) {
     pcp_stats after;
-    rc = pcp_stats_read(c, &after, stream);
+    uint32_t flag_after = 0;
+    rc = read_counters(c, &after, &flag_after, stream);
     if (rc) return rc;
     stats->steps = after.steps - before.steps; stats->steps3 = after.steps3 - before.steps3;
     stats->narrowings = after.narrowings - before.narrowings; stats->waves = after.waves - before.waves;

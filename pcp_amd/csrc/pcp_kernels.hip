@@ -2595,8 +2595,14 @@ __global__ void __launch_bounds__(256) dfs_step_kernel(uint32_t V, int32_t* __re
       }
       new_sp = sp + 1;
     } else if (key != ~0ull) {
-      if (tid == 0) { counters[3] = 1; *stop = 1u; }  // stack overflow
-      new_sp = sp;
+      // stack overflow: terminal for this call.  The node stays on the stack, uncounted: a caller that resumes with a larger
+      // stack propagates it again (idempotent) and counts it then.
+      if (tid == 0) { counters[3] = 1; *stop = 1u; }
+      return;
+    } else {
+      // Unknown, yet no variable with more than one value: the reference panics here (first_smallest_var.rs:36); error 3
+      if (tid == 0) { counters[3] = 3; *stop = 1u; }
+      return;
     }
   }
   if (tid == 0) {

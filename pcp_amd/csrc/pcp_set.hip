@@ -348,8 +348,9 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
     const uint64_t* in_row = (IMPLICIT || !a.live_in) ? nullptr : a.live_in + (size_t)node * words;
     const SetDom dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow};
     for (uint32_t w = wv; w < words; w += nwv) {
-      uint64_t word = in_row ? in_row[w] : ~0ull;
-      if (w == words - 1) word &= tail_mask;
+      const uint64_t raw = in_row ? in_row[w] : ~0ull;
+      uint64_t word = raw;
+      if (w == words - 1) word &= tail_mask;  // bits at or above n_recs name no record: they are dropped from the caller's row
       const uint32_t r = (w << 6) + lane;
       bool e = false;
       if ((word >> lane) & 1ull) {
@@ -359,12 +360,17 @@ __global__ void __launch_bounds__(kSetThreads) setfix_kernel(const SetArgs a) {
       }
       if constexpr (!IMPLICIT) {
         const uint64_t nw = word & ~__ballot(e);
-        if (lane == 0 && (in_row != live_row || nw != word)) live_row[w] = nw;
+        if (lane == 0 && (in_row != live_row || nw != raw)) live_row[w] = nw;
       }
     }
   } else if constexpr (!IMPLICIT) {
-    if (a.live_in && a.live_in != a.live)
-      for (uint32_t w = tid; w < words; w += nth) live_row[w] = a.live_in[(size_t)node * words + w];
+    // failed while staging: the row that is exported must still be defined (the caller's row, or all units active)
+    if (a.live_in != a.live || !a.live_in)
+      for (uint32_t w = tid; w < words; w += nth) {
+        uint64_t word = a.live_in ? a.live_in[(size_t)node * words + w] : ~0ull;
+        if (w == words - 1) word &= tail_mask;
+        live_row[w] = word;
+      }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

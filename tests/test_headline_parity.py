@@ -104,3 +104,82 @@ def test_deep_dive_nodes(env, dive, implicit, neq):
     got_act = gact[pick] if gact is not None else None
     assert_parity((ref[0], ref[1], ref[2] if got_act is not None else None, ref[3]), (glb[pick], gub[pick], got_act, gst[pick]), f"dive {dive} implicit={implicit}")
     ctx.set_option("nodes_per_block", 0)
+
+
+def test_device_side_dfs_at_n1000_node_for_node(env):
+    """pcp_dfs_device at the benchmarked size (parity corner b): the first 64 nodes of the reference's DFS on
+    N-queens-1000, one step per call — the node on top of the device stack before step k is the oracle's k-th visited node (its
+    folded input domains, bit for bit), and the status the step leaves is the oracle's.  A node's input is its parent's
+    propagated domains with one bound moved, so this pins the fixpoints and the order (one_solution.rs:46-51: left first)."""
+    import ctypes as C
+    ctx, om, torch = env
+    _headline_opts(ctx)
+    ctx.set_option("nodes_per_block", 0)
+    K = 64
+    lb0, ub0 = np.ones(N, np.int32), np.full(N, N, np.int32)
+    _, _, rec, _ = om.search(lb0, ub0, all_solutions=False, node_limit=K, check_dup=False, max_records=K)
+    dev = torch.device("cuda", 0)
+    cap = 256
+    lb = torch.zeros((cap, N), dtype=torch.int32, device=dev)
+    ub = torch.zeros((cap, N), dtype=torch.int32, device=dev)
+    lb[0] = torch.from_numpy(lb0).to(dev); ub[0] = torch.from_numpy(ub0).to(dev)
+    state = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+    status = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    counters = torch.zeros(5, dtype=torch.int64, device=dev)
+    st = E.DfsState(lb.data_ptr(), ub.data_ptr(), cap, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), None)
+    n_rec = rec["status"].shape[0]
+    assert n_rec == K
+    for k in range(K):
+        sp = int(state[0].item())
+        assert sp >= 1
+        top = sp - 1
+        assert np.array_equal(lb[top].cpu().numpy(), rec["lb_in"][k]) and np.array_equal(ub[top].cpu().numpy(), rec["ub_in"][k]), f"node {k}: input differs from the oracle's"
+        ctx._check(ctx._L.pcp_dfs_device(ctx._h, C.byref(st), 1, 0, 0, None))
+        torch.cuda.synchronize()
+        assert int(status[top].item()) == int(rec["status"][k]), f"node {k}: status"
+    assert int(counters[0].item()) == K and int(counters[3].item()) == 0
+
+
+@pytest.mark.parametrize("implicit", [False, True])
+def test_set_mode_nqueens_1000(implicit):
+    """N-queens-1000 over IntervalSet<i32> domains (FDSpace, what example/src/nqueens.rs:34 allocates) at the benchmarked size
+    (parity corner a): 16 nodes of the set-mode frontier and 16 nodes on top of the stack after a short dive —
+    125 KB of sets per node, 16 words per variable — against `consistency_set`, explicit rows and implicit nodes."""
+    import torch
+    from pcp_amd.search_device import DeviceSearch
+    ctx = E.Context(0)
+    props = M.nqueens_props(N)
+    sw = (N + 63) // 64
+    ctx.set_model(N, props, set_words=sw)
+    ctx.set_hull(1, N)
+    om = orc.OracleModel(N, props)
+    B, _, _ = W.nqueens_frontier_set(ctx, N, 64)
+    pick = np.arange(0, B.shape[0], max(1, B.shape[0] // 16))[:16]
+    ds = DeviceSearch(ctx, batch=16, capacity=1024, implicit=True)
+    ds.reset(np.ones(N, np.int32), np.full(N, N, np.int32), 1)
+    ds.advance(max_rounds=60, batch=1)
+    ds.advance(max_rounds=2, batch=16)
+    ds.compact()  # rows [0, size) are the open nodes, bottom to top
+    k = min(16, ds.size)
+    deep = ds.bits[ds.size - k:ds.size].cpu().numpy().view(np.uint64)
+    assert k >= 8
+    bits = np.concatenate([B[pick], deep])
+    n = bits.shape[0]
+    ref = om.consistency_set(bits, 1, None, check_dup=False)
+    if implicit:
+        got = ctx.propagate_set(bits, None)
+        assert ctx.last_plan()["implicit_active"] == 1 and ctx.last_plan()["set_mode"] == 1
+        gact = None
+    else:
+        ctx.set_option("implicit_active", 0)
+        got = ctx.propagate_set(bits, E.full_active(n, om.n_units))
+        ctx.set_option("implicit_active", 1)
+        assert ctx.last_plan()["implicit_active"] == 0
+        gact = got[3]
+    assert np.array_equal(ref[4], got[4]), (ref[4], got[4])
+    ok = ref[4] != 0
+    assert np.array_equal(ref[2][ok], got[2][ok]) and np.array_equal(ref[0][ok], got[0][ok]) and np.array_equal(ref[1][ok], got[1][ok])
+    if gact is not None:
+        assert np.array_equal(ref[3][ok], gact[ok])
+    assert (got[2] != bits).any()  # interior values were removed
+    ctx.close()
