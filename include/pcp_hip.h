@@ -60,8 +60,22 @@ typedef enum {
   PCP_GT3 = 4,  /* XGreaterYPlusZ   propagators/cmp/x_greater_y_plus_z.rs:75-128                        */
   PCP_EQ3 = 5,  /* XEqYPlusZ = GT3(x+1,y,z) && LT3(x-1,y,z), one propagator
                                     propagators/cmp/x_eq_y_plus_z.rs:31-105                              */
-  PCP_MUL3 = 6  /* XEqYMulZ         propagators/cmp/x_eq_y_mul_z.rs:68-115 (narrows x only)             */
+  PCP_MUL3 = 6, /* XEqYMulZ         propagators/cmp/x_eq_y_mul_z.rs:68-115 (narrows x only)             */
+  PCP_BOOL = 7, /* logic::Boolean   logic/boolean.rs:111-140: the formula "X = 1" over a 0/1 view (one operand)   */
+  PCP_NBOOL = 8 /* logic::BooleanNeg logic/boolean_neg.rs:71-96: "X = 0"                                          */
 } pcp_kind;
+
+/* The reified layer (logic/): ONE unit = a tree of Conjunction (logic/conjunction.rs:77-119) and Disjunction
+ * (logic/disjunction.rs:78-141) nodes over elementary leaves.  NotFormula::not is applied by the caller when the tree is built, as
+ * the reference does (implication f g = Disjunction[f, g.not()], logic/mod.rs:30-36; equivalence = Conjunction of both
+ * implications, logic/mod.rs:38-45): the engine only sees positive trees. */
+typedef enum { PCP_F_LEAF = 0, PCP_F_AND = 1, PCP_F_OR = 2 } pcp_fnode_type;
+typedef struct {
+  uint8_t type;        /* pcp_fnode_type */
+  uint8_t reserved;    /* must be 0 */
+  uint16_t n_children; /* inner nodes: >= 1 */
+  uint32_t first;      /* leaf: index into `leaves`; inner node: index in `nodes` of its first child (children are consecutive) */
+} pcp_fnode;
 
 /* SKleene as returned by Consistency::consistency (trilean::SKleene; propagation/store.rs:247-257). */
 typedef enum { PCP_FALSE = 0, PCP_TRUE = 1, PCP_UNKNOWN = 2 } pcp_status;
@@ -133,6 +147,13 @@ int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
  * in one propagator — directly or through its Sums — is PCP_ERR_CONTRACT like the reference's reactor panic.  Interval mode
  * only.  pcp_model_reset forgets the terms. */
 int32_t pcp_model_push_sum(pcp_ctx* ctx, uint32_t n_members, const uint32_t* vars, uint32_t* term);
+/* ≡ Store::alloc of ONE formula propagator: nodes[0] is the root, at most 8 levels deep; leaves are elementary props (group fields
+ * ignored; Sum operands allowed).  Its dependencies are the sorted, de-duplicated union of its leaves' (conjunction.rs:107-118,
+ * disjunction.rs:119-131), so a variable may occur in several leaves.  A pop of the unit runs Disjunction::propagate literally: a
+ * child is propagated only when every other child is disentailed.  Where the reference would PANIC — Boolean::propagate on a domain
+ * without 1 reached through a Conjunction (a non-monotonic update, variable/store.rs:153-156) — the node fails instead.
+ * Interval mode only.  Models with formula units run the general formula kernel (pcp_formula.hip). */
+int32_t pcp_model_push_formula(pcp_ctx* ctx, uint32_t n_nodes, const pcp_fnode* nodes, uint32_t n_leaves, const pcp_prop* leaves);
 /* ≡ FrozenStore::restore's `propagators.truncate(label.0)` (propagation/store.rs:319-323); n_units counts
  * units, not elementary props. */
 int32_t pcp_model_truncate(pcp_ctx* ctx, uint32_t n_units);
@@ -260,7 +281,8 @@ typedef struct {
   uint32_t path;            /* 0 = the generic kernels (every propagator tested in the initial sweep, in bulk where range tests allow);
                                1 = the assignment-driven kernel of all-XNeqY models over implicit nodes: the sweep is the adjacency
                                lists of the assigned variables (an XNeqY between two unassigned variables is a no-op, x_neq_y.rs:82-93);
-                               2 = the 10-bit-cell kernel of binary models whose store does not fit LDS as pairs (implicit nodes, declared hull) */
+                               2 = the 10-bit-cell kernel of binary models whose store does not fit LDS as pairs (implicit nodes, declared hull);
+                               3 = the formula kernel: a store with formula propagators (pcp_model_push_formula) or Boolean leaves */
 } pcp_plan;
 int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
 

@@ -68,6 +68,17 @@ pub struct pcp_device_batch {
     pub bits_out: *mut u64,
 }
 
+/// One node of a formula unit (logic/conjunction.rs, logic/disjunction.rs): type 0 leaf (first = index into the leaves), 1 Conjunction,
+/// 2 Disjunction (first = index of the first child, children consecutive).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct pcp_fnode {
+    pub type_: u8,
+    pub reserved: u8,
+    pub n_children: u16,
+    pub first: u32,
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct pcp_plan {
@@ -111,6 +122,7 @@ extern "C" {
     pub fn pcp_model_reset(ctx: *mut pcp_ctx, n_vars: u32, set_words: u32) -> i32; // Store::empty
     pub fn pcp_model_push_props(ctx: *mut pcp_ctx, n: u32, props: *const pcp_prop) -> i32; // Store::alloc
     pub fn pcp_model_push_sum(ctx: *mut pcp_ctx, n_members: u32, vars: *const u32, term: *mut u32) -> i32; // Sum::new
+    pub fn pcp_model_push_formula(ctx: *mut pcp_ctx, n_nodes: u32, nodes: *const pcp_fnode, n_leaves: u32, leaves: *const pcp_prop) -> i32; // one formula unit (logic/)
     pub fn pcp_model_truncate(ctx: *mut pcp_ctx, n_units: u32) -> i32; // FrozenStore::restore
     pub fn pcp_model_n_units(ctx: *const pcp_ctx, n_units: *mut u32, n_props: *mut u32) -> i32;
     pub fn pcp_model_set_hull(ctx: *mut pcp_ctx, lo: i32, hi: i32) -> i32; // hull of the VStore::alloc domains

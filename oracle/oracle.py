@@ -77,6 +77,8 @@ def lib():
         L.orc_model_free.argtypes = [C.c_void_p]
         L.orc_model_push_props.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_model_push_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.orc_model_push_formula.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_is_subsumed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_model_n_units.argtypes = [C.c_void_p]
         L.orc_model_n_units.restype = C.c_uint32
         L.orc_consistency.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -122,10 +124,13 @@ def _ptr(a: Optional[np.ndarray]):
 class OracleModel:
     """A model held by the oracle: n_vars + pcp_prop rows (same rows as fed to the HIP engine)."""
 
-    def __init__(self, n_vars: int, props: np.ndarray, sums=None):
-        props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
+    def __init__(self, n_vars: int, props: Optional[np.ndarray] = None, sums=None):
         self.n_vars = int(n_vars)
         self._h = lib().orc_model_new(self.n_vars)
+        if props is None:  # built push by push (pcp_amd.model.push_model: models with formula units)
+            self.n_units = self.words = 0
+            return
+        props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
         try:
             for members in (sums or []):  # term::Sum views, numbered in order
                 mv = np.ascontiguousarray(members, np.uint32)
@@ -143,6 +148,42 @@ class OracleModel:
         if getattr(self, "_h", None):
             lib().orc_model_free(self._h)
             self._h = None
+
+    # ---- the push interface pcp_amd.model.push_model drives (same calls as the engine's Context) --------------------------
+    def reset_model(self, n_vars: int, set_words: int = 0):
+        lib().orc_model_free(self._h)
+        self.n_vars = int(n_vars)
+        self._h = lib().orc_model_new(self.n_vars)
+        self._refresh()
+
+    def _refresh(self):
+        self.n_units = int(lib().orc_model_n_units(self._h))
+        self.words = (self.n_units + 63) // 64
+
+    def push_sum(self, members):
+        mv = np.ascontiguousarray(members, np.uint32)
+        t = C.c_uint32()
+        _check(lib().orc_model_push_sum(self._h, len(mv), _ptr(mv), C.byref(t)))
+        return t.value
+
+    def push_props(self, props):
+        props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
+        _check(lib().orc_model_push_props(self._h, len(props), _ptr(props)))
+        self._refresh()
+
+    def push_formula(self, nodes, leaves):
+        from pcp_amd.model import FNODE_DTYPE
+        nodes = np.ascontiguousarray(nodes, dtype=FNODE_DTYPE)
+        leaves = np.ascontiguousarray(leaves, dtype=PROP_DTYPE)
+        _check(lib().orc_model_push_formula(self._h, len(nodes), _ptr(nodes), len(leaves), _ptr(leaves)))
+        self._refresh()
+
+    def is_subsumed(self, lb, ub) -> int:
+        """Store::is_subsumed (propagation/store.rs:232-238) of ONE store: Kleene-and over all propagators, no propagation."""
+        lb = np.ascontiguousarray(lb, np.int32); ub = np.ascontiguousarray(ub, np.int32)
+        out = C.c_uint8()
+        _check(lib().orc_is_subsumed(self._h, _ptr(lb), _ptr(ub), C.byref(out)))
+        return int(out.value)
 
     def consistency(self, lb: np.ndarray, ub: np.ndarray, active: Optional[np.ndarray] = None, check_dup: bool = False):
         """≡ Consistency::consistency per node.  lb/ub: [n_nodes, n_vars] int32 (copied).  Returns

@@ -48,6 +48,8 @@ typename T::FormulaT make_elementary(const pcp_prop& p, uint32_t n_vars, const s
     case PCP_GT3: return std::make_unique<typename T::XGreaterYPlusZT>(v(0), v(1), v(2));
     case PCP_EQ3: return std::make_unique<typename T::XEqYPlusZT>(v(0), v(1), v(2));
     case PCP_MUL3: return std::make_unique<typename T::XEqYMulZT>(v(0), v(1), v(2));
+    case PCP_BOOL: return std::make_unique<typename T::BooleanT>(v(0));
+    case PCP_NBOOL: return std::make_unique<typename T::BooleanNegT>(v(0));
     default: throw Panic("unknown propagator kind");
   }
 }
@@ -69,13 +71,39 @@ struct DistinctGroup final : T::PropagatorT {
   uint64_t num_elementary() const override { return conj->num_elementary(); }
 };
 
+// A formula unit (pcp_model_push_formula): nodes[0] is the root; an inner node's children are nodes[first .. first + n_children).
 template <class T>
-std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props, uint32_t n_vars, const std::vector<std::vector<uint32_t>>& sums) {
+typename T::FormulaT build_formula(const std::vector<pcp_fnode>& nodes, uint32_t at, const pcp_prop* leaves, size_t n_leaves, uint32_t n_vars,
+                                   const std::vector<std::vector<uint32_t>>& sums, int depth = 0) {
+  if (at >= nodes.size() || depth > 16) throw Panic("malformed formula");
+  const pcp_fnode& nd = nodes[at];
+  if (nd.type == PCP_F_LEAF) {
+    if (nd.first >= n_leaves) throw Panic("formula leaf out of range");
+    return make_elementary<T>(leaves[nd.first], n_vars, sums);
+  }
+  if (nd.n_children == 0) throw Panic("a Conjunction / Disjunction needs at least one child");
+  std::vector<typename T::FormulaT> fs;
+  for (uint32_t c = 0; c < nd.n_children; ++c) fs.push_back(build_formula<T>(nodes, nd.first + c, leaves, n_leaves, n_vars, sums, depth + 1));
+  if (nd.type == PCP_F_AND) return std::make_unique<typename T::ConjunctionT>(std::move(fs));
+  if (nd.type == PCP_F_OR) return std::make_unique<typename T::DisjunctionT>(std::move(fs));
+  throw Panic("unknown formula node type");
+}
+
+template <class T>
+std::vector<typename T::FormulaT> build_units(const std::vector<pcp_prop>& props, uint32_t n_vars, const std::vector<std::vector<uint32_t>>& sums,
+                                              const std::vector<std::vector<pcp_fnode>>& formulas) {
   std::vector<typename T::FormulaT> units;
   size_t i = 0;
   while (i < props.size()) {
     const pcp_prop& p = props[i];
     if (p.group_kind == 0) { units.push_back(make_elementary<T>(p, n_vars, sums)); ++i; continue; }
+    if (p.group_kind == 3) {  // the leaves of formula number p.group, in a row
+      size_t j = i;
+      while (j < props.size() && props[j].group_kind == 3 && props[j].group == p.group) ++j;
+      units.push_back(build_formula<T>(formulas.at(p.group), 0, &props[i], j - i, n_vars, sums));
+      i = j;
+      continue;
+    }
     size_t j = i;
     std::vector<typename T::FormulaT> fs;
     typename T::DepsT ddeps;
@@ -102,11 +130,12 @@ struct Model {
   uint32_t n_vars = 0;
   std::vector<pcp_prop> props;
   std::vector<std::vector<uint32_t>> sums;  // term::Sum views (pcp_model_push_sum)
+  std::vector<std::vector<pcp_fnode>> formulas;  // formula units (pcp_model_push_formula): the trees; their leaves sit in `props`
   std::vector<fd::Formula> units;       // one per reference-level propagator, over Interval<i32>
   std::vector<fdset::Formula> units_s;  // the same model over IntervalSet<i32>
   bool units_s_valid = false;           // built on the first set-mode call
   void rebuild() {
-    units = build_units<fd::Types>(props, n_vars, sums);
+    units = build_units<fd::Types>(props, n_vars, sums, formulas);
     units_s.clear();
     units_s_valid = false;
   }
@@ -114,7 +143,7 @@ struct Model {
 };
 template <> const std::vector<fd::Formula>& Model::units_of<fd::Types>() { return units; }
 template <> const std::vector<fdset::Formula>& Model::units_of<fdset::Types>() {
-  if (!units_s_valid) { units_s = build_units<fdset::Types>(props, n_vars, sums); units_s_valid = true; }
+  if (!units_s_valid) { units_s = build_units<fdset::Types>(props, n_vars, sums, formulas); units_s_valid = true; }
   return units_s;
 }
 
@@ -194,7 +223,35 @@ int orc_model_push_sum(void* h, uint32_t n, const uint32_t* vars, uint32_t* term
     *term = (uint32_t)m->sums.size() - 1;
   });
 }
+// One formula unit: a tree of Conjunction / Disjunction nodes over elementary leaves (negations already applied by the caller,
+// as the reference's NotFormula::not does at construction time).
+int orc_model_push_formula(void* h, uint32_t n_nodes, const pcp_fnode* nodes, uint32_t n_leaves, const pcp_prop* leaves) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    if (n_nodes == 0 || n_leaves == 0) throw Panic("empty formula");
+    const size_t old = m->props.size();
+    m->formulas.emplace_back(nodes, nodes + n_nodes);
+    for (uint32_t i = 0; i < n_leaves; ++i) {
+      pcp_prop p = leaves[i];
+      p.group_kind = 3;
+      p.group = (uint32_t)m->formulas.size() - 1;
+      m->props.push_back(p);
+    }
+    try { m->rebuild(); } catch (...) { m->props.resize(old); m->formulas.pop_back(); m->rebuild(); throw; }
+  });
+}
 uint32_t orc_model_n_units(void* h) { return (uint32_t)static_cast<Model*>(h)->units.size(); }
+// Store::is_subsumed (propagation/store.rs:232-238): the Kleene conjunction over ALL propagators of the store.
+int orc_is_subsumed(void* h, const int32_t* lb, const int32_t* ub, uint8_t* out) {
+  auto* m = static_cast<Model*>(h);
+  return guard([&] {
+    fd::VStore vs;
+    for (uint32_t v = 0; v < m->n_vars; ++v) vs.alloc(Interval::make(lb[v], ub[v]));
+    SKleene k = SKleene::True;
+    for (auto& u : m->units) k = kand(k, u->is_subsumed(vs));
+    *out = (uint8_t)k;
+  });
+}
 
 // ≡ Consistency::consistency on n_nodes independent spaces (same contract as pcp_propagate).
 int orc_consistency(void* h, uint32_t n_nodes, int32_t* lb, int32_t* ub, uint64_t* active, uint8_t* status,

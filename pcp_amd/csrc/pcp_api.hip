@@ -23,6 +23,11 @@ struct pcp_ctx {
   uint32_t set_words = 0;   // > 0: IntervalSet<i32> domains as bitsets (pcp_model_reset)
   std::vector<pcp_prop> props;          // as pushed
   std::vector<uint32_t> unit_of_prop;   // unit index of each prop
+  std::vector<int32_t> formula_of_prop; // formula number of each prop (a leaf of that tree), or -1
+  std::vector<std::vector<pcp_fnode>> formulas;  // pcp_model_push_formula: the trees (leaf.first = index among the formula's own leaves)
+  bool has_formulas = false;            // a formula unit or a Boolean / BooleanNeg leaf: the store runs pcp_formula.hip
+  pcp_fnode* d_fnodes = nullptr; size_t cap_fnodes = 0;
+  uint32_t* d_unit_root = nullptr; size_t cap_unit_root = 0;
   uint32_t n_units = 0;
   std::vector<std::vector<uint32_t>> sums;  // term::Sum views: member variables of each term (pcp_model_push_sum)
   uint32_t* d_sum_off = nullptr; uint32_t* d_sum_mem = nullptr; size_t cap_sum_off = 0, cap_sum_mem = 0;
@@ -121,12 +126,13 @@ int32_t ensure(pcp_ctx* c, T*& p, size_t& cap, size_t n) {
   return PCP_OK;
 }
 
-int arity(uint8_t kind) { return kind <= PCP_LT ? 2 : 3; }
+int arity(uint8_t kind) { return kind >= PCP_BOOL ? 1 : (kind <= PCP_LT ? 2 : 3); }
 bool is_sum_operand(uint32_t var) { return var >= PCP_SUM && var < PCP_NOVAR; }
 
 // Reference-panic checks on one prop (SURVEY.md §8b "Error conventions").
 int32_t validate_prop(pcp_ctx* c, const pcp_prop& p) {
-  if (p.kind > PCP_MUL3) return fail(c, PCP_ERR_ARG, "unknown propagator kind");
+  if (p.kind > PCP_NBOOL) return fail(c, PCP_ERR_ARG, "unknown propagator kind");
+  if (p.kind >= PCP_BOOL && c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "the reified layer (Boolean / formulas) is interval mode only");
   if (p.group_kind > 2 || p.reserved != 0) return fail(c, PCP_ERR_ARG, "bad group_kind/reserved");
   const int n = arity(p.kind);
   std::vector<uint32_t> seen;  // every variable the propagator subscribes to, Sum members included
@@ -201,7 +207,8 @@ int32_t finalize_model(pcp_ctx* c) {
       off[i] = (p.var[i] == PCP_CONST) ? 0 : p.off[i];
     }
     int64_t d;
-    if (n == 2) d = off[1] - off[0];              // X = x, Y = y + d
+    if (n == 1) d = off[0];                       // Boolean / BooleanNeg over the view x + d
+    else if (n == 2) d = off[1] - off[0];         // X = x, Y = y + d
     else if (p.kind == PCP_MUL3) {                // (x + dx) = (y + dy) * (z + dz): the offsets go to a side table, d = its index
       d = (int64_t)(mul_off.size() / 3);
       for (int i = 0; i < 3; ++i) mul_off.push_back((int32_t)off[i]);
@@ -212,7 +219,7 @@ int32_t finalize_model(pcp_ctx* c) {
     recs[r].y = s[1];
     recs[r].z = (n == 3) ? s[2] : 0;
     recs[r].d = (int32_t)d;
-    tern |= (n == 3);
+    tern |= (n != 2);  // (Boolean leaves too: such stores take the formula kernel, never the binary fast paths)
     for (int i = 0; i < n; ++i) for_each_dep(p.var[i], [&](uint32_t v) { ++deg[v]; });
   }
   tern |= n_sum != 0;  // Sum views: generic path only (no compact stream, no adjacency payloads, no word descriptors)
@@ -412,6 +419,41 @@ int32_t finalize_model(pcp_ctx* c) {
     HIP_TRY(c, hipMemcpy(c->d_rec_unit, c->unit_of_prop.data(), P * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_unit_first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
   }
+  if (c->has_formulas) {
+    // every unit as a tree for pcp_formula.hip: a standalone propagator = one leaf, a Conjunction / Distinct group = an AND over
+    // its members, a formula = its own tree with the leaves renumbered to record indices
+    std::vector<pcp_fnode> fn;
+    std::vector<uint32_t> root(c->n_units, 0);
+    size_t r = 0;
+    while (r < P) {
+      const uint32_t u = c->unit_of_prop[r];
+      size_t e = r;
+      while (e < P && c->unit_of_prop[e] == u) ++e;
+      root[u] = (uint32_t)fn.size();
+      const int32_t f = c->formula_of_prop[r];
+      if (f >= 0) {
+        const auto& tree = c->formulas[(size_t)f];
+        const uint32_t base = (uint32_t)fn.size();
+        for (const pcp_fnode& nd : tree) {
+          pcp_fnode q = nd;
+          q.first = nd.type == PCP_F_LEAF ? (uint32_t)r + nd.first : base + nd.first;
+          fn.push_back(q);
+        }
+      } else if (e - r == 1) {
+        fn.push_back(pcp_fnode{PCP_F_LEAF, 0, 0, (uint32_t)r});
+      } else {
+        if (e - r > 65535) return fail(c, PCP_ERR_UNSUPPORTED, "a Conjunction of more than 65535 members next to formula propagators");
+        const uint32_t base = (uint32_t)fn.size();
+        fn.push_back(pcp_fnode{PCP_F_AND, 0, (uint16_t)(e - r), base + 1});
+        for (size_t k = r; k < e; ++k) fn.push_back(pcp_fnode{PCP_F_LEAF, 0, 0, (uint32_t)k});
+      }
+      r = e;
+    }
+    if ((rc = ensure(c, c->d_fnodes, c->cap_fnodes, fn.size()))) return rc;
+    if ((rc = ensure(c, c->d_unit_root, c->cap_unit_root, root.size()))) return rc;
+    if (!fn.empty()) HIP_TRY(c, hipMemcpy(c->d_fnodes, fn.data(), fn.size() * sizeof(pcp_fnode), hipMemcpyHostToDevice));
+    if (!root.empty()) HIP_TRY(c, hipMemcpy(c->d_unit_root, root.data(), root.size() * 4, hipMemcpyHostToDevice));
+  }
   c->n_slots = n_slots;
   c->has_ternary = tern;
   c->recs_by_kind_valid = false;
@@ -575,7 +617,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -591,6 +633,9 @@ int32_t pcp_model_reset(pcp_ctx* c, uint32_t n_vars, uint32_t set_words) {
   c->set_words = set_words;
   c->props.clear();
   c->unit_of_prop.clear();
+  c->formula_of_prop.clear();
+  c->formulas.clear();
+  c->has_formulas = false;
   c->n_units = 0;
   c->sums.clear();
   c->has_groups = false;
@@ -618,7 +663,48 @@ int32_t pcp_model_push_props(pcp_ctx* c, uint32_t n, const pcp_prop* props) {
     if (p.group_kind != 0) c->has_groups = true;
     c->props.push_back(p);
     c->unit_of_prop.push_back(c->n_units - 1);
+    c->formula_of_prop.push_back(-1);
+    if (p.kind >= PCP_BOOL) c->has_formulas = true;
   }
+  c->dirty = true;
+  return PCP_OK;
+}
+
+int32_t pcp_model_push_formula(pcp_ctx* c, uint32_t n_nodes, const pcp_fnode* nodes, uint32_t n_leaves, const pcp_prop* leaves) {
+  if (!c || !nodes || !leaves || n_nodes == 0 || n_leaves == 0) return PCP_ERR_ARG;
+  if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "formula propagators are interval mode only");
+  // the tree: children behind their parent and consecutive, every node reached exactly once, every leaf used exactly once, depth <= 8
+  std::vector<uint32_t> depth(n_nodes, 0), uses(n_nodes, 0), leaf_uses(n_leaves, 0);
+  depth[0] = 1; uses[0] = 1;
+  for (uint32_t i = 0; i < n_nodes; ++i) {
+    const pcp_fnode& nd = nodes[i];
+    if (nd.reserved != 0 || nd.type > PCP_F_OR) return fail(c, PCP_ERR_ARG, "bad formula node");
+    if (uses[i] != 1) return fail(c, PCP_ERR_ARG, "formula node not reached exactly once from the root");
+    if (depth[i] > 8) return fail(c, PCP_ERR_UNSUPPORTED, "formula deeper than 8 levels");
+    if (nd.type == PCP_F_LEAF) {
+      if (nd.first >= n_leaves) return fail(c, PCP_ERR_ARG, "formula leaf out of range");
+      if (++leaf_uses[nd.first] != 1) return fail(c, PCP_ERR_ARG, "formula leaf used twice");
+      continue;
+    }
+    if (nd.n_children == 0) return fail(c, PCP_ERR_CONTRACT, "a Conjunction / Disjunction needs at least one child");
+    if (nd.first <= i || (uint64_t)nd.first + nd.n_children > n_nodes) return fail(c, PCP_ERR_ARG, "formula children out of range");
+    for (uint32_t k = 0; k < nd.n_children; ++k) { ++uses[nd.first + k]; depth[nd.first + k] = depth[i] + 1; }
+  }
+  for (uint32_t i = 0; i < n_leaves; ++i) {
+    if (leaf_uses[i] != 1) return fail(c, PCP_ERR_ARG, "formula leaf not used");
+    int32_t rc = validate_prop(c, leaves[i]);
+    if (rc) return rc;
+  }
+  c->formulas.emplace_back(nodes, nodes + n_nodes);
+  ++c->n_units;
+  for (uint32_t i = 0; i < n_leaves; ++i) {
+    pcp_prop p = leaves[i];
+    p.group_kind = 0; p.group = 0;
+    c->props.push_back(p);
+    c->unit_of_prop.push_back(c->n_units - 1);
+    c->formula_of_prop.push_back((int32_t)c->formulas.size() - 1);
+  }
+  c->has_formulas = true;
   c->dirty = true;
   return PCP_OK;
 }
@@ -642,9 +728,15 @@ int32_t pcp_model_truncate(pcp_ctx* c, uint32_t n_units) {
   while (keep < c->props.size() && c->unit_of_prop[keep] < n_units) ++keep;
   c->props.resize(keep);
   c->unit_of_prop.resize(keep);
+  c->formula_of_prop.resize(keep);
   c->n_units = n_units;
   c->has_groups = false;
   for (auto& p : c->props) c->has_groups |= p.group_kind != 0;
+  int32_t last_formula = -1;
+  c->has_formulas = false;
+  for (size_t i = 0; i < keep; ++i) { last_formula = std::max(last_formula, c->formula_of_prop[i]); c->has_formulas |= c->props[i].kind >= PCP_BOOL; }
+  c->formulas.resize((size_t)(last_formula + 1));
+  c->has_formulas |= last_formula >= 0;
   c->dirty = true;
   return PCP_OK;
 }
@@ -741,6 +833,26 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const uint32_t block = (uint32_t)c->opt_block;
   const uint32_t list_cap = (uint32_t)c->opt_list_cap;
 
+  if (c->has_formulas) {
+    // the reified layer: every unit is evaluated as a tree, one lane per unit (pcp_formula.hip); `active` rows are unit-level there
+    const size_t lds = lds_bytes_formula(S, c->n_units);
+    if (!lds || lds > c->lds_max) return fail(c, PCP_ERR_UNSUPPORTED, "a store with formula propagators must fit one CU's LDS (8 bytes per variable)");
+    FormArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m.recs = c->d_recs; a.m.const_val = c->d_const; a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S;
+    a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
+    a.nodes = c->d_fnodes; a.unit_root = c->d_unit_root; a.n_units = c->n_units; a.n_nodes = n_nodes; a.violation = c->d_retry + 1;
+    a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
+    a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;
+    LaunchPlan plan;
+    plan.grid = n_nodes; plan.block = 256; plan.lds_bytes = lds;
+    c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, bt->active_in ? 0u : 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 3u};
+    HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+    HIP_TRY(c, launch_formfix(a, plan, stream));
+    HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+    c->ev_valid = true;
+    return PCP_OK;
+  }
   const bool implicit = bt->active_in == nullptr && c->opt_implicit;  // see below (a.live == nullptr)
   if (implicit && c->neq_model && c->opt_neq_path && c->opt_force_path != 2 && !c->opt_global_dom) {
     int32_t rcn = propagate_neq_device(c, n_nodes, bt, stream);

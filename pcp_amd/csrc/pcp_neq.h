@@ -46,4 +46,25 @@ struct BigArgs {
 size_t lds_bytes_big(uint32_t n_vars, uint32_t n_slots);
 hipError_t launch_bigfix(const BigArgs& a, const LaunchPlan& p, hipStream_t stream);
 
+// Stores with formula propagators (the reified layer): every unit as a tree, one lane per unit (pcp_formula.hip).
+using FNode = pcp_fnode;  // leaf: first = record index; inner node: first = index of its first child (children consecutive)
+struct FormArgs {
+  ModelDev m;                // needs recs, const_val, sums, n_vars, n_slots
+  const FNode* nodes;        // the trees of all units
+  const uint32_t* unit_root; // [n_units] root node of each unit
+  uint32_t n_units;
+  uint32_t n_nodes;
+  uint32_t* violation;
+  const int32_t* lb_in;
+  const int32_t* ub_in;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  const uint64_t* active_in; // [n_nodes][ceil(n_units/64)] or null = every unit active
+  uint64_t* active_out;      // or null
+  uint8_t* status;
+  pcp_stats* stats;
+};
+size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units);
+hipError_t launch_formfix(const FormArgs& a, const LaunchPlan& p, hipStream_t stream);
+
 }  // namespace pcp

@@ -24,7 +24,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 # Every symbol include/pcp_hip.h declares (tests/test_abi.py checks the .so exports each of them).
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
-    "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
+    "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
     "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
@@ -97,6 +97,8 @@ def load_library():
     L.pcp_model_reset.argtypes = [vp, u32, u32]
     L.pcp_model_push_props.argtypes = [vp, u32, vp]
     L.pcp_model_push_sum.argtypes = [vp, u32, vp, C.POINTER(u32)]
+    L.pcp_model_push_formula.argtypes = [vp, u32, vp, u32, vp]
+    L.pcp_model_push_formula.restype = i32
     L.pcp_model_truncate.argtypes = [vp, u32]
     L.pcp_model_n_units.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
     L.pcp_model_set_hull.argtypes = [vp, i32, i32]
@@ -110,7 +112,7 @@ def load_library():
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
-    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
+    for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
               "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
@@ -168,6 +170,26 @@ class Context:
         props = np.ascontiguousarray(props, dtype=PROP_DTYPE)
         if len(props):
             self._check(self._L.pcp_model_push_props(self._h, len(props), _np_ptr(props)))
+        self._refresh()
+
+    # ---- the push interface pcp_amd.model.push_model drives (stores with formula propagators) ------------------------------
+    def reset_model(self, n_vars: int, set_words: int = 0):
+        self._check(self._L.pcp_model_reset(self._h, n_vars, int(set_words)))
+        self.n_vars, self.set_words = int(n_vars), int(set_words)
+        self._refresh()
+
+    def push_sum(self, members) -> int:
+        mv = np.ascontiguousarray(members, np.uint32)
+        t = C.c_uint32()
+        self._check(self._L.pcp_model_push_sum(self._h, len(mv), _np_ptr(mv), C.byref(t)))
+        return t.value
+
+    def push_formula(self, nodes: np.ndarray, leaves: np.ndarray):
+        """pcp_model_push_formula: ONE unit = a tree of Conjunction / Disjunction nodes over elementary leaves."""
+        from .model import FNODE_DTYPE
+        nodes = np.ascontiguousarray(nodes, dtype=FNODE_DTYPE)
+        leaves = np.ascontiguousarray(leaves, dtype=PROP_DTYPE)
+        self._check(self._L.pcp_model_push_formula(self._h, len(nodes), _np_ptr(nodes), len(leaves), _np_ptr(leaves)))
         self._refresh()
 
     def set_hull(self, lo: int, hi: int):

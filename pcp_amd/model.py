@@ -28,8 +28,11 @@ PCP_NOVAR = 0xFFFFFFFE
 PCP_SUM = 0xC0000000
 PCP_BOUND_MAX = 0x1FFFFFFF
 
-NEQ, EQ, LT, LT3, GT3, EQ3, MUL3 = range(7)
-KIND_NAMES = ["NEQ", "EQ", "LT", "LT3", "GT3", "EQ3", "MUL3"]
+NEQ, EQ, LT, LT3, GT3, EQ3, MUL3, BOOL, NBOOL = range(9)
+KIND_NAMES = ["NEQ", "EQ", "LT", "LT3", "GT3", "EQ3", "MUL3", "BOOL", "NBOOL"]
+F_LEAF, F_AND, F_OR = 0, 1, 2  # pcp_fnode_type
+FNODE_DTYPE = np.dtype([("type", np.uint8), ("reserved", np.uint8), ("n_children", np.uint16), ("first", np.uint32)])
+assert FNODE_DTYPE.itemsize == 8
 FALSE, TRUE, UNKNOWN = 0, 1, 2
 
 # Same layout as `pcp_prop` in include/pcp_hip.h (32 bytes).
@@ -172,6 +175,109 @@ def AllEqual(vars: Sequence[View]) -> Conjunction:
     return Conjunction(fs, group_kind=2)
 
 
+# ----------------------------------------------------------------------------------------------- the reified layer (logic/)
+def Boolean(var: View) -> Elementary:
+    """logic/boolean.rs:111-140: the formula "var = 1" over a 0/1 variable (allocate it with vstore.alloc((0, 1)))."""
+    return Elementary(BOOL, (var,))
+
+
+def BooleanNeg(var: View) -> Elementary:
+    """logic/boolean_neg.rs:71-96: "var = 0"."""
+    return Elementary(NBOOL, (var,))
+
+
+@dataclass(frozen=True)
+class And:
+    """logic::Conjunction over arbitrary formulas (logic/conjunction.rs:77-119): ONE unit, lowered as a formula tree."""
+    fs: Tuple["FormulaT", ...]
+
+
+@dataclass(frozen=True)
+class Or:
+    """logic::Disjunction (logic/disjunction.rs:78-141): ONE unit; a child is propagated only when all others are disentailed."""
+    fs: Tuple["FormulaT", ...]
+
+
+FormulaT = Union[Elementary, And, Or]
+
+
+def not_(f: FormulaT) -> FormulaT:
+    """NotFormula::not (logic/ops.rs:17-19), applied when the formula is built, as the reference does."""
+    if isinstance(f, And):
+        return Or(tuple(not_(g) for g in f.fs))          # De Morgan, conjunction.rs:70-74
+    if isinstance(f, Or):
+        return And(tuple(not_(g) for g in f.fs))         # disjunction.rs:68-75
+    if isinstance(f, Conjunction):
+        return Or(tuple(not_(g) for g in f.fs))
+    k, o = f.kind, f.ops
+    if k == NEQ:
+        return XEqY(o[0], o[1])                          # x_neq_y.rs:61-63
+    if k == EQ:
+        return XNeqY(o[0], o[1])                         # x_eq_y.rs:62-64
+    if k == LT:
+        return x_geq_y(o[0], o[1])                       # x_less_y.rs:62-64
+    if k == LT3:
+        return x_geq_y_plus_z(o[0], o[1], o[2])          # x_less_y_plus_z.rs:66-72
+    if k == GT3:
+        return x_leq_y_plus_z(o[0], o[1], o[2])          # x_greater_y_plus_z.rs:66-72
+    if k == BOOL:
+        return BooleanNeg(o[0])                          # boolean.rs:74-76
+    if k == NBOOL:
+        return Boolean(o[0])                             # boolean_neg.rs:66-68
+    raise ContractViolation("not implemented")           # XEqYPlusZ / XEqYMulZ: unimplemented!() (x_eq_y_plus_z.rs:74-76)
+
+
+def implication(f: FormulaT, g: FormulaT) -> Or:
+    """logic/mod.rs:30-36 — exactly the reference's shape, Disjunction[f, g.not()]."""
+    return Or((f, not_(g)))
+
+
+def equivalence(f: FormulaT, g: FormulaT) -> And:
+    """logic/mod.rs:38-45."""
+    return And((implication(f, g), implication(g, f)))
+
+
+def lower_formula(f: FormulaT, n_vars: int, sums_out=None, max_depth: int = 8):
+    """One formula unit as (nodes, leaves) for pcp_model_push_formula: nodes[0] is the root, the children of an inner node are
+    consecutive (breadth-first layout)."""
+    nodes, leaves = [], []
+    queue = [(f, 0)]
+    nodes.append(None)
+    qi = 0
+    while qi < len(queue):
+        g, at = queue[qi]
+        qi += 1
+        depth = 0 if at == 0 else None
+        if isinstance(g, Conjunction):
+            g = And(tuple(g.fs))
+        if isinstance(g, (And, Or)):
+            if len(g.fs) == 0:
+                raise ContractViolation("a Conjunction / Disjunction needs at least one child")
+            first = len(nodes)
+            nodes[at] = (F_AND if isinstance(g, And) else F_OR, len(g.fs), first)
+            for c in g.fs:
+                nodes.append(None)
+                queue.append((c, len(nodes) - 1))
+        else:
+            nodes[at] = (F_LEAF, 0, len(leaves))
+            leaves.append(g)
+
+    def depth_of(i):
+        t, n, first = nodes[i]
+        return 1 if t == F_LEAF else 1 + max(depth_of(first + c) for c in range(n))
+    if depth_of(0) > max_depth:
+        raise ContractViolation(f"formula deeper than {max_depth} levels")
+    nd = np.zeros(len(nodes), dtype=FNODE_DTYPE)
+    for i, (t, n, first) in enumerate(nodes):
+        nd[i]["type"], nd[i]["n_children"], nd[i]["first"] = t, n, first
+    lv = _lower_rows([(e.kind, e.ops) for e in leaves], n_vars, sums_out, dedup_unit=False)
+    return nd, lv
+
+
+def is_formula_unit(u) -> bool:
+    return isinstance(u, (And, Or))
+
+
 # ----------------------------------------------------------------------------------------------- stores
 class VStore:
     """variable::Store over Interval<i32> (VStoreFD, variable/mod.rs:36): just the domains."""
@@ -249,6 +355,22 @@ class CStore:
 
     def lower(self, n_vars: int) -> np.ndarray:
         return lower_units(self.units, n_vars)
+
+    def pushes(self, n_vars: int, sums_out=None):
+        """The model as a sequence of pushes, in unit order: ("props", rows) for runs of elementary / Conjunction units,
+        ("formula", nodes, leaves) for each formula unit (And / Or trees)."""
+        out, run = [], []
+        for u in self.units:
+            if is_formula_unit(u):
+                if run:
+                    out.append(("props", lower_units(run, n_vars, sums_out=sums_out)))
+                    run = []
+                out.append(("formula",) + lower_formula(u, n_vars, sums_out))
+            else:
+                run.append(u)
+        if run:
+            out.append(("props", lower_units(run, n_vars, sums_out=sums_out)))
+        return out
 
 
 def join_distinct(vstore: VStore, cstore: CStore, vars: Sequence[View]) -> None:
@@ -330,6 +452,80 @@ def lower_units(units: Sequence[Union[Elementary, Conjunction]], n_vars: int, gi
             seen_unit |= seen
             r += 1
     return out[:r]
+
+
+def _lower_rows(rows, n_vars: int, sums_out, dedup_unit: bool = True) -> np.ndarray:
+    """pcp_prop rows of a formula's leaves (group fields unused).  A variable twice in ONE leaf is the reactor's panic; across
+    leaves it is fine (a formula's dependencies are the de-duplicated union, conjunction.rs:107-118, disjunction.rs:119-131)."""
+    out = np.zeros(len(rows), dtype=PROP_DTYPE)
+    out["var"][:] = PCP_NOVAR
+    for r, (kind, ops) in enumerate(rows):
+        out[r]["kind"] = kind
+        seen = set()
+        for k, op in enumerate(ops):
+            var, off, deps = _flat_operand(op, sums_out)
+            if abs(off) > PCP_BOUND_MAX:
+                raise ContractViolation("offset outside +-PCP_BOUND_MAX")
+            for dv in deps:
+                if not (0 <= dv < n_vars):
+                    raise ContractViolation(f"variable {dv} is not in the vstore (size {n_vars})")
+                if dv in seen:
+                    raise ContractViolation("propagator already subscribed to this variable")
+                seen.add(dv)
+            out[r]["var"][k] = var
+            out[r]["off"][k] = off
+    return out
+
+
+def push_model(target, cstore: "CStore", n_vars: int, set_words: int = 0):
+    """Send a model with formula units to `target` — an engine Context or an OracleModel: both offer reset_model / push_sum /
+    push_props / push_formula.  Sum views are registered first (their numbers are fixed by the lowering order)."""
+    sums = []
+    pushes = cstore.pushes(n_vars, sums_out=sums)
+    target.reset_model(n_vars, set_words)
+    for members in sums:
+        target.push_sum(members)
+    for p in pushes:
+        if p[0] == "props":
+            target.push_props(p[1])
+        else:
+            target.push_formula(p[1], p[2])
+    return pushes
+
+
+class Cumulative:
+    """propagators/cumulative.rs:59-114 — the decomposition of Schutt et al.: for each task j, the resources of the tasks that
+    overlap j's start must fit the capacity.  join() allocates, per ordered pair (j, i != j): a Boolean b_i, the unit
+    b_i <=> (s_i <= s_j /\\ s_j < s_i + d_i), an intermediate r = b_i * r_i (XEqYMulZ), then c >= r_j + Sum(r).  Variable and
+    propagator allocation order as in the reference (the tests pin statuses, not indices, but the order is kept)."""
+
+    def __init__(self, starts, durations, resources, capacity):
+        assert len(starts) == len(durations) == len(resources)
+        self.starts, self.durations, self.resources, self.capacity = list(starts), list(durations), list(resources), capacity
+        self.intermediate: List[List[int]] = []
+
+    def join(self, vstore: VStore, cstore: CStore) -> None:
+        tasks = len(self.starts)
+        if tasks == 1:
+            cstore.alloc(x_geq_y(self.capacity, self.resources[0]))       # c >= r[j]   (cumulative.rs:67-70)
+            return
+        for j in range(tasks):
+            resource_vars = []
+            self.intermediate.append([])
+            for i in range(tasks):
+                if i == j:
+                    continue
+                conj = And((x_leq_y(self.starts[i], self.starts[j]),                                   # s[i] <= s[j]
+                            XLessYPlusZ(self.starts[j], self.starts[i], self.durations[i])))           # s[j] < s[i] + d[i]
+                bi = vstore.alloc((0, 1))                                                                # Boolean::new (boolean.rs:38-43)
+                cstore.alloc(equivalence(Boolean(bi), conj))
+                ri = self.resources[i]
+                ri_ub = ri.value if isinstance(ri, Constant) else vstore.ub[ri.flat()[0]] + ri.flat()[1]
+                r = vstore.alloc((0, ri_ub))
+                self.intermediate[-1].append(r.idx)
+                cstore.alloc(XEqYMulZ(r, bi, ri))                                                        # r = bi * r[i]
+                resource_vars.append(r)
+            cstore.alloc(x_geq_y_plus_z(self.capacity, self.resources[j], Sum(tuple(resource_vars))))  # c >= r[j] + sum
 
 
 # ----------------------------------------------------------------------------------------------- models
