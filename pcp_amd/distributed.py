@@ -97,11 +97,7 @@ def balance(wl: Worklist, dist, device=None) -> int:
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
-    mine = torch.tensor([len(wl)], dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    lengths = [int(t.item()) for t in gathered]
-    moves = plan_moves(lengths)
+    moves = plan_moves(_gather_sizes(len(wl), dist, dev))
     ops, recv_bufs, delta = [], [], 0
     rec_words = 2 * wl.n_vars * 4 + wl.words * 8  # bytes per node record
     for src, dst, k in moves:
@@ -200,28 +196,52 @@ def parallel_search(ctx, lb0, ub0, dist, batch: int = 64, all_solutions: bool = 
 # move GPU-to-GPU — over RCCL/xGMI with backend "nccl", over gloo with CPU tensors in the tests.  Same plan, same
 # three exchange steps as above; the only host traffic is the all_gather of the stack sizes and the counters.
 # ---------------------------------------------------------------------------------------------------------------
-def balance_stacks(stack, dist) -> int:
-    """X1 + X2 on a stack object with tensors ``lb [cap,V]``, ``ub [cap,V]``, ``act [cap,W]`` and an int ``size``
-    (rows [0,size) are open nodes, the top of the stack is the end).  Senders give away their OLDEST rows (bottom of
-    the stack: closest to the root, the largest subtrees); receivers put them at the bottom too.  Returns the number
-    of rows sent (+) or received (-)."""
+def _gather_sizes(size: int, dist, dev) -> List[int]:
+    """X1: every rank's stack size — ONE all_gather and one device-to-host read."""
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([size], dtype=torch.int64, device=dev)
+    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return [int(x) for x in torch.cat(gathered).tolist()]
+
+
+def balance_stacks(stack, dist, info: Optional[dict] = None) -> int:
+    """X1 + X2 on a stack object with tensors ``lb [cap,V]``, ``ub [cap,V]``, ``act [cap,W]`` (and ``bits`` in set mode).  The open
+    nodes are either rows [0, size) (a plain stack: ``size``) or DeviceSearch's segments ``segs`` = [start, length] bottom to top.
+    Senders give away their OLDEST rows (bottom of the stack: closest to the root, the largest subtrees); receivers put them at the
+    bottom too.  ONLY THE MOVED ROWS ARE TOUCHED: a sender packs the k rows it gives into one send buffer and advances its bottom
+    segment (no shift of what stays); a receiver writes the k rows into the hole below its bottom segment (DeviceSearch starts its
+    stack an eighth into the buffer for that) and shifts only when that hole is used up.  Returns rows sent (+) or received (-);
+    ``info`` accumulates moved_rows / moved_bytes / record_bytes."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = stack.lb.device
-    if hasattr(stack, "compact"):
-        stack.compact()  # DeviceSearch keeps its open nodes as segments; the moves below work on rows [0, size)
-    mine = torch.tensor([stack.size], dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, mine)
-    moves = plan_moves([int(t.item()) for t in gathered])
-    ops, incoming, delta, give = [], [], 0, 0
+    segmented = hasattr(stack, "segs")
+    segs = stack.segs if segmented else ([[0, int(stack.size)]] if stack.size else [])
+    size = sum(l for _, l in segs)
+    moves = plan_moves(_gather_sizes(size, dist, dev))
     # implicit-active stacks carry no `active` rows; set-mode stacks carry the sets as well
     rows = tuple(stack._rows()) if hasattr(stack, "_rows") else tuple(t for t in (stack.lb, stack.ub, stack.act) if t is not None)
+    cap = int(stack.lb.shape[0])
+    rec_bytes = sum(int(np.prod(t.shape[1:])) * t.element_size() for t in rows)
+    ops, incoming, delta = [], [], 0
     for src, dst, k in moves:
         if rank == src:
+            # the k oldest rows: from the bottom segments, packed into one buffer per tensor
+            pieces, need = [], k
+            while need:
+                s0, l0 = segs[0]
+                take = min(need, l0)
+                pieces.append((s0, take))
+                need -= take
+                if take == l0:
+                    segs.pop(0)
+                else:
+                    segs[0] = [s0 + take, l0 - take]
             for t in rows:
-                ops.append(dist.P2POp(dist.isend, t[give:give + k].contiguous(), dst))
-            give += k
+                buf = t[pieces[0][0]:pieces[0][0] + pieces[0][1]].contiguous() if len(pieces) == 1 else torch.cat([t[a:a + n] for a, n in pieces])
+                ops.append(dist.P2POp(dist.isend, buf, dst))
             delta += k
         elif rank == dst:
             bufs = [torch.empty((k,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev) for t in rows]
@@ -232,45 +252,92 @@ def balance_stacks(stack, dist) -> int:
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    if give:  # drop the rows given away: shift the rest down
-        keep = stack.size - give
-        for t in rows:
-            t[:keep] = t[give:stack.size].clone()
-        stack.size = keep
-    for bufs in incoming:  # insert received rows at the bottom
+    for bufs in incoming:  # received rows go below the bottom segment
         k = bufs[0].shape[0]
-        if stack.size + k > stack.lb.shape[0]:
+        cur = sum(l for _, l in segs)
+        if cur + k > cap:
             raise RuntimeError("open-node stack overflow while receiving work; raise `capacity`")
+        if not segs:
+            at = min(cap // 8, cap - k)
+            segs.append([at, 0])
+        if segs[0][0] < k:
+            # the hole below the stack is used up: move the stack up once, leaving half of the free rows below it
+            gap = max(k, (cap - cur) // 2)
+            for t in rows:
+                packed = torch.cat([t[a:a + n] for a, n in segs]) if len(segs) > 1 else t[segs[0][0]:segs[0][0] + segs[0][1]].clone()
+                t[gap:gap + cur] = packed
+            segs[:] = [[gap, cur]]
+        s0, l0 = segs[0]
         for t, b in zip(rows, bufs):
-            t[k:stack.size + k] = t[:stack.size].clone()
-            t[:k] = b
-        stack.size += k
+            t[s0 - k:s0] = b
+        segs[0] = [s0 - k, l0 + k]
+    if info is not None:
+        info["moved_rows"] = info.get("moved_rows", 0) + max(delta, 0)
+        info["moved_bytes"] = info.get("moved_bytes", 0) + max(delta, 0) * rec_bytes
+        info["record_bytes"] = rec_bytes
+    if segmented:
+        stack.segs = [sg for sg in segs if sg[1] > 0]
+    else:
+        # a plain stack keeps its open nodes in rows [0, size)
+        pos = 0
+        for s0, l0 in segs:
+            if l0 and s0 != pos:
+                for t in rows:
+                    t[pos:pos + l0] = t[s0:s0 + l0].clone()
+            pos += l0
+        stack.size = pos
     return delta
 
 
-def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None,
-                           base: int = 0):
-    """Sharded subtree search with device-resident stacks: ``search`` is a pcp_amd.search_device.DeviceSearch of this
-    rank's GPU.  Rank 0 starts with the root; every ``rounds_per_exchange`` rounds the stacks are balanced GPU-to-GPU
-    (X1+X2) and termination / totals agreed on (X3).  Returns the global (nodes, solutions, failures, filter steps)."""
-    import torch
-    rank = dist.get_rank()
-    dev = search.lb.device
+def seed_frontier(search, lb0, ub0, dist, target: int, all_solutions: bool = True, base: int = 0) -> None:
+    """"the frontier is first expanded breadth-first to >= 8*64 open nodes, then sharded".  Every rank runs the SAME
+    expansion of the root (no communication: it is a few rounds of at most `batch` nodes) and keeps the open nodes r, r + world,
+    r + 2 world, ...; the nodes of the expansion are counted once, on rank 0.  No GPU waits for the first exchange."""
+    world, rank = dist.get_world_size(), dist.get_rank()
     search.reset(lb0, ub0, base) if getattr(search, "bits", None) is not None else search.reset(lb0, ub0)
-    if rank != 0:
-        search.size = 0
+    while 0 < search.size < target:
+        if search.advance(all_solutions=all_solutions, max_rounds=1, keep_solutions=0):
+            break
+    if world == 1:
+        return
+    found = (not all_solutions) and search.stats.num_solution > 0
+    if rank != 0:  # the expansion's nodes, failures and solutions are rank 0's to report
+        search.stats = type(search.stats)()
+        search.ctx.stats_reset(search._stream())
+    if found:
+        search.segs = []
+        return
+    search.compact()
+    n = search.size
+    import torch
+    idx = torch.arange(rank, n, world, device=search.lb.device)
+    for t in search._rows():
+        t[:idx.numel()] = t[idx]
+    search.segs = [[0, int(idx.numel())]] if idx.numel() else []
+
+
+def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None,
+                           base: int = 0, seed_nodes: int = 8 * 64):
+    """Sharded subtree search with device-resident stacks: ``search`` is a pcp_amd.search_device.DeviceSearch of this
+    rank's GPU.  The root is expanded to a frontier that is dealt out over the ranks (seed_frontier); every
+    ``rounds_per_exchange`` rounds the stacks are balanced GPU-to-GPU (X1+X2) and termination / totals agreed on (X3).
+    Returns the global (nodes, solutions, failures, filter steps, moved records)."""
     import time
+    import torch
+    dev = search.lb.device
+    world = dist.get_world_size()
+    seed_frontier(search, lb0, ub0, dist, min(seed_nodes, search.batch * world) if world > 1 else 0, all_solutions=all_solutions, base=base)
     moved = 0
     exchange_s, exchanges = 0.0, 0
-    world = dist.get_world_size()
+    xinfo = {}
     while True:
-        if search.size > 0:
+        if search.size > 0 and (all_solutions or search.stats.num_solution == 0):
             # a rank's share of what is left of the node budget (the budget is global; it is checked at every exchange)
             left = max(1, (node_limit - search.stats.num_nodes * world) // world) if node_limit else 0
             search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0,
                            node_limit=(search.stats.num_nodes + left) if node_limit else 0)
         t0 = time.perf_counter()
-        moved += max(balance_stacks(search, dist), 0)
+        moved += max(balance_stacks(search, dist, xinfo), 0)
         st = search.stats
         flags = torch.tensor([search.size, st.num_solution, st.num_nodes], dtype=torch.int64, device=dev)
         dist.all_reduce(flags, op=dist.ReduceOp.SUM)
@@ -280,7 +347,7 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
         if open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit):
             break
     if info is not None:
-        info.update(exchange_s=exchange_s, exchanges=exchanges)
+        info.update(exchange_s=exchange_s, exchanges=exchanges, moved_bytes=xinfo.get("moved_bytes", 0), record_bytes=xinfo.get("record_bytes", 0))
     st = search.stats
     tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, moved], dtype=torch.int64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)

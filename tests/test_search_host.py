@@ -159,7 +159,7 @@ def _device_worker(rank, world, port, n, batch, implicit, q):
         ds = DeviceSearch(ctx, batch=batch, capacity=4096, device=torch.device("cpu"), implicit=implicit)
         info = {}
         tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, info=info)
-        q.put((rank, tot, ds.stats.num_nodes, info["exchanges"]))
+        q.put((rank, tot, ds.stats.num_nodes, info["exchanges"], info["moved_bytes"], info["record_bytes"], info["exchange_s"]))
     finally:
         dist.destroy_process_group()
 
@@ -179,9 +179,38 @@ def test_two_rank_device_search_gloo(implicit):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, tot0, n0, x0), (r1, tot1, n1, x1) = res
+    (r0, tot0, n0, x0, mb0, rb0, _), (r1, tot1, n1, x1, mb1, rb1, _) = res
     assert tot0 == tot1 and tot0[:3] == (779, 92, 298)   # nodes, solutions, failures of the reference's tree (all_solution.rs:70)
     assert tot0[4] > 0 and n0 > 0 and n1 > 0 and n0 + n1 == 779 and x0 == x1 > 1
+    assert rb0 == rb1 == 8 * 8 + (0 if implicit else 8 * ((3 * 28 + 63) // 64)) and mb0 + mb1 == tot0[4] * rb0  # only whole records moved
+
+
+@pytest.mark.parametrize("n,batch", [(8, 4), (9, 8)])
+def test_four_rank_device_search_gloo(n, batch):
+    """world_size 4, implicit nodes: the frontier is dealt out after a replicated expansion (seed_frontier), the subtrees are of very
+    different sizes so work keeps moving; the union is exactly the reference's tree, every rank propagates nodes, and the bytes moved
+    are the moved records times the record size (8 bytes per variable: nothing but the rows given away is touched)."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctxm.Process(target=_device_worker, args=(r, world, port, n, batch, True, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ss, _, _, _ = orc.OracleModel(n, M.nqueens_props(n)).search(np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True)
+    tots = {r[1] for r in res}
+    assert len(tots) == 1
+    tot = res[0][1]
+    assert tot[:3] == (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
+    assert sum(r[2] for r in res) == ss["num_nodes"] and all(r[2] > 0 for r in res)
+    assert tot[4] > 0 and sum(r[4] for r in res) == tot[4] * res[0][5] and res[0][5] == 8 * n
+    share = max(r[6] for r in res)
+    print(f"exchange seconds (max over ranks) {share:.3f} over {res[0][3]} exchanges, {tot[4]} records moved")
 
 
 def _stack_worker(rank, world, port, q):
