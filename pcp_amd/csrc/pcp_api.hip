@@ -97,6 +97,7 @@ struct pcp_ctx {
   int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
+  int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
 
@@ -801,6 +802,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "neq_dfs") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_dfs must be 0 or 1");
+    c->opt_neq_dfs = value;
   } else if (k == "neq_debug") {
     c->opt_neq_debug = value;
   } else if (k == "neq_block") {
@@ -1117,6 +1121,32 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   const int64_t keep_path = c->opt_force_path;
   HIP_TRY(c, hipSetDevice(c->device));
   { const int32_t rcf = finalize_model(c); if (rcf) return rcf; }
+  if (!keep_path && c->neq_model && c->opt_neq_path && c->opt_neq_dfs) {
+    // an all-XNeqY model: the whole loop — pop, propagate, count, branch — runs in ONE workgroup, n_steps nodes per launch
+    // (neqfix_kernel<.., DFS>); a node is the lists of its assigned variables, there is no sweep to share out over the chip
+    const uint32_t S = c->n_slots, V = c->n_vars;
+    const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
+    const bool packed = hull_fits16 && c->consts_fit16 && c->opt_packed;
+    const size_t lds = lds_bytes_neq(S, V, 1, packed);
+    if (lds && lds <= c->lds_max && n_steps) {
+      NeqArgs a;
+      memset(&a, 0, sizeof(a));
+      a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
+      a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
+      a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
+      a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
+      a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1;
+      a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
+      a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
+      a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
+      LaunchPlan plan;
+      plan.grid = 1; plan.block = 512; plan.lds_bytes = lds;
+      c->last_plan = pcp_plan{1u, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, 1u, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
+      c->ev_valid = false;
+      HIP_TRY(c, launch_neqfix(a, plan, reinterpret_cast<hipStream_t>(hip_stream)));
+      return PCP_OK;
+    }
+  }
   // one node per step: the team geometry unless the caller forced a path — or the model takes the assignment-driven kernel, which
   // has no sweep to share out (a node is one workgroup: its assigned variables' lists)
   if (!keep_path && !(c->neq_model && c->opt_neq_path)) c->opt_force_path = 2;

@@ -16,8 +16,18 @@ struct NeqArgs {
   uint32_t packed;              // 1 = 16-bit (-lb, ub) cells (declared hull within +-kPackedMax), 0 = int2 cells
   uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL
-  const uint32_t* sp_ptr;       // device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
+  const uint32_t* sp_ptr;       // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
   const uint32_t* stop_ptr;
+  struct {                      // n_steps > 0: the search loop itself runs in ONE workgroup (grid 1, nodes_per_block 1): pcp_dfs_device
+    uint32_t* sp;               //   lb_in/ub_in = lb_out/ub_out = the stack's rows [capacity][n_vars]; status [capacity]
+    uint32_t* stop;
+    unsigned long long* counters;  // nodes, solutions, failed nodes, error, internal (pcp_hip.h)
+    int32_t* first_solution;
+    uint32_t capacity;
+    uint32_t n_steps;
+    uint32_t stop_on_solution;
+    unsigned long long node_limit;
+  } dfs;
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;

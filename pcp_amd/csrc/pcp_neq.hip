@@ -196,11 +196,19 @@ template <> struct TileDomOf<true> { using type = TileDom16; };
 
 }  // namespace
 
-template <bool PACKED, bool PAY4>
-__global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
+// DFS = true: ONE workgroup runs the reference's search loop itself (pcp_dfs_device) — OneSolution / AllSolution over
+// Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>> on a VectorStack (search/mod.rs:45-52, one_solution.rs:92-105),
+// under StopNode (stop_node.rs:47-62): up to a.dfs.n_steps nodes per launch, each popped from the device stack, propagated, counted
+// and branched in place (the right child x > v over the parent's row, the left child x <= v on top: left first, one_solution.rs:46-51).
+// The left child is the next node and its domains are already in LDS — the parent's fixpoint with one bound moved — so it is neither
+// staged again nor swept again: the only variable whose lists must run is the one branched on (Store::react's argument: at the
+// parent's fixpoint every propagator is a no-op until one of its variables changes).  A node popped from the stack is staged from
+// global memory and swept in full, like any node handed in by a caller.
+template <bool PACKED, bool PAY4, bool DFS>
+__global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
-  if (a.sp_ptr) {  // device-side DFS (pcp_dfs_device): the node on top of the stack
+  if (!DFS && a.sp_ptr) {  // host-stepped device-side DFS: the node on top of the stack
     const uint32_t sp = *a.sp_ptr;
     if (sp == 0 || *a.stop_ptr) return;
     const size_t off = (size_t)(sp - 1) * a.m.n_vars;
@@ -223,19 +231,36 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
   uint4* const list = reinterpret_cast<uint4*>(smem + cv.list);  // (v | M << 16, list offset, degree, windows w0 | w1 << 16)
   Win* const win = reinterpret_cast<Win*>(smem + cv.win);
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
-  const uint32_t node0 = blockIdx.x * B, nb = min(B, a.n_nodes - node0);
+  const uint32_t node0 = DFS ? 0u : blockIdx.x * B, nb = DFS ? 1u : min(B, a.n_nodes - node0);
   auto dom_of = [&](uint32_t b, Ctr* c) { return TDom{dom + b, B, sh, chg + (size_t)b * Wv, misc, 1u << b, c}; };
 
   // ---- phase 0: stage the domains (16-byte row loads), find the assigned variables ------------------------------------------
   // the lists' offsets: an LDS copy (the build pass of a round then has no global load in its chain)
   uint32_t* const adjo = reinterpret_cast<uint32_t*>(smem + cv.adj);
   for (uint32_t v = tid; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
+  // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
+  uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
+  const int32_t* const stack_lb = a.lb_in;
+  unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;  // DFS: the search counters, replicated in every thread
+  uint32_t c_err = 0;
+  if constexpr (DFS) { dfs_sp = *a.dfs.sp; dfs_stop = *a.dfs.stop; c_nodes = a.dfs.counters[0]; c_sols = a.dfs.counters[1]; c_fail = a.dfs.counters[2]; }
+  const int lim = PACKED ? kPackedMax : kBoundMax;
+  for (uint32_t dfs_it = 0;; ++dfs_it) {
+  bool resume = false;
+  if constexpr (DFS) {
+    if (dfs_sp == 0 || dfs_stop || dfs_it >= a.dfs.n_steps) break;
+    const size_t off = (size_t)(dfs_sp - 1) * V;
+    a.lb_in = stack_lb + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + (dfs_sp - 1);
+    resume = dfs_resume_var != 0xFFFFFFFFu;
+  }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   __syncthreads();
-  const int lim = PACKED ? kPackedMax : kBoundMax;
-  const bool vec = (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0;
-  {
+  // DFS rows may have been written by this very workgroup a moment ago: they are read past the L1 (relaxed agent-scope loads)
+  const bool vec = !DFS && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0;
+  if (resume) {
+    if (tid == 0) chg[dfs_resume_var >> 5] = 1u << (dfs_resume_var & 31u);  // the left child: only the variable branched on has changed
+  } else {
     uint32_t badm = 0, oobm = 0;
     auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) {
       uint32_t nib = 0;
@@ -285,7 +310,14 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
         int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if ((uint32_t)i < cnt) { l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i]; }
+          if ((uint32_t)i < cnt) {
+            if constexpr (DFS) {
+              l[i] = __hip_atomic_load(a.lb_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              u[i] = __hip_atomic_load(a.ub_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+              l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i];
+            }
+          }
         put(b, v0, l, u, cnt);
       }
     }
@@ -679,6 +711,77 @@ __global__ void __launch_bounds__(1024) neqfix_kernel(const NeqArgs a_in) {
     const uint32_t nf = __popc(misc[N_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)));
     if (nf && !(a.debug & 8u)) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
   }
+  if constexpr (!DFS) {
+    break;
+  } else {
+    // ---- the search step on the node just propagated (what dfs_step_kernel does for the generic kernels) ---------------------
+    __syncthreads();
+    const bool failed = (misc[N_FAIL] & 1u) != 0, refused = (misc[N_OOB] & 1u) != 0, open = (misc[N_UNK] & 1u) != 0;
+    dfs_resume_var = 0xFFFFFFFFu;
+    uint32_t new_sp = dfs_sp - 1;
+    if (refused) {
+      c_err = 2; dfs_stop = 1;  // a node the engine refused (PCP_STATUS_HULL)
+      ++c_nodes;
+    } else if (failed) {
+      ++c_nodes; ++c_fail;
+    } else if (!open) {  // True: a solution (monitor.rs:19-68); the first one is kept
+      ++c_nodes;
+      if (c_sols == 0 && a.dfs.first_solution)
+        for (uint32_t v = tid; v < V; v += nth) a.dfs.first_solution[v] = cell_bounds<PACKED>(dom[rowof(v)]).x;
+      ++c_sols;
+      if (a.dfs.stop_on_solution) dfs_stop = 1;
+    } else {
+      // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (brancher.rs:52-71): the first variable of minimal size > 1
+      unsigned long long key = ~0ull;
+      for (uint32_t v = tid; v < V; v += nth) {
+        const int2 d = cell_bounds<PACKED>(dom[rowof(v)]);
+        const unsigned long long size = (unsigned long long)((long long)d.y - (long long)d.x + 1);
+        if (size > 1) key = min(key, (size << 32) | v);
+      }
+      for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+      unsigned long long* best = reinterpret_cast<unsigned long long*>(list);  // (the round list is idle here)
+      if (lane == 0) best[wv] = key;
+      __syncthreads();
+      key = best[0];
+      for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
+      __syncthreads();
+      if (key == ~0ull) {
+        c_err = 3; dfs_stop = 1;  // Unknown, yet nothing to branch on: the reference panics (first_smallest_var.rs:36)
+        new_sp = dfs_sp;
+      } else if (dfs_sp >= a.dfs.capacity) {
+        c_err = 1; dfs_stop = 1;  // stack overflow: the node stays on the stack, uncounted
+        new_sp = dfs_sp;
+      } else {
+        ++c_nodes;
+        const uint32_t var = (uint32_t)key;
+        const int2 d = cell_bounds<PACKED>(dom[rowof(var)]);
+        const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27: `/` truncates toward zero)
+        // the right child x > val takes the parent's row (which holds the fixpoint: written back above if it changed)
+        if (tid == 0) a.lb_out[var] = max(d.x, val + 1);
+        // the left child x <= val: one bound of one LDS cell, and its row on top of the stack
+        if (tid == 0) {
+          if constexpr (PACKED) dom[rowof(var)] = pack16(d.x, min(d.y, val)); else dom[rowof(var)] = make_int2(-d.x, min(d.y, val));
+        }
+        __syncthreads();
+        int32_t* l0 = a.lb_out + V;
+        int32_t* u0 = a.ub_out + V;
+        for (uint32_t v = tid; v < V; v += nth) { const int2 c = cell_bounds<PACKED>(dom[rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
+        new_sp = dfs_sp + 1;
+        dfs_resume_var = var;
+      }
+    }
+    if (a.dfs.node_limit && c_nodes >= a.dfs.node_limit) dfs_stop = 1;  // StopNode (stop_node.rs:57-62)
+    dfs_sp = new_sp;
+    __syncthreads();
+  }
+  }  // the DFS loop (one pass otherwise)
+  if constexpr (DFS) {
+    if (tid == 0) {
+      *a.dfs.sp = dfs_sp; *a.dfs.stop = dfs_stop;
+      a.dfs.counters[0] = c_nodes; a.dfs.counters[1] = c_sols; a.dfs.counters[2] = c_fail;
+      if (c_err) a.dfs.counters[3] = c_err;
+    }
+  }
 }
 
 size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed) {
@@ -686,20 +789,28 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4>
+template <bool PACKED, bool PAY4, bool DFS>
 static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
+}
+template <bool DFS>
+static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS>(a, p, stream) : launch_neq_k<false, true, DFS>(a, p, stream);
+  return a.packed ? launch_neq_k<true, false, DFS>(a, p, stream) : launch_neq_k<false, false, DFS>(a, p, stream);
 }
 
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.nodes_per_block == 0 || a.nodes_per_block > 16 || a.m.n_slots >= 65536u || !a.m.adjp) return hipErrorInvalidValue;
-  if (a.adjp4) return a.packed ? launch_neq_k<true, true>(a, p, stream) : launch_neq_k<false, true>(a, p, stream);
-  return a.packed ? launch_neq_k<true, false>(a, p, stream) : launch_neq_k<false, false>(a, p, stream);
+  if (a.dfs.n_steps) {
+    if (a.nodes_per_block != 1 || p.grid != 1 || !a.dfs.sp || !a.dfs.stop || !a.dfs.counters) return hipErrorInvalidValue;
+    return launch_neq_d<true>(a, p, stream);
+  }
+  return launch_neq_d<false>(a, p, stream);
 }
 
 }  // namespace pcp
