@@ -97,6 +97,7 @@ struct pcp_ctx {
   int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
+  int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
@@ -514,20 +515,21 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   const uint32_t S = c->n_slots, V = c->n_vars, P = (uint32_t)c->props.size();
   const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
   const bool packed = hull_fits16 && c->consts_fit16 && c->opt_packed;
-  // nodes per workgroup: enough tiles for two resident workgroups per CU, as large as that allows (a round's list walk decodes an
-  // entry once for all the nodes of the tile in which the variable changed)
-  uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, n_nodes / (2u * (uint32_t)c->num_cu));
+  // nodes per workgroup: a tile per CU, as large as that allows — a round's list walk decodes an entry once for all the nodes of the
+  // tile in which the variable changed, and deep tiles (many assigned variables, shared by neighbouring nodes) live on that
+  // (measured, 4096 nodes 3000 nodes down a dive: 16-node tiles 0.64 ms, 8-node tiles 0.83 ms)
+  uint32_t want = c->opt_nodes_per_block ? (uint32_t)c->opt_nodes_per_block : std::max<uint32_t>(1, n_nodes / (uint32_t)c->num_cu);
   want = std::min<uint32_t>(want, 16);
   uint32_t B = 0;
   for (uint32_t t : {16u, 8u, 4u, 2u, 1u}) {
     if (t > want) continue;
-    const size_t need = lds_bytes_neq(S, V, t, packed);
+    const size_t need = lds_bytes_neq(S, V, t, packed, (uint32_t)c->opt_neq_wgs);
     if (need && need <= c->lds_max) { B = t; break; }
   }
   if (!B) return 1;
   LaunchPlan plan;
   plan.grid = (n_nodes + B - 1) / B;
-  plan.lds_bytes = lds_bytes_neq(S, V, B, packed);
+  plan.lds_bytes = lds_bytes_neq(S, V, B, packed, (uint32_t)c->opt_neq_wgs);
   // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
   // staging overlaps the other's list walk
   plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
@@ -540,6 +542,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u;
   a.violation = c->d_retry + 1;
   a.debug = (uint32_t)c->opt_neq_debug;
+  a.lds_wgs = (uint32_t)c->opt_neq_wgs;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
@@ -802,6 +805,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "neq_wgs") {
+    if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
+    c->opt_neq_wgs = value;
   } else if (k == "neq_dfs") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_dfs must be 0 or 1");
     c->opt_neq_dfs = value;
@@ -1127,7 +1133,7 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
     const uint32_t S = c->n_slots, V = c->n_vars;
     const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
     const bool packed = hull_fits16 && c->consts_fit16 && c->opt_packed;
-    const size_t lds = lds_bytes_neq(S, V, 1, packed);
+    const size_t lds = lds_bytes_neq(S, V, 1, packed, 2);
     if (lds && lds <= c->lds_max && n_steps) {
       NeqArgs a;
       memset(&a, 0, sizeof(a));
@@ -1135,7 +1141,7 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
       a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
       a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
       a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
-      a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1;
+      a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.lds_wgs = 2;
       a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
       a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
       a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;

@@ -14,6 +14,7 @@ struct NeqArgs {
   uint32_t n_nodes;
   uint32_t nodes_per_block;     // B <= 16 nodes per workgroup, domains in LDS node-major
   uint32_t packed;              // 1 = 16-bit (-lb, ub) cells (declared hull within +-kPackedMax), 0 = int2 cells
+  uint32_t lds_wgs;             // workgroups meant to share a CU's LDS (sizes the jump-window area; must match lds_bytes_neq's argument)
   uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL
   const uint32_t* sp_ptr;       // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
@@ -35,7 +36,7 @@ struct NeqArgs {
   uint8_t* status;
   pcp_stats* stats;
 };
-size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed);
+size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, uint32_t wgs = 2);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node

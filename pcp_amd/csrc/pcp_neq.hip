@@ -49,7 +49,7 @@ namespace pcp {
 namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
-       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_WORDS = 18 };
+       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19 };
 
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
 constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
@@ -71,7 +71,7 @@ struct NeqCarve {
 };
 // cell index of (slot, node 0): rows of B cells, four cells of padding after every 2^sh rows (2^sh rows of packed cells = 256 bytes)
 __host__ __device__ inline uint32_t neq_row(uint32_t slot, uint32_t B, uint32_t sh) { return slot * B + ((slot >> sh) << 2); }
-__host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B, bool packed) {
+__host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B, bool packed, uint32_t wgs = 2) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   NeqCarve c;
   c.sh = B >= 16 ? 2u : B >= 8 ? 3u : B >= 4 ? 4u : B >= 2 ? 5u : 6u;
@@ -82,8 +82,11 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   c.list = o; o = up(o + (size_t)kListCap * 16);
   c.adj = o; o = up(o + ((size_t)V + 1) * 4);
   c.misc = o; o = up(o + 32 * 4);
-  // the windows take what is left of HALF a CU's LDS (two workgroups per CU), of all of it when the tile needs more than half
-  const size_t budget = o <= 80 * 1024 ? 80 * 1024 : 160 * 1024;
+  // the windows take what is left of the CU's LDS divided by the workgroups that are to share it (two by default; one when the
+  // tile needs more than its share)
+  // (256 bytes short of an even share: __syncthreads_or and friends take a few bytes of static LDS on top of the dynamic carve)
+  const size_t share = (((size_t)160 * 1024 / (wgs ? wgs : 2)) & ~(size_t)15) - 256;
+  const size_t budget = o <= share ? share : 160 * 1024;
   c.wcap = (uint32_t)std::min<size_t>(kWinCap, o < budget ? (budget - o) / sizeof(Win) : 0);
   c.win = o; o = up(o + (size_t)c.wcap * sizeof(Win));
   c.total = o;
@@ -223,7 +226,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = a.nodes_per_block;
-  const NeqCarve cv = neq_carve(S, V, B, PACKED);
+  const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
   const uint32_t sh = cv.sh, wcap = cv.wcap;
   auto rowof = [&](uint32_t slot) { return neq_row(slot, B, sh); };  // index of node 0's cell of a slot
   Cell* const dom = reinterpret_cast<Cell*>(smem + cv.dom);
@@ -237,7 +240,16 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   // ---- phase 0: stage the domains (16-byte row loads), find the assigned variables ------------------------------------------
   // the lists' offsets: an LDS copy (the build pass of a round then has no global load in its chain)
   uint32_t* const adjo = reinterpret_cast<uint32_t*>(smem + cv.adj);
-  for (uint32_t v = tid; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
+  // (the first four offsets per thread are only LOADED here and stored behind the staging loads below: one memory round trip
+  // for both instead of two in a row)
+  const bool ptime = (a.debug & 32u) != 0;  // profiling: s_memtime ticks per phase, summed over workgroups into the counters
+  const uint64_t pt0 = ptime ? __builtin_amdgcn_s_memtime() : 0;
+  uint64_t pt1 = 0, pt2 = 0, pt3 = 0;
+  uint32_t adj_pre[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; adj_pre[j] = a.m.adj_off[min(v, V)]; }
+  for (uint32_t v = tid + 4 * nth; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
+  bool adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
   const int32_t* const stack_lb = a.lb_in;
@@ -296,6 +308,11 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
           L[j] = reinterpret_cast<const int4*>(a.lb_in + row)[qq[j]];
           U[j] = reinterpret_cast<const int4*>(a.ub_in + row)[qq[j]];
         }
+        if (!adj_stored) {
+          adj_stored = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+        }
 #pragma unroll
         for (int j = 0; j < UF; ++j) {
           if (t0 + j * nth >= tasks) break;
@@ -330,7 +347,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (badm) atomicOr(&misc[N_FAIL], badm);
     if (oobm) atomicOr(&misc[N_OOB], oobm);
   }
+  if (!adj_stored) {
+    adj_stored = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+  }
   __syncthreads();
+  if (ptime) pt1 = __builtin_amdgcn_s_memtime();
   if (misc[N_OOB] && tid == 0) atomicMax(a.violation, 1u);  // sticky: reported by pcp_stats_read
 
   // ---- rounds: round 0 = the lists of the assigned variables (the sweep), round r = the lists of the changed variables ------
@@ -341,27 +364,36 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
+    const uint32_t narrow_before = ctr.narrow;
     // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
     // here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
     // marks and are listed by the next round.
+    // One WAVEFRONT per mask word, lane b = node b: a ballot per bit gives the node mask of a variable directly (one thread per
+    // word read the B words of every bit one after the other: a chain of dependent LDS reads that was most of a shallow tile's
+    // round).
     {
       uint32_t rm = 0;
-      for (uint32_t w = tid; w < Wv; w += nth) {
-        uint32_t uni = 0;
-        for (uint32_t b = 0; b < nb; ++b) {
-          if ((inert >> b) & 1u) chg[b * Wv + w] = 0;  // a failed or refused node is inert
-          else uni |= chg[b * Wv + w];
+      for (uint32_t w = wv; w < Wv; w += nwv) {
+        uint32_t x = 0;
+        if (lane < nb) {
+          x = chg[lane * Wv + w];
+          if ((inert >> lane) & 1u) { if (x) chg[lane * Wv + w] = 0; x = 0; }  // a failed or refused node is inert
         }
-        if (!uni) continue;
-        const uint32_t pos0 = atomicAdd(&misc[m_count], (uint32_t)__popc(uni));
-        uint32_t bits = uni, pos = pos0, taken = 0;
-        while (bits && pos < kListCap) {
-          const uint32_t i = __builtin_ctz(bits);
-          bits &= bits - 1;
+        if (__ballot(x != 0) == 0) continue;
+        uint32_t taken = 0;
+        for (uint32_t i = 0; i < 32; ++i) {
+          const uint32_t M = (uint32_t)__ballot((x >> i) & 1u);  // (lanes >= nb hold 0)
+          if (!M) continue;
+          // lane 0 emits the entry (wave-uniform values: every lane computes them, one writes)
+          uint32_t pos = 0;
+          if (lane == 0) pos = atomicAdd(&misc[m_count], 1u);
+          pos = __builtin_amdgcn_readfirstlane(pos);
+          if (pos >= kListCap) {  // full: this variable and the rest wait for the next round
+            if (lane == 0) { atomicSub(&misc[m_count], 1u); misc[N_MORE] = round + 1; }
+            break;
+          }
           taken |= 1u << i;
           const uint32_t v = (w << 5) + i;
-          uint32_t M = 0;
-          for (uint32_t b = 0; b < nb; ++b) M |= ((chg[b * Wv + w] >> i) & 1u) << b;
           const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
           // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
           uint32_t wsel = kNoWin | (kNoWin << 16);
@@ -371,20 +403,24 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
               const uint32_t b = (uint32_t)__builtin_ctz(m);
               const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
               if (d.x >= d.y) continue;
-              const uint32_t wi = atomicAdd(&misc[m_win], 1u);
+              uint32_t wi = 0;
+              if (lane == 0) wi = atomicAdd(&misc[m_win], 1u);
+              wi = __builtin_amdgcn_readfirstlane(wi);
               if (wi >= wcap) continue;
-              Win nw;
-              nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
-              win[wi] = nw;
+              if (lane == 0) {
+                Win nw;
+                nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
+                win[wi] = nw;
+              }
               wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
             }
           }
-          list[pos++] = make_uint4(v | (M << 16), o0, dg, wsel);
+          if (lane == 0) list[pos] = make_uint4(v | (M << 16), o0, dg, wsel);
           rm |= M;
         }
-        for (uint32_t b = 0; b < nb; ++b) chg[b * Wv + w] &= ~taken;
+        if (lane < nb && (x & taken)) chg[lane * Wv + w] = x & ~taken;
       }
-      if (rm) atomicOr(&misc[m_rmask], rm);
+      if (rm && lane == 0) atomicOr(&misc[m_rmask], rm);
     }
     __syncthreads();
     const uint32_t total = min(misc[m_count], kListCap);
@@ -587,7 +623,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       if (round == 0) ev0 += my_ev;
       ctr.ev += my_ev;
     }
-    __syncthreads();
+    // (the barrier also answers "did this round narrow anything?": if not — the usual case of a shallow tile's sweep round — no
+    // variable is marked and the next round's list pass and barrier are skipped)
+    const bool narrowed = __syncthreads_or(ctr.narrow != narrow_before) != 0;
+    if (!narrowed && !nwin && misc[N_MORE] != round + 1) break;
     // (c) the jumps: each window's bound moves to the first value no assigned neighbour forbids
     if (nwin) {
       for (uint32_t wi = tid; wi < nwin; wi += nth) {
@@ -619,6 +658,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
   }
 
+  if (ptime) pt2 = __builtin_amdgcn_s_memtime();
   // ---- status: is any record NOT entailed under the final domains? (store.rs:250-256) ------------------------
   // Records of two assigned variables are entailed at a fixpoint that did not fail (two different values: disjoint), so only the
   // lists of unassigned variables can hold an open record; x != y + d is entailed iff the intervals are disjoint
@@ -657,6 +697,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   __syncthreads();
+  if (ptime) pt3 = __builtin_amdgcn_s_memtime();
   {
     const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
     const uint32_t dirty = misc[N_DIRTY], refused = misc[N_OOB];
@@ -706,10 +747,16 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[N_EV]), sfu = *reinterpret_cast<unsigned long long*>(&misc[N_FULL]);
     if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
     if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
-    if (!(a.debug & 8u)) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
+    if (ptime) {
+      atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(pt1 - pt0));        // staging
+      atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)(pt2 - pt1));  // rounds
+      atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(pt3 - pt2));         // status scan
+      atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)(__builtin_amdgcn_s_memtime() - pt3));  // write-back, counters
+    }
+    if (!(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
     atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[N_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)));
-    if (nf && !(a.debug & 8u)) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    if (nf && !(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
   }
   if constexpr (!DFS) {
     break;
@@ -784,8 +831,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   }
 }
 
-size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed) {
-  const NeqCarve c = neq_carve(n_slots, n_vars, nodes_per_block, packed);
+size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, uint32_t wgs) {
+  const NeqCarve c = neq_carve(n_slots, n_vars, nodes_per_block, packed, wgs);
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 

@@ -24,7 +24,7 @@ for d in (500, 3000):
         batches[f"deep{d}"] = (lb, ub)
 
 def timeit(lb, ub, opts, reps=5):
-    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, **opts}.items():
+    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, "neq_wgs": 2, **opts}.items():
         ctx.set_option(k, v)
     N = lb.shape[0]
     st = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -35,6 +35,14 @@ def timeit(lb, ub, opts, reps=5):
         ctx.propagate_device(N, l, u, l, u, None, None, st)
         if i: ms.append(ctx.last_kernel_ms())
     pl = ctx.last_plan()
+    if opts.get("neq_debug", 0) & 32:
+        ctx.stats_reset()
+        l, u = lb.clone(), ub.clone()
+        ctx.propagate_device(N, l, u, l, u, None, None, st)
+        torch.cuda.synchronize()
+        s = ctx.stats_read()
+        g_ = pl["grid"]
+        print(f"    phase ticks per workgroup (avg): staging {s['steps3']/g_:.0f}  rounds {s['failed_nodes']/g_:.0f}  status {s['waves']/g_:.0f}  write-back+counters {s['full_evals']/g_:.0f}")
     if opts.get("neq_debug", 0) & 8:
         ctx.stats_reset()
         l, u = lb.clone(), ub.clone()
@@ -45,8 +53,7 @@ def timeit(lb, ub, opts, reps=5):
         print(f"    timers (round 0, per wavefront avg): walk {s['steps3']/nw:.0f} ticks, node loops {s['failed_nodes']/nw:.0f} ticks, pieces {(s['waves']-N)/nw:.1f}; evaluated {s['evaluated']:.3e}")
     return float(np.median(ms)), pl
 
-configs = [{}, {"neq_debug": 12}, {"neq_debug": 12, "nodes_per_block": 16}, {"neq_debug": 4}, {"neq_debug": 4, "nodes_per_block": 16}, {"nodes_per_block": 16}, {"nodes_per_block": 16, "neq_block": 768}, {"nodes_per_block": 16, "neq_block": 512}, {"nodes_per_block": 16, "neq_block": 1024}, {"neq_block": 256}, {"neq_block": 512}, {"neq_block": 1024}, {"nodes_per_block": 8}, {"nodes_per_block": 8, "neq_block": 256}, {"nodes_per_block": 8, "neq_block": 1024},
-           {"nodes_per_block": 4, "neq_block": 256}, {"neq_debug": 1}, {"neq_debug": 3}, {"neq_debug": 3, "neq_block": 1024}, {"neq_debug": 3, "nodes_per_block": 8, "neq_block": 256}, {"neq_path": 0}]
+configs = [{}, {"neq_debug": 32}, {"neq_debug": 3}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "neq_block": 512}, {"nodes_per_block": 16, "neq_block": 1024}, {"neq_path": 0}]
 for name, (lb, ub) in batches.items():
     for c in configs:
         ms, pl = timeit(lb, ub, c)

@@ -1,0 +1,76 @@
+"""Replays ONE bench leg's timed launches and nothing else, so that a rocprofv3 PMC pass sees only those dispatches (the deep
+batches are built by thousands of one-node launches, which made the PMC passes of round 2 abort):
+   python tools/replay_leg.py save deep500 deep3000     # build the batches once, un-profiled, into /tmp on the GPU box
+   python tools/replay_leg.py run deep500 [launches]    # load and launch: in place on fresh copies, HIP-event time per launch
+   python tools/replay_leg.py run c3 | c4 | frontier | search   # these build their input with a handful of launches"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as g
+g.build()
+import pcp_amd.engine as E
+from pcp_amd import model as M, workloads as W
+
+mode, names = sys.argv[1], sys.argv[2:]
+n = 1000
+dev = torch.device("cuda", 0)
+ctx = E.Context(0)
+
+
+def nq():
+    ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
+
+
+def launches(lb, ub, act, k):
+    N = lb.shape[0]
+    st = torch.zeros(N, dtype=torch.uint8, device=dev)
+    ms = []
+    for i in range(k + 1):
+        l, u = lb.clone(), ub.clone()
+        a = None if act is None else act.clone()
+        torch.cuda.synchronize()
+        ctx.propagate_device(N, l, u, l, u, a, a, st)
+        if i:
+            ms.append(ctx.last_kernel_ms())
+    return ms, ctx.last_plan()
+
+
+if mode == "save":
+    nq()
+    for nm in names:
+        d = int(nm.replace("deep", ""))
+        lb, ub, _ = W.nqueens_deep(ctx, n, d, 4096, implicit=True)
+        torch.save((lb.cpu(), ub.cpu()), f"/tmp/{nm}.pt")
+        print("saved", nm, tuple(lb.shape))
+else:
+    nm = names[0]
+    k = int(names[1]) if len(names) > 1 else 5
+    act = None
+    if nm.startswith("deep"):
+        nq()
+        lb, ub = (t.to(dev) for t in torch.load(f"/tmp/{nm}.pt"))
+    elif nm == "frontier":
+        nq()
+        L, U, _ = W.nqueens_frontier(ctx, n, 16384, share=0, shares=8, implicit=True)
+        lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+    elif nm == "c3":
+        p3, lb3, ub3, sol3 = W.planted_binary_csp(0xC3, 50_000, 500_000)
+        L3, U3 = W.unit_narrowing_prefix(0xC3 + 1, lb3, ub3, sol3, 4096)
+        ctx.set_model(50_000, p3); ctx.set_hull(0, 999)
+        lb, ub = torch.from_numpy(L3).to(dev), torch.from_numpy(U3).to(dev)
+    elif nm == "c4":
+        p4, L4, U4, A4 = W.golomb_frontier(ctx, 4096)
+        lb, ub, act = torch.from_numpy(L4).to(dev), torch.from_numpy(U4).to(dev), torch.from_numpy(A4.view(np.int64)).to(dev)
+    elif nm == "search":
+        from pcp_amd.search_device import DeviceSearch
+        nq()
+        ds = DeviceSearch(ctx, batch=4096, capacity=40 * 4096, implicit=True)
+        ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
+        ds.advance(max_rounds=40)   # ~30 full rounds of 4096 nodes: propagate + branch per round
+        print(json.dumps({"leg": nm, "nodes": ds.stats.num_nodes, "rounds": ds.stats.rounds}))
+        sys.exit(0)
+    else:
+        raise SystemExit(nm)
+    ms, pl = launches(lb, ub, act, k)
+    print(json.dumps({"leg": nm, "kernel_ms": ms, "median_ms": float(np.median(ms)), "plan": pl}))
