@@ -50,6 +50,7 @@ namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19 };
+constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
 constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
@@ -365,6 +366,50 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
     const uint32_t narrow_before = ctr.narrow;
+    // (a0) the cheaper of two covers.  A changed variable that is NOT assigned wakes only propagators that can act if their OTHER
+    // side is assigned (x_neq_y.rs:82-93), and those sit in the assigned variables' lists too.  After an assignment near the root
+    // ~V variables of a node lose a bound and each would re-walk its whole list to find nothing; the lists of the node's few
+    // assigned variables cover the same propagators.  Per node, whichever set of lists is shorter is walked: the node's marks
+    // become {assigned variables} + {changed variables with a Constant neighbour: that record is in their own list only}.  Every
+    // propagator incident to a changed variable that can act is still evaluated, so the fixpoint is the same; the choice is made
+    // again every round, so the tail of a cascade (few changed variables) goes back to the changed lists and their jump windows.
+    // One wavefront per node; nothing leaves the wavefront until the barrier.  (-DPCP_NEQ_NO_RESWEEP: A/B builds without it.)
+#ifndef PCP_NEQ_NO_RESWEEP
+    if (round) {
+#pragma unroll 1
+      for (uint32_t b = wv; b < nb; b += nwv) {
+        if ((inert >> b) & 1u) continue;
+        uint32_t* const row = chg + (size_t)b * Wv;
+        uint32_t c = 0;
+        for (uint32_t w = lane; w < Wv; w += 64) c += __popc(row[w]);
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (c < kResweepMin) continue;
+        uint32_t cdeg = 0, adeg = 0;
+#pragma unroll 1
+        for (uint32_t v = lane; v < V; v += 64) {
+          const uint32_t dg = adjo[v + 1] - adjo[v];
+          const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
+          if ((row[v >> 5] >> (v & 31u)) & 1u) cdeg += dg;
+          if (d.x == d.y) adeg += dg;
+        }
+        for (int o = 32; o > 0; o >>= 1) { cdeg += __shfl_xor(cdeg, o); adeg += __shfl_xor(adeg, o); }
+        if (adeg >= cdeg) continue;
+#pragma unroll 1
+        for (uint32_t base = 0; base < V; base += 64) {
+          const uint32_t v = base + lane;
+          bool single = false;
+          if (v < V) { const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]); single = d.x == d.y; }
+          const uint64_t bal = __ballot(single);
+          const uint32_t w = (base >> 5) + lane;
+          if (lane < 2 && w < Wv) {
+            const uint32_t keep = a.seed_always ? (row[w] & a.seed_always[w]) : 0u;
+            row[w] = (uint32_t)(bal >> (32u * lane)) | keep;
+          }
+        }
+      }
+      __syncthreads();
+    }
+#endif
     // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
     // here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
     // marks and are listed by the next round.

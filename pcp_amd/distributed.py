@@ -349,6 +349,10 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
     if info is not None:
         info.update(exchange_s=exchange_s, exchanges=exchanges, moved_bytes=xinfo.get("moved_bytes", 0), record_bytes=xinfo.get("record_bytes", 0))
     st = search.stats
-    tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, moved], dtype=torch.int64, device=dev)
+    tot = torch.tensor([st.num_nodes, st.num_solution, st.num_failed_node, st.filter_steps, moved, getattr(st, "evaluated", 0)],
+                       dtype=torch.int64, device=dev)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    return tuple(int(x) for x in tot.tolist())
+    vals = [int(x) for x in tot.tolist()]
+    if info is not None:
+        info["evaluated"] = vals[5]  # (propagator, node) pairs tested one by one, all ranks (pcp_stats.evaluated)
+    return tuple(vals[:5])
