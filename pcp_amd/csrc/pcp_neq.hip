@@ -50,6 +50,7 @@ namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19 };
+constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
@@ -199,6 +200,38 @@ template <bool PACKED> struct TileDomOf { using type = TileDom32; };
 template <> struct TileDomOf<true> { using type = TileDom16; };
 
 }  // namespace
+
+// The cheaper of two covers for one node's next round (see (a0) in the kernel): ONE wavefront, node b.  Kept out of line: inlined,
+// its loops cost the kernel 14 VGPRs and 9 % of the headline launch although frontier tiles hardly ever reach it.
+template <bool PACKED>
+__device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type* dom, uint32_t* row, const uint32_t* adjo,
+                                           const uint32_t* seed_always, uint32_t V, uint32_t Wv, uint32_t B, uint32_t sh, uint32_t b,
+                                           uint32_t lane) {
+  uint32_t c = 0;
+  for (uint32_t w = lane; w < Wv; w += 64) c += __popc(row[w]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (c < kResweepMin) return;
+  uint32_t cdeg = 0, adeg = 0;
+  for (uint32_t v = lane; v < V; v += 64) {
+    const uint32_t dg = adjo[v + 1] - adjo[v];
+    const int2 d = cell_bounds<PACKED>(dom[neq_row(v, B, sh) + b]);
+    if ((row[v >> 5] >> (v & 31u)) & 1u) cdeg += dg;
+    if (d.x == d.y) adeg += dg;
+  }
+  for (int o = 32; o > 0; o >>= 1) { cdeg += __shfl_xor(cdeg, o); adeg += __shfl_xor(adeg, o); }
+  if (adeg >= cdeg) return;
+  for (uint32_t base = 0; base < V; base += 64) {
+    const uint32_t v = base + lane;
+    bool single = false;
+    if (v < V) { const int2 d = cell_bounds<PACKED>(dom[neq_row(v, B, sh) + b]); single = d.x == d.y; }
+    const uint64_t bal = __ballot(single);
+    const uint32_t w = (base >> 5) + lane;
+    if (lane < 2 && w < Wv) {
+      const uint32_t keep = seed_always ? (row[w] & seed_always[w]) : 0u;
+      row[w] = (uint32_t)(bal >> (32u * lane)) | keep;
+    }
+  }
+}
 
 // DFS = true: ONE workgroup runs the reference's search loop itself (pcp_dfs_device) — OneSolution / AllSolution over
 // Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>> on a VectorStack (search/mod.rs:45-52, one_solution.rs:92-105),
@@ -362,6 +395,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint32_t ev0 = 0;  // item tests of round 0 (they stand for the sweep: counted as evaluated, not as extra steps)
   const uint32_t U4 = 4;
   const bool one_piece = a.m.max_deg <= 64u * U4;
+  bool cascade = false;  // the round before narrowed in many threads at once (workgroup-uniform)
   for (uint32_t round = 0;; ++round) {
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
@@ -375,38 +409,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     // again every round, so the tail of a cascade (few changed variables) goes back to the changed lists and their jump windows.
     // One wavefront per node; nothing leaves the wavefront until the barrier.  (-DPCP_NEQ_NO_RESWEEP: A/B builds without it.)
 #ifndef PCP_NEQ_NO_RESWEEP
-    if (round) {
-#pragma unroll 1
-      for (uint32_t b = wv; b < nb; b += nwv) {
-        if ((inert >> b) & 1u) continue;
-        uint32_t* const row = chg + (size_t)b * Wv;
-        uint32_t c = 0;
-        for (uint32_t w = lane; w < Wv; w += 64) c += __popc(row[w]);
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (c < kResweepMin) continue;
-        uint32_t cdeg = 0, adeg = 0;
-#pragma unroll 1
-        for (uint32_t v = lane; v < V; v += 64) {
-          const uint32_t dg = adjo[v + 1] - adjo[v];
-          const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
-          if ((row[v >> 5] >> (v & 31u)) & 1u) cdeg += dg;
-          if (d.x == d.y) adeg += dg;
-        }
-        for (int o = 32; o > 0; o >>= 1) { cdeg += __shfl_xor(cdeg, o); adeg += __shfl_xor(adeg, o); }
-        if (adeg >= cdeg) continue;
-#pragma unroll 1
-        for (uint32_t base = 0; base < V; base += 64) {
-          const uint32_t v = base + lane;
-          bool single = false;
-          if (v < V) { const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]); single = d.x == d.y; }
-          const uint64_t bal = __ballot(single);
-          const uint32_t w = (base >> 5) + lane;
-          if (lane < 2 && w < Wv) {
-            const uint32_t keep = a.seed_always ? (row[w] & a.seed_always[w]) : 0u;
-            row[w] = (uint32_t)(bal >> (32u * lane)) | keep;
-          }
-        }
-      }
+#ifdef PCP_NEQ_RESWEEP_DEAD  // A/B: the code is there, never run
+    if (cascade && (a.debug & 64u)) {
+#else
+    if (cascade) {
+#endif
+      for (uint32_t b = wv; b < nb; b += nwv)
+        if (!((inert >> b) & 1u)) resweep_marks<PACKED>(dom, chg + (size_t)b * Wv, adjo, a.seed_always, V, Wv, B, sh, b, lane);
       __syncthreads();
     }
 #endif
@@ -670,7 +679,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
     // (the barrier also answers "did this round narrow anything?": if not — the usual case of a shallow tile's sweep round — no
     // variable is marked and the next round's list pass and barrier are skipped)
-    const bool narrowed = __syncthreads_or(ctr.narrow != narrow_before) != 0;
+    // (the count of narrowing threads also says whether this round was a cascade: only then is the next round's cover priced)
+    const uint32_t n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
+    const bool narrowed = n_narrowing != 0;
+    cascade = n_narrowing >= kCascadeThreads;
     if (!narrowed && !nwin && misc[N_MORE] != round + 1) break;
     // (c) the jumps: each window's bound moves to the first value no assigned neighbour forbids
     if (nwin) {
