@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 4
+#define PCP_ABI_VERSION 5
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -255,6 +255,41 @@ typedef struct {
   int32_t* first_solution;
 } pcp_dfs_state;
 int32_t pcp_dfs_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
+
+/* ---- the same loop over FDSpace (set mode), a FOREST of trees, one per workgroup (ABI v5) --------------------------------------
+ * ≡ the engine above over VStoreSet = VStoreTrail<IntervalSet<i32>> (variable/mod.rs:38): like the reference, a node is restored
+ * by undoing a TRAIL (variable/memory/trail_memory.rs:100-104) instead of being copied — a tree's current node stays in one CU's
+ * LDS, every narrowing appends (word, removed bits) to the tree's trail, a backtrack ORs them back down to the level's mark and
+ * takes the right branch.  Within a tree: exactly the reference's left-first order (FirstSmallestVar on CARDINALITIES, MiddleVal,
+ * BinarySplit).  Several trees = the subtrees below the open nodes of a frontier (pcp_propagate_device + pcp_branch_device_set
+ * produce one), searched concurrently; n_trees = 1 with the root in bits[0] IS the reference's search.  One call runs at most
+ * n_steps nodes per tree; the caller repeats it until every tree is finished, `stop` is raised, or the budget is spent.
+ *   bits        : [n_trees][n_vars][set_words] device: in = each tree's root, afterwards each tree's current node
+ *   tree        : [n_trees][4] device uint32 = { levels, trail length, pending variable, finished }; the caller initialises every
+ *                 tree to { 0, 0, PCP_DFS_FULL, 0 } (PCP_DFS_FULL: the current node has not been propagated at all)
+ *   levels      : [n_trees][level_capacity][4] device uint32: the branch decisions whose right child is still open
+ *   trail       : [n_trees][trail_capacity][4] device uint32
+ *   counters    : [n_trees][4] device uint64 = { nodes, solutions, failed nodes, error (1 level stack full — the node stays current,
+ *                 uncounted; 3 an Unknown node without a variable to branch on; 4 trail full: the tree cannot be restored) }, accumulated
+ *   total_nodes : device uint64: nodes of all trees; with node_limit != 0 no node beyond it is run (StopNode, stop_node.rs:57-62)
+ *   stop        : device uint32: raised on a solution (stop_on_solution), at the node limit, on an error; the caller zeroes it
+ *   first_solution / solution_flag : [n_vars] device int32 and a device uint32 (zeroed by the caller), or both NULL: the first solution
+ *                 any tree reports (with several trees "first" is in time, not in the reference's order)
+ * Set mode, implicit nodes. */
+#define PCP_DFS_FULL 0xFFFFFFFFu
+typedef struct {
+  uint32_t n_trees, level_capacity, trail_capacity, reserved;
+  uint64_t* bits;
+  uint32_t* tree;
+  uint32_t* levels;
+  uint32_t* trail;
+  uint64_t* counters;
+  uint64_t* total_nodes;
+  uint32_t* stop;
+  int32_t* first_solution;
+  uint32_t* solution_flag;
+} pcp_forest_state;
+int32_t pcp_dfs_forest_device_set(pcp_ctx* ctx, const pcp_forest_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
 
 /* Counters accumulate on the device across pcp_propagate_device calls.  pcp_stats_reset also clears the sticky hull-violation word;
  * pcp_stats_read is the only call that reports (and then clears) it. */

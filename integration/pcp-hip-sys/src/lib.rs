@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PCP_ABI_VERSION: u32 = 4;
+pub const PCP_ABI_VERSION: u32 = 5;
 pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
 pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
 pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
@@ -111,6 +111,26 @@ pub struct pcp_dfs_state {
     pub first_solution: *mut i32,
 }
 
+/// `pcp_dfs_forest_device_set` (ABI v5): the search loop over FDSpace on the device, one tree per workgroup, an undo trail per tree.
+pub const PCP_DFS_FULL: u32 = 0xFFFF_FFFF;
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct pcp_forest_state {
+    pub n_trees: u32,
+    pub level_capacity: u32,
+    pub trail_capacity: u32,
+    pub reserved: u32,
+    pub bits: *mut u64,        // [n_trees][n_vars][set_words]
+    pub tree: *mut u32,        // [n_trees][4]: levels, trail length, pending variable, finished
+    pub levels: *mut u32,      // [n_trees][level_capacity][4]
+    pub trail: *mut u32,       // [n_trees][trail_capacity][4]
+    pub counters: *mut u64,    // [n_trees][4]: nodes, solutions, failed, error
+    pub total_nodes: *mut u64,
+    pub stop: *mut u32,
+    pub first_solution: *mut i32,
+    pub solution_flag: *mut u32,
+}
+
 pub enum pcp_ctx {}
 
 extern "C" {
@@ -135,6 +155,8 @@ extern "C" {
     pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
                                  status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
                                  hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains
+    pub fn pcp_dfs_forest_device_set(ctx: *mut pcp_ctx, st: *const pcp_forest_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
+                                     hip_stream: *mut c_void) -> i32;
     pub fn pcp_dfs_device(ctx: *mut pcp_ctx, st: *const pcp_dfs_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
                           hip_stream: *mut c_void) -> i32; // OneSolution/AllSolution<Propagation<Brancher<..>>> under StopNode, n_steps nodes
     pub fn pcp_stats_reset(ctx: *mut pcp_ctx, hip_stream: *mut c_void) -> i32;

@@ -1117,6 +1117,41 @@ static int32_t dfs_enqueue_steps(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n
   return rc;
 }
 
+int32_t pcp_dfs_forest_device_set(pcp_ctx* c, const pcp_forest_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream) {
+  if (!c || !st) return PCP_ERR_ARG;
+  if (!c->set_words) return fail(c, PCP_ERR_ARG, "pcp_dfs_forest_device_set needs a set-mode model (pcp_model_reset with set_words > 0)");
+  if (!c->hull_set) return fail(c, PCP_ERR_CONTRACT, "set mode needs the hull of the initial domains (pcp_model_set_hull)");
+  if ((int64_t)c->hull_hi - c->hull_lo >= (int64_t)c->set_words * 64) return fail(c, PCP_ERR_CONTRACT, "the declared hull does not fit set_words * 64 values");
+  if (!st->n_trees || !st->bits || !st->tree || !st->levels || !st->trail || !st->counters || !st->total_nodes || !st->stop || !st->level_capacity || !st->trail_capacity)
+    return fail(c, PCP_ERR_ARG, "null buffer / zero capacity");
+  if ((st->first_solution == nullptr) != (st->solution_flag == nullptr)) return fail(c, PCP_ERR_ARG, "first_solution and solution_flag go together");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIP_TRY(c, hipSetDevice(c->device));
+  { const int32_t rcf = finalize_model(c); if (rcf) return rcf; }
+  const uint32_t P = (uint32_t)c->props.size(), S = c->n_slots;
+  uint32_t cap = (uint32_t)std::min<int64_t>(c->opt_list_cap, 1024);
+  while (cap > 64 && !lds_bytes_set_dfs(c->n_vars, S, c->set_words, cap)) cap /= 2;
+  const size_t lds = lds_bytes_set_dfs(c->n_vars, S, c->set_words, cap);
+  if (!lds || lds > c->lds_max) return fail(c, PCP_ERR_UNSUPPORTED, "set-mode variable store does not fit one CU's LDS (n_vars * (set_words + 1) * 8 bytes)");
+  SetDfsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->have_adjp ? c->d_adjp : nullptr; a.m.const_val = c->d_const;
+  a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
+  a.set_words = c->set_words; a.list_cap = cap; a.base = c->hull_lo;
+  a.n_trees = st->n_trees; a.level_cap = st->level_capacity; a.trail_cap = st->trail_capacity; a.n_steps = n_steps; a.stop_on_solution = stop_on_solution;
+  a.node_limit = node_limit;
+  a.bits = st->bits; a.tree = st->tree; a.levels = reinterpret_cast<uint4*>(st->levels); a.trail = reinterpret_cast<uint4*>(st->trail);
+  a.counters = reinterpret_cast<unsigned long long*>(st->counters); a.total_nodes = reinterpret_cast<unsigned long long*>(st->total_nodes);
+  a.stop = st->stop; a.first_solution = st->first_solution; a.solution_flag = st->solution_flag; a.stats = c->d_stats;
+  if (!n_steps) return PCP_OK;
+  c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, 1u, 1u, st->n_trees, 1024u, (uint32_t)lds, cap, 0u};
+  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  HIP_TRY(c, launch_setdfs(a, stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  c->ev_valid = true;
+  return PCP_OK;
+}
+
 int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream) {
   if (!c || !st) return PCP_ERR_ARG;
   if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_dfs_device runs interval-mode models only");

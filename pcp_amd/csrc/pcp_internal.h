@@ -174,6 +174,27 @@ hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words
                          uint64_t* bits_out, int32_t* lb_out, int32_t* ub_out, const uint64_t* live_in, uint64_t* live, uint8_t* status,
                          pcp_stats* stats, uint64_t* derive_into, hipStream_t stream);
 
+// Set mode, the search loop on the device: one tree per workgroup, the current node in LDS, an undo trail in HBM (pcp_set.hip).
+struct SetDfsArgs {
+  ModelDev m;
+  uint32_t set_words, list_cap;
+  int32_t base;
+  uint32_t n_trees, level_cap, trail_cap, n_steps, stop_on_solution;
+  unsigned long long node_limit;
+  uint64_t* bits;                 // [n_trees][n_vars][set_words]: each tree's current node
+  uint32_t* tree;                 // [n_trees][4]: levels, trail length, pending variable, finished
+  uint4* levels;                  // [n_trees][level_cap]: (variable, value, trail mark, -)
+  uint4* trail;                   // [n_trees][trail_cap]: (word index, variable, removed bits lo, hi)
+  unsigned long long* counters;   // [n_trees][4]: nodes, solutions, failed, error
+  unsigned long long* total_nodes;
+  uint32_t* stop;
+  int32_t* first_solution;
+  uint32_t* solution_flag;
+  pcp_stats* stats;
+};
+size_t lds_bytes_set_dfs(uint32_t n_vars, uint32_t n_slots, uint32_t set_words, uint32_t list_cap);
+hipError_t launch_setdfs(const SetDfsArgs& a, hipStream_t stream);
+
 hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t* child_base, uint32_t* counts, hipStream_t stream);
 // Set-mode branching: FirstSmallestVar by CARDINALITY, MiddleVal on the bounds, BinarySplit on the sets.
 hipError_t launch_set_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t set_words, int32_t base, uint32_t words, const uint64_t* bits, const int32_t* lb,

@@ -51,10 +51,14 @@ __host__ __device__ inline SetCarve set_carve(uint32_t V, uint32_t S, uint32_t s
   return c;
 }
 
-enum { S_FAIL = 0, S_TOTAL = 1, S_ITEMS = 2, S_TOTAL2 = 3, S_ITEMS2 = 4, S_WAVES = 5, S_OPEN = 6, S_NARROW = 7, S_STEPS2 = 8, S_STEPS3 = 10, S_EVAL = 12, S_LIVE = 14, S_NSING = 15 };
+enum { S_FAIL = 0, S_TOTAL = 1, S_ITEMS = 2, S_TOTAL2 = 3, S_ITEMS2 = 4, S_WAVES = 5, S_OPEN = 6, S_NARROW = 7, S_STEPS2 = 8, S_STEPS3 = 10, S_EVAL = 12, S_LIVE = 14, S_NSING = 15,
+       S_TRAILOVF = 16, S_TRAILLEN = 17, S_CTL = 18 /* .. 23: the DFS loop's broadcast words */ };
 
-// One node's domains in LDS.
-struct SetDom {
+// One node's domains in LDS.  TRAIL = true (the device-side DFS, setdfs_kernel): every narrowing also appends (word, removed bits)
+// to the tree's undo trail, which is what the reference's VStoreTrail keeps (variable/memory/trail_memory.rs:100-104): a
+// backtrack ORs the removed bits back instead of reloading a node.
+template <bool TRAIL>
+struct SetDomT {
   unsigned long long* bits;  // [V][sw]
   int2* bnd;                 // [V] (lb, ub)
   const int32_t* cval;       // constants, slots >= V
@@ -63,6 +67,18 @@ struct SetDom {
   uint32_t* chg;             // changed mask to mark
   uint32_t* misc;
   uint32_t* narrow;          // per-thread counter
+  uint4* trail = nullptr;    // TRAIL: the tree's trail in HBM, its length (an LDS word) and its capacity
+  uint32_t* trail_len = nullptr;
+  uint32_t trail_cap = 0;
+
+  __device__ __forceinline__ void log(uint32_t var, uint32_t widx, unsigned long long removed) const {
+    if constexpr (TRAIL) {
+      if (!removed) return;
+      const uint32_t pos = atomicAdd(trail_len, 1u);
+      if (pos < trail_cap) trail[pos] = make_uint4(widx, var, (uint32_t)removed, (uint32_t)(removed >> 32));
+      else atomicOr(&misc[S_TRAILOVF], 1u);
+    }
+  }
 
   __device__ __forceinline__ bool is_const(uint32_t s) const { return s >= V; }
   __device__ __forceinline__ int2 bounds(uint32_t s) const {
@@ -86,7 +102,7 @@ struct SetDom {
     const unsigned long long m = 1ull << (b & 63);
     unsigned long long* w = &bits[(size_t)s * sw + (b >> 6)];
     if (!(*w & m)) return;
-    if (atomicAnd(w, ~m) & m) mark(s);
+    if (atomicAnd(w, ~m) & m) { log(s, s * sw + (uint32_t)(b >> 6), m); mark(s); }
   }
   // keep only the values <= t  (shrink_right) / >= t (shrink_left), within the cached bounds [lo, hi] of slot s
   __device__ __forceinline__ void keep_le(uint32_t s, long long t, const int2 cur) const {
@@ -110,7 +126,11 @@ struct SetDom {
       if (k == (b0 >> 6)) m &= ~0ull << (b0 & 63);
       if (k == (b1 >> 6)) m &= ~0ull >> (63 - (b1 & 63));
       unsigned long long* w = &bits[(size_t)s * sw + k];
-      if (*w & m) changed |= (atomicAnd(w, ~m) & m) != 0;
+      if (*w & m) {
+        const unsigned long long gone = atomicAnd(w, ~m) & m;
+        log(s, s * sw + (uint32_t)k, gone);
+        changed |= gone != 0;
+      }
     }
     if (changed) mark(s);
   }
@@ -140,7 +160,11 @@ struct SetDom {
       } else {
         other = window(y, (long long)k * 64 - d);  // value v of x  <->  value v - d of y
       }
-      if (cur & ~other) changed |= (atomicAnd(w, other) & ~other) != 0;
+      if (cur & ~other) {
+        const unsigned long long gone = atomicAnd(w, other) & ~other;
+        log(x, x * sw + k, gone);
+        changed |= gone != 0;
+      }
     }
     if (changed) mark(x);
   }
@@ -153,10 +177,12 @@ struct SetDom {
     return true;
   }
 };
+using SetDom = SetDomT<false>;
 
 // One filter step on sets: propagate() + is_subsumed().  `want_entailed` = false skips the (possibly expensive) subsumption
 // test — implicit-active nodes need it only in the final scan.  Returns whether the propagator is entailed.
-__device__ __forceinline__ bool eval_set(const Rec& rec, const SetDom& dm, const bool want_entailed) {
+template <class DM>
+__device__ __forceinline__ bool eval_set(const Rec& rec, const DM& dm, const bool want_entailed) {
   const uint32_t kind = rec.xk >> 28, x = rec.xk & kSlotMask, y = rec.y;
   const long long d = rec.d;
   const int2 X = dm.bounds(x), Y = dm.bounds(y);
@@ -565,6 +591,322 @@ __global__ void __launch_bounds__(kSetThreads) set_derive_active_kernel(const Se
     const uint64_t word = __ballot(on);
     if (lane == 0) live[(size_t)node * words + w] = word;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's search loop over FDSpace on the device, ONE TREE PER WORKGROUP (pcp_dfs_forest_device_set):
+// OneSolution / AllSolution<Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>>> (search/mod.rs:45-52) over
+// VStoreSet = VStoreTrail<IntervalSet<i32>> (variable/mod.rs:38).  The reference restores a node by undoing a TRAIL
+// (variable/memory/trail_memory.rs:100-104); so does this kernel: the current node never leaves LDS, every narrowing appends
+// (variable, word, removed bits) to the tree's trail in HBM, a backtrack ORs the bits back down to the level's mark and applies the
+// right branch.  Per node the HBM traffic is the trail (a few KB after an assignment, a few bytes otherwise) instead of the
+// 125 KB-per-node rows of the batched search (pcp_propagate_device + pcp_branch_device_set).
+// A child differs from its parent's fixpoint in the branched variable only, so only that variable is marked changed (at a fixpoint
+// every other propagator is a no-op until one of its variables changes); a root (pending == kDfsFull) runs the sweep of setfix_kernel.
+// Exactly the reference's left-first order within a tree; several trees = the subtrees of an open-node frontier, each on its CU.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kDfsFull = 0xFFFFFFFFu;
+
+struct SetDfsCarve { SetCarve c; size_t touched, total; };
+__host__ __device__ inline SetDfsCarve set_dfs_carve(uint32_t V, uint32_t S, uint32_t sw, uint32_t cap) {
+  SetDfsCarve d;
+  d.c = set_carve(V, S, sw, cap);
+  d.touched = d.c.total;
+  d.total = (d.touched + ((size_t)(S + 31) / 32) * 4 + 15) & ~(size_t)15;
+  return d;
+}
+
+__global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, sw = a.set_words, C = a.list_cap, P = a.m.n_recs, words = (P + 63) >> 6;
+  const uint32_t Wv = (S + 31) >> 5;
+  const SetDfsCarve dcv = set_dfs_carve(V, S, sw, C);
+  const SetCarve& cv = dcv.c;
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(smem + cv.bits);
+  int2* bnd = reinterpret_cast<int2*>(smem + cv.bnd);
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem + cv.chg_a);
+  uint32_t* nxt = reinterpret_cast<uint32_t*>(smem + cv.chg_b);
+  uint32_t* list_id = reinterpret_cast<uint32_t*>(smem + cv.list_id);
+  uint32_t* list_off = reinterpret_cast<uint32_t*>(smem + cv.list_off);
+  uint32_t* list_deg = reinterpret_cast<uint32_t*>(smem + cv.list_deg);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+  uint32_t* touched = reinterpret_cast<uint32_t*>(smem + dcv.touched);
+  const uint32_t t = blockIdx.x;
+  pcp_stats* const st_slot = a.stats + (blockIdx.x & (kStatSlots - 1));
+  uint32_t* const tree = a.tree + (size_t)t * 4;
+  uint32_t n_levels = tree[0], pending = tree[2];
+  if (tree[3]) return;  // this tree is finished
+  uint4* const trail = a.trail + (size_t)t * a.trail_cap;
+  uint4* const levels = a.levels + (size_t)t * a.level_cap;
+  unsigned long long* const gbits = reinterpret_cast<unsigned long long*>(a.bits) + (size_t)t * V * sw;
+
+  // ---- the tree's current node into LDS, its bounds ------------------------------------------------------------------------
+  if (tid < 32) misc[tid] = 0;
+  for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; touched[i] = 0; }
+  {
+    const uint32_t nwords = V * sw;
+    if (!(nwords & 1u) && !((size_t)gbits & 15)) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(gbits);
+      uint4* d4 = reinterpret_cast<uint4*>(bits);
+      for (uint32_t i = tid; i < nwords / 2; i += nth) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = tid; i < nwords; i += nth) bits[i] = gbits[i];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) misc[S_TRAILLEN] = tree[1];
+  for (uint32_t v = tid; v < V; v += nth) {
+    const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+    bnd[v] = b;
+    if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+  }
+  if (pending != kDfsFull && tid == 0) cur[pending >> 5] = 1u << (pending & 31u);  // (a node persisted by the launch before)
+  __syncthreads();
+
+  uint32_t narrow = 0;
+  uint64_t ev = 0;
+  unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;
+  uint32_t c_err = 0;
+  bool finished = false;
+  const bool neq_only = a.m.uniform_kind == PCP_NEQ && S == V;
+  using DM = SetDomT<true>;
+
+  for (uint32_t step = 0; step < a.n_steps; ++step) {
+    // ---- may this node run?  (stop flag of the forest, the node limit of all trees together: StopNode, stop_node.rs:57-62) ----
+    if (tid == 0) {
+      uint32_t go = 1, last = 0;
+      if (__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) go = 0;
+      else {
+        const unsigned long long old = atomicAdd(a.total_nodes, 1ull);
+        if (a.node_limit && old >= a.node_limit) { atomicAdd(a.total_nodes, ~0ull); atomicExch(a.stop, 1u); go = 0; }
+        // the node that reaches the limit is explored and counted, but StopNode replaces its status by EndOfSearch
+        // (stop_node.rs:55-62): it is neither a solution nor a failure
+        else if (a.node_limit && old + 1 >= a.node_limit) last = 1;
+      }
+      misc[S_CTL] = go; misc[S_CTL + 2] = last; misc[S_OPEN] = 0; misc[S_TOTAL] = 0; misc[S_TOTAL2] = 0;  // (a node's last round leaves its count behind)
+    }
+    __syncthreads();
+    if (!misc[S_CTL]) break;
+
+    // ---- propagate ---------------------------------------------------------------------------------------------------------
+    if (pending == kDfsFull && !misc[S_FAIL]) {
+      const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
+      bool bulk = false;
+      if (neq_only) {  // the lists of the assigned variables stand for the whole sweep (see setfix_kernel)
+        if (tid == 0) misc[S_NSING] = 0;
+        __syncthreads();
+        for (uint32_t v = tid; v < V; v += nth) {
+          const int2 b = bnd[v];
+          if (b.x == b.y) { const uint32_t pos = atomicAdd(&misc[S_NSING], 1u); if (pos < C) list_id[pos] = v; }
+        }
+        __syncthreads();
+        const uint32_t ns = misc[S_NSING];
+        bulk = ns <= C;
+        if (bulk)
+          for (uint32_t e = 0; e < ns; ++e) {
+            const uint32_t v = list_id[e], o0 = a.m.adj_off[v], o1 = a.m.adj_off[v + 1];
+            for (uint32_t i = o0 + tid; i < o1; i += nth) { (void)eval_set(a.m.recs[a.m.adj[i]], dm, false); ++ev; }
+          }
+      }
+      if (!bulk)
+        for (uint32_t r = tid; r < P; r += nth) { (void)eval_set(a.m.recs[r], dm, false); ++ev; }
+      __syncthreads();
+    }
+    for (uint32_t round = 0;; ++round) {
+      const uint32_t m_total = (round & 1u) ? S_TOTAL2 : S_TOTAL;
+      for (uint32_t v = tid; v < V; v += nth) {
+        if (!((cur[v >> 5] >> (v & 31)) & 1u)) continue;
+        const int2 b = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+        bnd[v] = b;
+        if (b.x > b.y) atomicOr(&misc[S_FAIL], 1u);
+      }
+      __syncthreads();
+      for (uint32_t w = tid; w < Wv; w += nth) {
+        if (round) nxt[w] = 0;
+        uint32_t bitsw = cur[w];
+        if (!bitsw) continue;
+        uint32_t dropped = 0;
+        while (bitsw) {
+          const uint32_t v = (w << 5) + __builtin_ctz(bitsw);
+          bitsw &= bitsw - 1;
+          if (v < V && neq_only) { const int2 b = bnd[v]; if (b.x != b.y) { dropped |= 1u << (v & 31); continue; } }
+          const uint32_t pos = atomicAdd(&misc[m_total], 1u);
+          if (pos < C) {
+            const uint32_t o0 = (v < V) ? a.m.adj_off[v] : 0u, o1 = (v < V) ? a.m.adj_off[v + 1] : 0u;
+            list_id[pos] = v; list_off[pos] = o0; list_deg[pos] = o1 - o0;
+          }
+        }
+        if (dropped) cur[w] &= ~dropped;
+      }
+      __syncthreads();
+      const uint32_t total = misc[m_total];
+      if (total == 0 || misc[S_FAIL]) break;
+      if (tid == 0) misc[(round & 1u) ? S_TOTAL : S_TOTAL2] = 0;
+      const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
+      auto run = [&](uint32_t v, uint32_t r) {  // FIFO dedup as in setfix_kernel: the lowest changed variable of a record runs it
+        const Rec rec = a.m.recs[r];
+        const uint32_t x = rec.xk & kSlotMask;
+        const bool tern = (rec.xk >> 28) > PCP_LT;
+        if (x < v && ((cur[x >> 5] >> (x & 31)) & 1u)) return;
+        if (rec.y < v && ((cur[rec.y >> 5] >> (rec.y & 31)) & 1u)) return;
+        if (tern && rec.z < v && ((cur[rec.z >> 5] >> (rec.z & 31)) & 1u)) return;
+        ++ev;
+        (void)eval_set(rec, dm, false);
+      };
+      if (total <= C) {
+        for (uint32_t e = 0; e < total; ++e) {
+          const uint32_t v = list_id[e], deg = list_deg[e], off = list_off[e];
+          for (uint32_t i = tid; i < deg; i += nth) run(v, a.m.adj[off + i]);
+        }
+      } else {
+        for (uint32_t r = tid; r < P; r += nth) {
+          const Rec rec = a.m.recs[r];
+          const uint32_t x = rec.xk & kSlotMask;
+          const bool tern = (rec.xk >> 28) > PCP_LT;
+          uint32_t vmin = 0xFFFFFFFFu;
+          if ((cur[x >> 5] >> (x & 31)) & 1u) vmin = x;
+          if (((cur[rec.y >> 5] >> (rec.y & 31)) & 1u) && rec.y < vmin) vmin = rec.y;
+          if (tern && ((cur[rec.z >> 5] >> (rec.z & 31)) & 1u) && rec.z < vmin) vmin = rec.z;
+          if (vmin != 0xFFFFFFFFu) run(vmin, r);
+        }
+      }
+      __syncthreads();
+      uint32_t* sw_ = cur; cur = nxt; nxt = sw_;
+    }
+    __syncthreads();
+    // ---- status (store.rs:250-256): failed / every propagator entailed / open -------------------------------------------------
+    const bool failed = misc[S_FAIL] != 0;
+    if (!failed) {
+      const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
+      for (uint32_t w = wv; w < words; w += nwv) {
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+        const uint32_t r = (w << 6) + lane;
+        bool open_rec = false;
+        if (r < P) open_rec = !eval_set(a.m.recs[r], dm, true);
+        if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }  // (a failed node leaves marks behind)
+    const bool open = misc[S_OPEN] != 0;
+    const uint32_t tlen = misc[S_TRAILLEN];
+    if (misc[S_TRAILOVF]) { c_err = 4; break; }  // the trail is full: the tree cannot be restored any more (terminal)
+    ++c_nodes;
+    const bool last = misc[S_CTL + 2] != 0;
+    bool descend = false;
+    if (failed) {
+      if (!last) ++c_fail;
+    } else if (!open && last) {
+    } else if (!open) {  // a solution (monitor.rs:19-68); the first one of the forest is kept
+      ++c_sols;
+      if (a.first_solution) {
+        if (tid == 0) misc[S_CTL + 1] = atomicCAS(a.solution_flag, 0u, 1u) == 0u ? 1u : 0u;
+        __syncthreads();
+        if (misc[S_CTL + 1])
+          for (uint32_t v = tid; v < V; v += nth) a.first_solution[v] = bnd[v].x;
+      }
+      if (a.stop_on_solution && tid == 0) atomicExch(a.stop, 1u);
+    } else {
+      // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter on sets: minimal CARDINALITY > 1, first index
+      unsigned long long key = ~0ull;
+      for (uint32_t v = tid; v < V; v += nth) {
+        unsigned long long size = 0;
+        for (uint32_t k = 0; k < sw; ++k) size += (unsigned long long)__popcll(bits[(size_t)v * sw + k]);
+        if (size > 1) key = min(key, (size << 32) | v);
+      }
+      for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+      unsigned long long* best = reinterpret_cast<unsigned long long*>(list_off);  // (idle between rounds; 16 x 8 bytes)
+      if (lane == 0) best[wv] = key;
+      __syncthreads();
+      key = best[0];
+      for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
+      __syncthreads();
+      if (key == ~0ull) { c_err = 3; --c_nodes; if (tid == 0) atomicAdd(a.total_nodes, ~0ull); break; }  // Unknown, yet nothing to branch on: the reference panics
+      if (n_levels >= a.level_cap) { c_err = 1; --c_nodes; pending = kDfsFull; if (tid == 0) atomicAdd(a.total_nodes, ~0ull); break; }
+      const uint32_t var = (uint32_t)key;
+      const int2 d = bnd[var];
+      const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27)
+      if (tid == 0) {
+        levels[n_levels] = make_uint4(var, (uint32_t)val, tlen, 0u);
+        const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
+        dm.clear_range(var, (long long)val + 1, d.y);  // the left child x <= val (binary_split.rs:46-57)
+      }
+      ++n_levels;
+      pending = var;
+      descend = true;
+    }
+    if (!descend) {
+      // ---- backtrack: the deepest level whose right branch is still open --------------------------------------------------
+      if (n_levels == 0) { finished = true; break; }
+      --n_levels;
+      const uint4 lv = levels[n_levels];
+      const uint32_t T = lv.z;
+      for (uint32_t i = T + tid; i < tlen; i += nth) {
+        const uint4 e = trail[i];
+        atomicOr(&bits[e.x], ((unsigned long long)e.w << 32) | e.z);
+        atomicOr(&touched[e.y >> 5], 1u << (e.y & 31u));
+      }
+      __syncthreads();
+      if (tid == 0) { misc[S_TRAILLEN] = T; misc[S_FAIL] = 0; }
+      for (uint32_t v = tid; v < V; v += nth)
+        if ((touched[v >> 5] >> (v & 31u)) & 1u) bnd[v] = scan_bounds(bits + (size_t)v * sw, sw, a.base);
+      __syncthreads();
+      for (uint32_t i = tid; i < Wv; i += nth) touched[i] = 0;
+      if (tid == 0) {
+        const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
+        const int2 d = bnd[lv.x];
+        dm.clear_range(lv.x, d.x, (long long)(int)lv.y);  // the right child x > val
+      }
+      pending = lv.x;
+    }
+    if (last && tid == 0) atomicExch(a.stop, 1u);
+    if (last || (a.stop_on_solution && c_sols)) { __syncthreads(); break; }
+    __syncthreads();
+  }
+
+  // ---- persist the tree: its current node, its stacks' lengths, its counters --------------------------------------------------
+  __syncthreads();
+  {
+    const uint32_t nwords = V * sw;
+    if (!(nwords & 1u) && !((size_t)gbits & 15)) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(bits);
+      uint4* d4 = reinterpret_cast<uint4*>(gbits);
+      for (uint32_t i = tid; i < nwords / 2; i += nth) d4[i] = s4[i];
+    } else {
+      for (uint32_t i = tid; i < nwords; i += nth) gbits[i] = bits[i];
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { narrow += __shfl_down(narrow, o); ev += __shfl_down(ev, o); }
+  if (lane == 0) {
+    if (narrow) atomicAdd((unsigned long long*)&st_slot->narrowings, (unsigned long long)narrow);
+    if (ev) { atomicAdd((unsigned long long*)&st_slot->evaluated, (unsigned long long)ev); atomicAdd((unsigned long long*)&st_slot->full_evals, (unsigned long long)ev); }
+  }
+  if (tid == 0) {
+    tree[0] = n_levels; tree[1] = misc[S_TRAILLEN]; tree[2] = pending; tree[3] = finished ? 1u : 0u;
+    unsigned long long* cn = a.counters + (size_t)t * 4;
+    cn[0] += c_nodes; cn[1] += c_sols; cn[2] += c_fail;
+    if (c_err) cn[3] = c_err;
+    // reference-equivalent steps: every propagator of every node once (init_scheduler) — the wake-ups are in `evaluated`
+    atomicAdd((unsigned long long*)&st_slot->steps, c_nodes * (unsigned long long)P);
+    atomicAdd((unsigned long long*)&st_slot->nodes, c_nodes);
+    if (c_fail) atomicAdd((unsigned long long*)&st_slot->failed_nodes, c_fail);
+    if (c_err) atomicExch(a.stop, 1u);
+  }
+}
+
+size_t lds_bytes_set_dfs(uint32_t n_vars, uint32_t n_slots, uint32_t set_words, uint32_t list_cap) {
+  const SetDfsCarve c = set_dfs_carve(n_vars, n_slots, set_words, list_cap);
+  return c.total <= 160 * 1024 ? c.total : 0;
+}
+
+hipError_t launch_setdfs(const SetDfsArgs& a, hipStream_t stream) {
+  const size_t lds = set_dfs_carve(a.m.n_vars, a.m.n_slots, a.set_words, a.list_cap).total;
+  hipError_t e;
+  if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(setdfs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+  hipLaunchKernelGGL(setdfs_kernel, dim3(a.n_trees), dim3(kSetThreads), lds, stream, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_setfix(const ModelDev& m, uint32_t n_nodes, uint32_t set_words, int32_t base, uint32_t list_cap, const uint64_t* bits_in,

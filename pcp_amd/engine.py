@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -52,6 +52,15 @@ class DeviceBatch(C.Structure):
 class DfsState(C.Structure):
     _fields_ = [("lb", C.c_void_p), ("ub", C.c_void_p), ("capacity", C.c_uint32), ("sp", C.c_void_p), ("stop", C.c_void_p), ("status", C.c_void_p),
                 ("counters", C.c_void_p), ("first_solution", C.c_void_p)]
+
+
+class ForestState(C.Structure):
+    _fields_ = [("n_trees", C.c_uint32), ("level_capacity", C.c_uint32), ("trail_capacity", C.c_uint32), ("reserved", C.c_uint32),
+                ("bits", C.c_void_p), ("tree", C.c_void_p), ("levels", C.c_void_p), ("trail", C.c_void_p), ("counters", C.c_void_p),
+                ("total_nodes", C.c_void_p), ("stop", C.c_void_p), ("first_solution", C.c_void_p), ("solution_flag", C.c_void_p)]
+
+
+DFS_FULL = 0xFFFFFFFF
 
 
 class EngineUnavailable(RuntimeError):
@@ -107,13 +116,14 @@ def load_library():
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
+    L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -317,6 +327,48 @@ class Context:
         sp, stop = state.cpu().tolist()
         return {"nodes": cn[0], "solutions": cn[1], "failed": cn[2], "error": cn[3], "open": sp, "stopped": bool(stop), "steps_enqueued": done,
                 "first_solution": sol.cpu().numpy() if cn[1] else None}
+
+    def dfs_forest_set(self, root_bits, stop_on_solution: bool = False, node_limit: int = 0, steps_per_launch: int = 256,
+                       level_capacity: int = 4096, trail_capacity: int = 1 << 20, max_launches: int = 1 << 30, want_solution: bool = True,
+                       info: dict | None = None):
+        """pcp_dfs_forest_device_set: the reference's search loop over FDSpace on the device, one tree per workgroup, the current
+        node in LDS, an undo trail in HBM.  root_bits: [n_trees, n_vars, set_words] uint64 (numpy or a CUDA int64 tensor): the roots,
+        not yet propagated.  Launches of steps_per_launch nodes per tree are repeated until every tree is finished, the forest
+        stopped (solution / node limit / error) or max_launches is reached.
+        Returns dict(nodes, solutions, failed, error, finished_trees, stopped, launches, first_solution, per_tree=[n_trees, 4])."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        V, sw = self.n_vars, self.set_words
+        if isinstance(root_bits, np.ndarray):
+            bits = torch.from_numpy(np.ascontiguousarray(root_bits).view(np.int64)).to(dev)
+        else:
+            bits = root_bits.to(dev).contiguous().clone()
+        bits = bits.reshape(-1, V, sw)
+        T = bits.shape[0]
+        tree = torch.zeros((T, 4), dtype=torch.int32, device=dev)
+        tree[:, 2] = -1  # PCP_DFS_FULL
+        levels = torch.empty((T, level_capacity, 4), dtype=torch.int32, device=dev)  # (written before they are read: no fill)
+        trail = torch.empty((T, trail_capacity, 4), dtype=torch.int32, device=dev)
+        counters = torch.zeros((T, 4), dtype=torch.int64, device=dev)
+        glob = torch.zeros(4, dtype=torch.int64, device=dev)  # total nodes | stop (low word of [1]) | solution flag (low word of [2])
+        sol = torch.zeros(V, dtype=torch.int32, device=dev) if want_solution else None
+        st = ForestState(T, level_capacity, trail_capacity, 0, bits.data_ptr(), tree.data_ptr(), levels.data_ptr(), trail.data_ptr(), counters.data_ptr(),
+                         glob.data_ptr(), glob.data_ptr() + 8, sol.data_ptr() if want_solution else None, glob.data_ptr() + 16 if want_solution else None)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        launches = 0
+        while launches < max_launches:
+            self._check(self._L.pcp_dfs_forest_device_set(self._h, C.byref(st), int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit), C.c_void_p(stream)))
+            launches += 1
+            g = glob.cpu().tolist()  # (the launch's only synchronisation)
+            if (g[1] & 0xFFFFFFFF) or int(tree[:, 3].sum().item()) == T:
+                break
+        cn = counters.cpu().numpy()
+        g = glob.cpu().tolist()
+        if info is not None:
+            info.update(trail_max=int(tree[:, 1].max().item()), levels_max=int(tree[:, 0].max().item()), trees=T)
+        return {"nodes": int(cn[:, 0].sum()), "solutions": int(cn[:, 1].sum()), "failed": int(cn[:, 2].sum()), "error": int(cn[:, 3].max()),
+                "finished_trees": int(tree[:, 3].sum().item()), "stopped": bool(g[1] & 0xFFFFFFFF), "launches": launches, "total_nodes": int(g[0]),
+                "first_solution": sol.cpu().numpy() if (want_solution and (g[2] & 0xFFFFFFFF)) else None, "per_tree": cn}
 
     def stats_reset(self, stream_ptr: int = 0):
         self._check(self._L.pcp_stats_reset(self._h, C.c_void_p(stream_ptr)))
