@@ -160,8 +160,10 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     ctx.set_model(n, M.nqueens_props(n), set_words=(n + 63) // 64 if set_mode else 0)
     ctx.set_hull(1, n)
     batch = args.search_batch
-    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    if set_mode:
+        return run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0)
+    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
     if world == 1 and not dist.is_initialized():
         # a single GPU still goes through the process group (RCCL with one rank): same driver, same exchange steps
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -206,6 +208,53 @@ def run_search_mode(args, torch, dist, world, rank, dev):
         }), flush=True)
 
 
+def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0):
+    """--mode search --domains set: every rank expands the root to the same frontier (no communication), takes the open nodes
+    r, r + world, ... and searches each as a tree in one CU's LDS with an undo trail (pcp_amd.search_forest); one all_reduce of
+    the counters at the end.  Subtrees are not re-balanced (N-queens-1000: no subtree ends within the budget)."""
+    from pcp_amd.search_forest import forest_search_set
+    n = args.n
+    trees = args.trees
+    forest_search_set(ctx, lb0, ub0, 1, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world)  # warm-up
+    torch.cuda.synchronize()
+    ctx.stats_reset()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    info = {}
+    fr = forest_search_set(ctx, lb0, ub0, 1, node_limit=args.node_budget, n_trees=trees, steps_per_launch=args.steps_per_launch, rank=rank, world=world, info=info)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    fs = ctx.stats_read()
+    tot = torch.tensor([fr["nodes"], fr["solutions"], fr["failed"], fs["evaluated"], fs["steps"] + fs["steps3"], fr["trees"], fr["error"]], dtype=torch.int64, device=dev)
+    t_dt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t_dt, op=dist.ReduceOp.MAX)
+    dt = float(t_dt.item())
+    nodes, sols, fails, evaluated, steps, ntrees, err = (int(x) for x in tot.tolist())
+    if rank == 0:
+        _flush_c_stdio()
+        print(json.dumps({
+            "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: parallel subtree search over FDSpace)",
+            "value": evaluated / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": f"N-queens n={n} parallel subtree search over IntervalSet<i32> domains (FDSpace, the reference's default), first {args.node_budget} nodes of the tree "
+                            f"(all ranks together): the root is expanded breadth-first to {ntrees} open nodes, each the root of a tree searched depth-first by one workgroup "
+                            "(current node in LDS, undo trail in HBM: pcp_dfs_forest_device_set); no data-path collective",
+                "value_is": "filter steps EXECUTED per second, all ranks (pcp_stats.evaluated); steps_reference_equivalent_per_s = every propagator of every node once "
+                            "(init_scheduler) plus the wake-ups",
+                "steps_reference_equivalent_per_s": steps / dt, "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails,
+                "trees": ntrees, "steps_per_launch": args.steps_per_launch, "launches_rank0": fr["launches"], "error": err,
+                "trail_entries_max_rank0": info.get("trail_max"), "levels_max_rank0": info.get("levels_max"), "domains": "set",
+                "parallelism": f"subtrees sharded over {world} GPU(s)",
+            },
+        }), flush=True)
+
+
 def _flush_c_stdio():
     """librccl prints a version banner through C stdio when the process group comes up; flush it now so that the JSON line is
     the LAST line of rank 0's stdout."""
@@ -234,6 +283,8 @@ def main():
     ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
     ap.add_argument("--search-batch", type=int, default=4096)
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
+    ap.add_argument("--trees", type=int, default=512, help="--mode search --domains set: trees (workgroups) per GPU")
+    ap.add_argument("--steps-per-launch", type=int, default=2048, help="--mode search --domains set: nodes per tree and launch")
     ap.add_argument("--domains", choices=["interval", "set"], default="interval",
                     help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
     args = ap.parse_args()
@@ -581,25 +632,46 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         ctx.set_model(n, props)
         ctx.set_hull(1, n)
     if "setsearch" in want:
-        # the reference's own workload end to end: example/src/nqueens.rs over FDSpace, stack + propagation + branching on the GPU
+        # the reference's own workload end to end: example/src/nqueens.rs over FDSpace, entirely on the GPU
         reset_opts()
         sw = (n + 63) // 64
         ctx.set_model(n, props, set_words=sw)
         ctx.set_hull(1, n)
+        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+        # (a) one tree per workgroup, the current node in LDS, an undo trail (pcp_dfs_forest_device_set)
+        from pcp_amd.search_forest import forest_search_set
+        budget_f, trees = 1_000_000, 512
+        forest_search_set(ctx, lb0, ub0, 1, node_limit=4 * trees, n_trees=trees, steps_per_launch=4)
+        torch.cuda.synchronize()
+        ctx.stats_reset()
+        finfo = {}
+        t0 = time.perf_counter()
+        fr = forest_search_set(ctx, lb0, ub0, 1, node_limit=budget_f, n_trees=trees, steps_per_launch=2048, info=finfo)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        fs = ctx.stats_read()
+        legs.append({"name": "C2-set-mode-device-search", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
+                     "steps_per_s": (fs["steps"] + fs["steps3"]) / dt, "evaluated_per_s": fs["evaluated"] / dt, "last_kernel_us": ctx.last_kernel_ms() * 1e3,
+                     "failed_nodes": fr["failed"], "solutions": fr["solutions"], "trees": fr["trees"], "seeded_nodes": fr["seeded_nodes"], "launches": fr["launches"],
+                     "error": fr["error"], "trail_entries_max": finfo.get("trail_max"), "levels_max": finfo.get("levels_max"),
+                     "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "implicit_active", "set_mode", "grid", "lds_bytes")},
+                     "note": f"N-queens n={n} over IntervalSet<i32> domains (FDSpace): first {budget_f} nodes of the tree; the root is expanded breadth-first by the batched "
+                             f"search to {fr['trees']} open nodes ({fr['seeded_nodes']} nodes), then one tree per workgroup: the current node stays in LDS, "
+                             "backtracking undoes a trail (what VStoreTrail does); the timed region includes the expansion"})
+        # (b) the batched search of round 2 on the same workload: every node a 133 KB row in HBM, copied for each child
         budget, sb = 100_000, 1024
         ds = DeviceSearch(ctx, batch=sb, capacity=budget + 8 * sb, implicit=True)
-        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
         ds.run(lb0, ub0, all_solutions=True, node_limit=4 * sb, base=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = ds.run(lb0, ub0, all_solutions=True, node_limit=budget, base=1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        legs.append({"name": "C2-set-mode-device-search", "nodes": st.num_nodes, "seconds": dt, "us_per_node": dt / st.num_nodes * 1e6, "nodes_per_s": st.num_nodes / dt,
+        legs.append({"name": "C2-set-mode-batched-search", "nodes": st.num_nodes, "seconds": dt, "us_per_node": dt / st.num_nodes * 1e6, "nodes_per_s": st.num_nodes / dt,
                      "steps_per_s": st.filter_steps / dt, "evaluated_per_s": st.evaluated / dt, "last_kernel_us": ctx.last_kernel_ms() * 1e3,
                      "failed_nodes": st.num_failed_node, "solutions": st.num_solution, "rounds": st.rounds,
                      "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "team", "packed", "implicit_active", "set_mode", "grid")},
-                     "note": f"N-queens n={n} over IntervalSet<i32> domains (FDSpace): first {budget} nodes of the tree, batch {sb} nodes per round, implicit nodes of 133 KB (sets + bounds)"})
+                     "note": f"the same search with pcp_propagate_device + pcp_branch_device_set per round: first {budget} nodes, batch {sb} nodes per round, implicit nodes of 133 KB (sets + bounds)"})
         del ds
         ctx.set_model(n, props)
         ctx.set_hull(1, n)

@@ -606,6 +606,7 @@ __global__ void __launch_bounds__(kSetThreads) set_derive_active_kernel(const Se
 // Exactly the reference's left-first order within a tree; several trees = the subtrees of an open-node frontier, each on its CU.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kDfsFull = 0xFFFFFFFFu;
+constexpr uint32_t kDfsChunk = 8;  // nodes a tree reserves from the forest's counter at a time
 
 struct SetDfsCarve { SetCarve c; size_t touched, total; };
 __host__ __device__ inline SetDfsCarve set_dfs_carve(uint32_t V, uint32_t S, uint32_t sw, uint32_t cap) {
@@ -670,25 +671,63 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
   unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;
   uint32_t c_err = 0;
   bool finished = false;
+  uint32_t reserved = 0;       // nodes this tree may still run before it asks the forest's counter again
+  bool res_has_last = false;   // ... the last of which is the node that reaches the limit
   const bool neq_only = a.m.uniform_kind == PCP_NEQ && S == V;
   using DM = SetDomT<true>;
 
+  // a branch constraint folded into the variable's set: the values lo..hi leave it — one lane per word (one thread doing the up
+  // to set_words atomics and trail entries in turn was a quarter of a cheap node)
+  auto restrict_var = [&](uint32_t var, long long lo, long long hi) {
+    if (wv != 0) return;
+    long long b0 = lo - a.base, b1 = hi - a.base;
+    if (b0 < 0) b0 = 0;
+    if (b1 >= (long long)sw * 64) b1 = (long long)sw * 64 - 1;
+    bool changed = false;
+    for (long long k = (b0 >> 6) + lane; b0 <= b1 && k <= (b1 >> 6); k += 64) {
+      unsigned long long m = ~0ull;
+      if (k == (b0 >> 6)) m &= ~0ull << (b0 & 63);
+      if (k == (b1 >> 6)) m &= ~0ull >> (63 - (b1 & 63));
+      unsigned long long* w = &bits[(size_t)var * sw + k];
+      const unsigned long long gone = atomicAnd(w, ~m) & m;
+      if (gone) {
+        changed = true;
+        const uint32_t pos = atomicAdd(&misc[S_TRAILLEN], 1u);
+        if (pos < a.trail_cap) trail[pos] = make_uint4(var * sw + (uint32_t)k, var, (uint32_t)gone, (uint32_t)(gone >> 32));
+        else atomicOr(&misc[S_TRAILOVF], 1u);
+      }
+    }
+    if (__ballot(changed) != 0 && lane == 0) { atomicOr(&cur[var >> 5], 1u << (var & 31u)); ++narrow; }
+  };
+
   for (uint32_t step = 0; step < a.n_steps; ++step) {
     // ---- may this node run?  (stop flag of the forest, the node limit of all trees together: StopNode, stop_node.rs:57-62) ----
-    if (tid == 0) {
-      uint32_t go = 1, last = 0;
-      if (__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) go = 0;
-      else {
-        const unsigned long long old = atomicAdd(a.total_nodes, 1ull);
-        if (a.node_limit && old >= a.node_limit) { atomicAdd(a.total_nodes, ~0ull); atomicExch(a.stop, 1u); go = 0; }
-        // the node that reaches the limit is explored and counted, but StopNode replaces its status by EndOfSearch
-        // (stop_node.rs:55-62): it is neither a solution nor a failure
-        else if (a.node_limit && old + 1 >= a.node_limit) last = 1;
+    // Nodes are reserved kDfsChunk at a time from the forest's counter (two device-scope atomics and a barrier per node were a fifth
+    // of a cheap node); what a tree does not use goes back when the launch ends.  The node that reaches the limit is explored and
+    // counted, but StopNode replaces its status by EndOfSearch (stop_node.rs:55-62): it is neither a solution nor a failure.
+    if (reserved == 0) {
+      if (tid == 0) {
+        uint32_t got = 0, has_last = 0;
+        if (!__hip_atomic_load(a.stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          const unsigned long long want = min((unsigned long long)kDfsChunk, (unsigned long long)(a.n_steps - step));
+          const unsigned long long old = atomicAdd(a.total_nodes, want);
+          if (!a.node_limit) got = (uint32_t)want;
+          else if (old >= a.node_limit) atomicAdd(a.total_nodes, 0ull - want);
+          else {
+            got = (uint32_t)min(want, a.node_limit - old);
+            if (got < want) atomicAdd(a.total_nodes, 0ull - (want - got));
+            has_last = old + got >= a.node_limit ? 1u : 0u;
+          }
+        }
+        misc[S_CTL] = got; misc[S_CTL + 2] = has_last;
       }
-      misc[S_CTL] = go; misc[S_CTL + 2] = last; misc[S_OPEN] = 0; misc[S_TOTAL] = 0; misc[S_TOTAL2] = 0;  // (a node's last round leaves its count behind)
+      __syncthreads();
+      reserved = misc[S_CTL];
+      res_has_last = misc[S_CTL + 2] != 0;
+      if (!reserved) break;
     }
-    __syncthreads();
-    if (!misc[S_CTL]) break;
+    --reserved;
+    const bool last = res_has_last && reserved == 0;
 
     // ---- propagate ---------------------------------------------------------------------------------------------------------
     if (pending == kDfsFull && !misc[S_FAIL]) {
@@ -777,24 +816,52 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
     }
     __syncthreads();
     // ---- status (store.rs:250-256): failed / every propagator entailed / open -------------------------------------------------
+    // The candidate for branching first — the variable of minimal CARDINALITY > 1, first index (first_smallest_var.rs:30-39 on
+    // Domain::size()): an open node almost always has an open record in that variable's list, while the table's first records
+    // belong to the variables a dive assigned first and are all entailed.  Only when the list holds no open record is the whole
+    // table scanned (exact either way).
     const bool failed = misc[S_FAIL] != 0;
+    unsigned long long key = ~0ull;
     if (!failed) {
+      for (uint32_t v = tid; v < V; v += nth) {
+        unsigned long long size = 0;
+        for (uint32_t k = 0; k < sw; ++k) size += (unsigned long long)__popcll(bits[(size_t)v * sw + k]);
+        if (size > 1) key = min(key, (size << 32) | v);
+      }
+      for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+      unsigned long long* best = reinterpret_cast<unsigned long long*>(list_off);  // (idle between rounds; 16 x 8 bytes)
+      if (lane == 0) best[wv] = key;
+      __syncthreads();
+      key = best[0];
+      for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
       const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
-      for (uint32_t w = wv; w < words; w += nwv) {
-        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
-        const uint32_t r = (w << 6) + lane;
-        bool open_rec = false;
-        if (r < P) open_rec = !eval_set(a.m.recs[r], dm, true);
-        if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
+      if (key != ~0ull) {
+        const uint32_t u = (uint32_t)key, o0 = a.m.adj_off[u], o1 = a.m.adj_off[u + 1];
+        for (uint32_t i0 = o0 + wv * 64; i0 < o1; i0 += nth) {
+          if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+          bool open_rec = false;
+          if (i0 + lane < o1) open_rec = !eval_set(a.m.recs[a.m.adj[i0 + lane]], dm, true);
+          if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
+        }
+      }
+      __syncthreads();
+      if (!misc[S_OPEN]) {
+        for (uint32_t w = wv; w < words; w += nwv) {
+          if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+          const uint32_t r = (w << 6) + lane;
+          bool open_rec = false;
+          if (r < P) open_rec = !eval_set(a.m.recs[r], dm, true);  // at the fixpoint the filters are no-ops: only is_subsumed()
+          if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
+        }
       }
     }
     __syncthreads();
-    for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }  // (a failed node leaves marks behind)
+    if (failed)  // (only a failed node leaves marks behind; its backtrack has barriers before anything is marked again)
+      for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; }
     const bool open = misc[S_OPEN] != 0;
     const uint32_t tlen = misc[S_TRAILLEN];
     if (misc[S_TRAILOVF]) { c_err = 4; break; }  // the trail is full: the tree cannot be restored any more (terminal)
     ++c_nodes;
-    const bool last = misc[S_CTL + 2] != 0;
     bool descend = false;
     if (failed) {
       if (!last) ++c_fail;
@@ -809,30 +876,14 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
       }
       if (a.stop_on_solution && tid == 0) atomicExch(a.stop, 1u);
     } else {
-      // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter on sets: minimal CARDINALITY > 1, first index
-      unsigned long long key = ~0ull;
-      for (uint32_t v = tid; v < V; v += nth) {
-        unsigned long long size = 0;
-        for (uint32_t k = 0; k < sw; ++k) size += (unsigned long long)__popcll(bits[(size_t)v * sw + k]);
-        if (size > 1) key = min(key, (size << 32) | v);
-      }
-      for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
-      unsigned long long* best = reinterpret_cast<unsigned long long*>(list_off);  // (idle between rounds; 16 x 8 bytes)
-      if (lane == 0) best[wv] = key;
-      __syncthreads();
-      key = best[0];
-      for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
-      __syncthreads();
+      // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter on sets: the candidate found above
       if (key == ~0ull) { c_err = 3; --c_nodes; if (tid == 0) atomicAdd(a.total_nodes, ~0ull); break; }  // Unknown, yet nothing to branch on: the reference panics
       if (n_levels >= a.level_cap) { c_err = 1; --c_nodes; pending = kDfsFull; if (tid == 0) atomicAdd(a.total_nodes, ~0ull); break; }
       const uint32_t var = (uint32_t)key;
       const int2 d = bnd[var];
       const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27)
-      if (tid == 0) {
-        levels[n_levels] = make_uint4(var, (uint32_t)val, tlen, 0u);
-        const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
-        dm.clear_range(var, (long long)val + 1, d.y);  // the left child x <= val (binary_split.rs:46-57)
-      }
+      if (tid == 0) levels[n_levels] = make_uint4(var, (uint32_t)val, tlen, 0u);
+      restrict_var(var, (long long)val + 1, d.y);  // the left child x <= val (binary_split.rs:46-57)
       ++n_levels;
       pending = var;
       descend = true;
@@ -854,17 +905,14 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
         if ((touched[v >> 5] >> (v & 31u)) & 1u) bnd[v] = scan_bounds(bits + (size_t)v * sw, sw, a.base);
       __syncthreads();
       for (uint32_t i = tid; i < Wv; i += nth) touched[i] = 0;
-      if (tid == 0) {
-        const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, cur, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
-        const int2 d = bnd[lv.x];
-        dm.clear_range(lv.x, d.x, (long long)(int)lv.y);  // the right child x > val
-      }
+      restrict_var(lv.x, bnd[lv.x].x, (long long)(int)lv.y);  // the right child x > val
       pending = lv.x;
     }
-    if (last && tid == 0) atomicExch(a.stop, 1u);
+    if (tid == 0) { misc[S_OPEN] = 0; misc[S_TOTAL] = 0; misc[S_TOTAL2] = 0; if (last) atomicExch(a.stop, 1u); }  // (a node's last round leaves its count behind)
     if (last || (a.stop_on_solution && c_sols)) { __syncthreads(); break; }
     __syncthreads();
   }
+  if (reserved && tid == 0) atomicAdd(a.total_nodes, 0ull - (unsigned long long)reserved);  // what this tree reserved and did not run
 
   // ---- persist the tree: its current node, its stacks' lengths, its counters --------------------------------------------------
   __syncthreads();

@@ -360,7 +360,7 @@ class Context:
             self._check(self._L.pcp_dfs_forest_device_set(self._h, C.byref(st), int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit), C.c_void_p(stream)))
             launches += 1
             g = glob.cpu().tolist()  # (the launch's only synchronisation)
-            if (g[1] & 0xFFFFFFFF) or int(tree[:, 3].sum().item()) == T:
+            if (g[1] & 0xFFFFFFFF) or (node_limit and g[0] >= node_limit) or int(tree[:, 3].sum().item()) == T:
                 break
         cn = counters.cpu().numpy()
         g = glob.cpu().tolist()

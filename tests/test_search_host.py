@@ -261,3 +261,12 @@ def test_device_stack_balancing_gloo():
     assert sorted(t0 + t1) == sorted(list(range(23)) + [1000, 1001])  # every row exactly once
     assert t0 == list(range(d0, 23))  # rank 0 gave away its oldest rows
     assert t1[:d0] == list(range(d0)) and t1[d0:] == [1000, 1001]  # and they sit at the bottom of rank 1's stack
+
+
+def test_forest_budget_shares_add_up():
+    """search_forest.share_of_budget: the ranks' shares of a node limit differ by at most one and add up to what the expansion left."""
+    from pcp_amd.search_forest import share_of_budget
+    for limit, seeded, world in [(1000, 255, 1), (1000, 255, 8), (1_000_003, 4095, 8), (10, 50, 4), (0, 0, 2), (7, 0, 8)]:
+        shares = [share_of_budget(limit, seeded, r, world) for r in range(world)]
+        assert sum(shares) == max(limit - seeded, 0)
+        assert max(shares) - min(shares) <= 1

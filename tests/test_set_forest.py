@@ -136,3 +136,18 @@ def test_contract(ctx):
             ctx.dfs_forest_set(np.zeros((1, n, 1), np.uint64))
     finally:
         ctx.set_words = 0
+
+
+@pytest.mark.parametrize("n,trees", [(8, 4), (9, 16), (10, 64)])
+def test_forest_search_driver_single_and_two_ranks(ctx, n, trees):
+    """pcp_amd.search_forest.forest_search_set: expansion + forest = the oracle's complete FDSpace tree; two ranks (run one after the
+    other here) take alternate open nodes and their counters add up to the same tree."""
+    from pcp_amd.search_forest import forest_search_set
+    props, sw, lb0, ub0 = nqueens(ctx, n)
+    ss, _, _, _ = orc.OracleModel(n, props).search_set(lb0, ub0, sw, 1, all_solutions=True)
+    want = (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
+    one = forest_search_set(ctx, lb0, ub0, 1, n_trees=trees, steps_per_launch=32)
+    assert one["error"] == 0 and (one["nodes"], one["solutions"], one["failed"]) == want
+    parts = [forest_search_set(ctx, lb0, ub0, 1, n_trees=trees, steps_per_launch=32, rank=r, world=2) for r in range(2)]
+    assert all(p["error"] == 0 for p in parts) and all(p["trees"] > 0 for p in parts)
+    assert tuple(sum(p[k] for p in parts) for k in ("nodes", "solutions", "failed")) == want
