@@ -161,8 +161,8 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     ctx.set_hull(1, n)
     batch = args.search_batch
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
-    if set_mode:
-        return run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0)
+    if set_mode or args.engine == "forest":
+        return run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode)
     ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
     if world == 1 and not dist.is_initialized():
         # a single GPU still goes through the process group (RCCL with one rank): same driver, same exchange steps
@@ -208,21 +208,28 @@ def run_search_mode(args, torch, dist, world, rank, dev):
         }), flush=True)
 
 
-def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0):
-    """--mode search --domains set: every rank expands the root to the same frontier (no communication), takes the open nodes
+def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode=True):
+    """--mode search (--engine forest, and always with --domains set): every rank expands the root to the same frontier (no communication), takes the open nodes
     r, r + world, ... and searches each as a tree in one CU's LDS with an undo trail (pcp_amd.search_forest); one all_reduce of
     the counters at the end.  Subtrees are not re-balanced (N-queens-1000: no subtree ends within the budget)."""
-    from pcp_amd.search_forest import forest_search_set
+    from pcp_amd.search_forest import forest_search, forest_search_set
     n = args.n
-    trees = args.trees
-    forest_search_set(ctx, lb0, ub0, 1, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world)  # warm-up
+    trees = args.trees if args.trees else (512 if set_mode else 2048)
+    spl = args.steps_per_launch if args.steps_per_launch else (2048 if set_mode else 1024)
+    info = {}
+
+    def search(limit, steps):
+        if set_mode:
+            return forest_search_set(ctx, lb0, ub0, 1, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world, info=info)
+        return forest_search(ctx, lb0, ub0, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world)
+
+    search(4 * trees * world, 4)  # warm-up
     torch.cuda.synchronize()
     ctx.stats_reset()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    info = {}
-    fr = forest_search_set(ctx, lb0, ub0, 1, node_limit=args.node_budget, n_trees=trees, steps_per_launch=args.steps_per_launch, rank=rank, world=world, info=info)
+    fr = search(args.node_budget, spl)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -238,18 +245,20 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0):
     if rank == 0:
         _flush_c_stdio()
         print(json.dumps({
-            "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: parallel subtree search over FDSpace)",
+            "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: parallel subtree search" + (" over FDSpace)" if set_mode else ")"),
             "value": evaluated / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64" if set_mode else "i32", "data": "synthetic",
             "config": {
-                "workload": f"N-queens n={n} parallel subtree search over IntervalSet<i32> domains (FDSpace, the reference's default), first {args.node_budget} nodes of the tree "
-                            f"(all ranks together): the root is expanded breadth-first to {ntrees} open nodes, each the root of a tree searched depth-first by one workgroup "
-                            "(current node in LDS, undo trail in HBM: pcp_dfs_forest_device_set); no data-path collective",
+                "workload": f"N-queens n={n} parallel subtree search over " + ("IntervalSet<i32> domains (FDSpace, the reference's default)" if set_mode else "Interval<i32> domains")
+                            + f", about the first {args.node_budget} nodes of the tree (all ranks together; `nodes` is the exact count): the root is expanded breadth-first to {ntrees} open nodes, "
+                            "each the root of a tree searched depth-first by one workgroup ("
+                            + ("current node in LDS, undo trail in HBM: pcp_dfs_forest_device_set" if set_mode else "current node in LDS, stack rows in HBM: pcp_dfs_forest_device")
+                            + "); no data-path collective",
                 "value_is": "filter steps EXECUTED per second, all ranks (pcp_stats.evaluated); steps_reference_equivalent_per_s = every propagator of every node once "
                             "(init_scheduler) plus the wake-ups",
                 "steps_reference_equivalent_per_s": steps / dt, "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails,
-                "trees": ntrees, "steps_per_launch": args.steps_per_launch, "launches_rank0": fr["launches"], "error": err,
-                "trail_entries_max_rank0": info.get("trail_max"), "levels_max_rank0": info.get("levels_max"), "domains": "set",
+                "trees": ntrees, "steps_per_launch": spl, "launches_rank0": fr["launches"], "error": err, "engine": "forest",
+                "trail_entries_max_rank0": info.get("trail_max"), "levels_max_rank0": info.get("levels_max"), "domains": "set" if set_mode else "interval",
                 "parallelism": f"subtrees sharded over {world} GPU(s)",
             },
         }), flush=True)
@@ -283,8 +292,11 @@ def main():
     ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
     ap.add_argument("--search-batch", type=int, default=4096)
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
-    ap.add_argument("--trees", type=int, default=512, help="--mode search --domains set: trees (workgroups) per GPU")
-    ap.add_argument("--steps-per-launch", type=int, default=2048, help="--mode search --domains set: nodes per tree and launch")
+    ap.add_argument("--engine", choices=["forest", "worklist"], default="forest",
+                    help="--mode search: forest = one in-kernel DFS per open node of a frontier, no exchange (default; the only engine for --domains set); "
+                         "worklist = batched rounds with the open-node stacks balanced GPU-to-GPU over RCCL")
+    ap.add_argument("--trees", type=int, default=0, help="--mode search, forest: trees (workgroups) per GPU (0 = 2048 for intervals, 512 for sets)")
+    ap.add_argument("--steps-per-launch", type=int, default=0, help="--mode search, forest: nodes per tree and launch (0 = 1024 for intervals, 2048 for sets)")
     ap.add_argument("--domains", choices=["interval", "set"], default="interval",
                     help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
     args = ap.parse_args()

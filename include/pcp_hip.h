@@ -255,6 +255,13 @@ typedef struct {
   int32_t* first_solution;
 } pcp_dfs_state;
 int32_t pcp_dfs_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
+/* The same loop on n_trees independent stacks at once, one workgroup per tree (ABI v5): tree t is exactly a pcp_dfs_device instance on
+ *   lb, ub [n_trees][capacity][n_vars] (tree t's rows start at t * capacity), sp / stop [n_trees], status [n_trees][capacity],
+ *   counters [n_trees][5], first_solution [n_trees][n_vars] or NULL;  node_limit applies to each tree.
+ * The trees are the subtrees below the open nodes of a frontier (pcp_propagate_device + pcp_branch_device produce one); the caller adds
+ * up the counters and decides when to stop launching (all sp == 0, any stop != 0, its node budget).  All-XNeqY models over implicit
+ * nodes only (PCP_ERR_UNSUPPORTED otherwise: pcp_dfs_device runs any interval model, one tree). */
+int32_t pcp_dfs_forest_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_trees, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
 
 /* ---- the same loop over FDSpace (set mode), a FOREST of trees, one per workgroup (ABI v5) --------------------------------------
  * ≡ the engine above over VStoreSet = VStoreTrail<IntervalSet<i32>> (variable/mod.rs:38): like the reference, a node is restored

@@ -1152,6 +1152,49 @@ int32_t pcp_dfs_forest_device_set(pcp_ctx* c, const pcp_forest_state* st, uint32
   return PCP_OK;
 }
 
+// The search loop of an all-XNeqY model inside the kernel (neqfix_kernel<.., DFS>): workgroup t runs tree t, n_steps nodes per launch.
+// Returns 1 when launched, 0 when this model / store cannot take the path, < 0 on error.
+static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_trees, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, hipStream_t stream) {
+  if (!(c->neq_model && c->opt_neq_path && c->opt_neq_dfs)) return 0;
+  const uint32_t S = c->n_slots, V = c->n_vars;
+  // 32-bit cells: a one-node tile has LDS to spare, and the 16-bit-cell instantiation of the search loop needs 147 VGPRs — one
+  // 512-thread workgroup per CU — where this one needs 115: two trees per CU in a forest, no scratch either way
+  const bool packed = false;
+  const size_t lds = lds_bytes_neq(S, V, 1, packed, 2);
+  if (!lds || lds > c->lds_max || !n_steps) return 0;
+  NeqArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
+  a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
+  a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
+  a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
+  a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.lds_wgs = 2;
+  a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
+  a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
+  a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
+  LaunchPlan plan;
+  plan.grid = n_trees; plan.block = 512; plan.lds_bytes = lds;
+  c->last_plan = pcp_plan{1u, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, n_trees, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
+  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  HIP_TRY(c, launch_neqfix(a, plan, stream));
+  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  c->ev_valid = true;
+  return 1;
+}
+
+int32_t pcp_dfs_forest_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_trees, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream) {
+  if (!c || !st) return PCP_ERR_ARG;
+  if (c->set_words) return fail(c, PCP_ERR_ARG, "pcp_dfs_forest_device runs interval-mode models (sets: pcp_dfs_forest_device_set)");
+  if (!n_trees || !st->lb || !st->ub || !st->sp || !st->stop || !st->status || !st->counters || st->capacity < 2) return fail(c, PCP_ERR_ARG, "null buffer / no tree / capacity < 2");
+  HIP_TRY(c, hipSetDevice(c->device));
+  { const int32_t rcf = finalize_model(c); if (rcf) return rcf; }
+  if (c->opt_force_path) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_dfs_forest_device: force_path is set");
+  const int32_t rc = launch_neq_dfs(c, st, n_trees, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
+  if (rc < 0) return rc;
+  if (rc == 0 && n_steps) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_dfs_forest_device needs an all-XNeqY model whose variable store fits the in-kernel search (pcp_dfs_device runs any model, one tree)");
+  return PCP_OK;
+}
+
 int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream) {
   if (!c || !st) return PCP_ERR_ARG;
   if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_dfs_device runs interval-mode models only");
@@ -1162,31 +1205,12 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   const int64_t keep_path = c->opt_force_path;
   HIP_TRY(c, hipSetDevice(c->device));
   { const int32_t rcf = finalize_model(c); if (rcf) return rcf; }
-  if (!keep_path && c->neq_model && c->opt_neq_path && c->opt_neq_dfs) {
+  if (!keep_path) {
     // an all-XNeqY model: the whole loop — pop, propagate, count, branch — runs in ONE workgroup, n_steps nodes per launch
     // (neqfix_kernel<.., DFS>); a node is the lists of its assigned variables, there is no sweep to share out over the chip
-    const uint32_t S = c->n_slots, V = c->n_vars;
-    const bool hull_fits16 = c->hull_set && c->hull_lo >= -kPackedMax && c->hull_hi <= kPackedMax;
-    const bool packed = hull_fits16 && c->consts_fit16 && c->opt_packed;
-    const size_t lds = lds_bytes_neq(S, V, 1, packed, 2);
-    if (lds && lds <= c->lds_max && n_steps) {
-      NeqArgs a;
-      memset(&a, 0, sizeof(a));
-      a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
-      a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
-      a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
-      a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
-      a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.lds_wgs = 2;
-      a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
-      a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
-      a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
-      LaunchPlan plan;
-      plan.grid = 1; plan.block = 512; plan.lds_bytes = lds;
-      c->last_plan = pcp_plan{1u, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, 1u, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
-      c->ev_valid = false;
-      HIP_TRY(c, launch_neqfix(a, plan, reinterpret_cast<hipStream_t>(hip_stream)));
-      return PCP_OK;
-    }
+    const int32_t rcn = launch_neq_dfs(c, st, 1u, n_steps, stop_on_solution, node_limit, reinterpret_cast<hipStream_t>(hip_stream));
+    if (rcn < 0) return rcn;
+    if (rcn == 1) return PCP_OK;
   }
   // one node per step: the team geometry unless the caller forced a path — or the model takes the assignment-driven kernel, which
   // has no sweep to share out (a node is one workgroup: its assigned variables' lists)

@@ -286,8 +286,15 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   bool adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
-  const int32_t* const stack_lb = a.lb_in;
+  // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
+  // the forest of one tree; pcp_dfs_forest_device launches many, each an independent instance of the same loop)
+  const size_t tree_row0 = DFS ? (size_t)blockIdx.x * a_in.dfs.capacity : 0;
+  if constexpr (DFS) {
+    a.dfs.sp += blockIdx.x; a.dfs.stop += blockIdx.x; a.dfs.counters += (size_t)blockIdx.x * 5;
+    if (a.dfs.first_solution) a.dfs.first_solution += (size_t)blockIdx.x * V;
+  }
   unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;  // DFS: the search counters, replicated in every thread
+  unsigned long long acc_steps = 0, acc_narrow = 0, acc_ev = 0, acc_full = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;  // DFS: pcp_stats, per launch
   uint32_t c_err = 0;
   if constexpr (DFS) { dfs_sp = *a.dfs.sp; dfs_stop = *a.dfs.stop; c_nodes = a.dfs.counters[0]; c_sols = a.dfs.counters[1]; c_fail = a.dfs.counters[2]; }
   const int lim = PACKED ? kPackedMax : kBoundMax;
@@ -295,8 +302,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   bool resume = false;
   if constexpr (DFS) {
     if (dfs_sp == 0 || dfs_stop || dfs_it >= a.dfs.n_steps) break;
-    const size_t off = (size_t)(dfs_sp - 1) * V;
-    a.lb_in = stack_lb + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + (dfs_sp - 1);
+    const size_t off = (tree_row0 + (dfs_sp - 1)) * V;
+    a.lb_in = a_in.lb_in + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + tree_row0 + (dfs_sp - 1);
     resume = dfs_resume_var != 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
@@ -799,21 +806,27 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const uint32_t active_nodes = (uint32_t)__popc(((nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~misc[N_OOB]));
     // reference-equivalent steps: every propagator of every node once (init_scheduler) + every wake-up of the later rounds
     const unsigned long long s2 = (unsigned long long)active_nodes * a.m.n_recs + *reinterpret_cast<unsigned long long*>(&misc[N_STEPS]);
-    atomicAdd((unsigned long long*)&a.stats->steps, s2);
-    if (misc[N_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[N_NARROW]);
     const unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[N_EV]), sfu = *reinterpret_cast<unsigned long long*>(&misc[N_FULL]);
-    if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
-    if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
-    if (ptime) {
-      atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(pt1 - pt0));        // staging
-      atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)(pt2 - pt1));  // rounds
-      atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(pt3 - pt2));         // status scan
-      atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)(__builtin_amdgcn_s_memtime() - pt3));  // write-back, counters
-    }
-    if (!(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
-    atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
     const uint32_t nf = __popc(misc[N_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)));
-    if (nf && !(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    if constexpr (DFS) {
+      // the search loop adds its counters up in registers and hands them over once per launch: six same-address atomics per node
+      // are nothing for one tree and serialise a forest of hundreds (pcp_dfs_forest_device)
+      acc_steps += s2; acc_narrow += misc[N_NARROW]; acc_ev += sev; acc_full += sfu; acc_waves += nb + misc[N_WAVES]; acc_nodes += nb; acc_failed += nf;
+    } else {
+      atomicAdd((unsigned long long*)&a.stats->steps, s2);
+      if (misc[N_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[N_NARROW]);
+      if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
+      if (sfu) atomicAdd((unsigned long long*)&a.stats->full_evals, sfu);
+      if (ptime) {
+        atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(pt1 - pt0));        // staging
+        atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)(pt2 - pt1));  // rounds
+        atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(pt3 - pt2));         // status scan
+        atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)(__builtin_amdgcn_s_memtime() - pt3));  // write-back, counters
+      }
+      if (!(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
+      atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
+      if (nf && !(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)nf);
+    }
   }
   if constexpr (!DFS) {
     break;
@@ -881,6 +894,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   }  // the DFS loop (one pass otherwise)
   if constexpr (DFS) {
     if (tid == 0) {
+      if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
+      if (acc_narrow) atomicAdd((unsigned long long*)&a.stats->narrowings, acc_narrow);
+      if (acc_ev) atomicAdd((unsigned long long*)&a.stats->evaluated, acc_ev);
+      if (acc_full) atomicAdd((unsigned long long*)&a.stats->full_evals, acc_full);
+      if (acc_waves) atomicAdd((unsigned long long*)&a.stats->waves, acc_waves);
+      if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
+      if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
       *a.dfs.sp = dfs_sp; *a.dfs.stop = dfs_stop;
       a.dfs.counters[0] = c_nodes; a.dfs.counters[1] = c_sols; a.dfs.counters[2] = c_fail;
       if (c_err) a.dfs.counters[3] = c_err;
@@ -911,7 +931,7 @@ static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.nodes_per_block == 0 || a.nodes_per_block > 16 || a.m.n_slots >= 65536u || !a.m.adjp) return hipErrorInvalidValue;
   if (a.dfs.n_steps) {
-    if (a.nodes_per_block != 1 || p.grid != 1 || !a.dfs.sp || !a.dfs.stop || !a.dfs.counters) return hipErrorInvalidValue;
+    if (a.nodes_per_block != 1 || p.grid < 1 || !a.dfs.sp || !a.dfs.stop || !a.dfs.counters) return hipErrorInvalidValue;  // (grid = trees)
     return launch_neq_d<true>(a, p, stream);
   }
   return launch_neq_d<false>(a, p, stream);

@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -117,13 +117,14 @@ def load_library():
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
+    L.pcp_dfs_forest_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, u32, C.c_uint64, vp]
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -327,6 +328,42 @@ class Context:
         sp, stop = state.cpu().tolist()
         return {"nodes": cn[0], "solutions": cn[1], "failed": cn[2], "error": cn[3], "open": sp, "stopped": bool(stop), "steps_enqueued": done,
                 "first_solution": sol.cpu().numpy() if cn[1] else None}
+
+    def dfs_forest(self, root_lb, root_ub, stop_on_solution: bool = False, node_limit_per_tree: int = 0, steps_per_launch: int = 256, capacity: int = 2048,
+                   max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False):
+        """pcp_dfs_forest_device: the reference's search loop (interval mode, all-XNeqY models) on many subtrees at once, one workgroup per
+        tree, each exactly a pcp_dfs_device instance.  root_lb / root_ub: [n_trees, n_vars] int32 (numpy or CUDA tensors): the roots, not yet
+        propagated.  Launches of steps_per_launch nodes per tree are repeated until every stack is empty, a tree stopped (solution with
+        stop_on_solution / error / its node limit), node_budget nodes were explored by all trees together (checked between launches) or
+        max_launches is reached.  Returns dict(nodes, solutions, failed, error, open, launches, per_tree=[n_trees, 5], first_solutions)."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        V = self.n_vars
+        to_dev = lambda x: (torch.from_numpy(np.ascontiguousarray(x, np.int32)) if isinstance(x, np.ndarray) else x).to(dev).reshape(-1, V)
+        rl, ru = to_dev(root_lb), to_dev(root_ub)
+        T = rl.shape[0]
+        lb = torch.empty((T, capacity, V), dtype=torch.int32, device=dev)
+        ub = torch.empty((T, capacity, V), dtype=torch.int32, device=dev)
+        lb[:, 0] = rl; ub[:, 0] = ru
+        sp = torch.ones(T, dtype=torch.int32, device=dev)
+        stop = torch.zeros(T, dtype=torch.int32, device=dev)
+        status = torch.zeros((T, capacity), dtype=torch.uint8, device=dev)
+        counters = torch.zeros((T, 5), dtype=torch.int64, device=dev)
+        sol = torch.zeros((T, V), dtype=torch.int32, device=dev) if want_solution else None
+        st = DfsState(lb.data_ptr(), ub.data_ptr(), capacity, sp.data_ptr(), stop.data_ptr(), status.data_ptr(), counters.data_ptr(), sol.data_ptr() if want_solution else None)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        launches = 0
+        while launches < max_launches:
+            self._check(self._L.pcp_dfs_forest_device(self._h, C.byref(st), T, int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit_per_tree), C.c_void_p(stream)))
+            launches += 1
+            live = (sp > 0) & (stop == 0)
+            summary = torch.stack([live.sum(), counters[:, 0].sum(), counters[:, 1].sum(), counters[:, 3].max()]).cpu().tolist()  # (the launch's only synchronisation)
+            if summary[0] == 0 or summary[3] or (stop_on_solution and summary[2]) or (node_budget and summary[1] >= node_budget):
+                break
+        cn = counters.cpu().numpy()
+        return {"nodes": int(cn[:, 0].sum()), "solutions": int(cn[:, 1].sum()), "failed": int(cn[:, 2].sum()), "error": int(cn[:, 3].max()),
+                "open": int(sp.sum().item()), "launches": launches, "per_tree": cn, "trees": T,
+                "first_solutions": sol.cpu().numpy() if want_solution else None}
 
     def dfs_forest_set(self, root_bits, stop_on_solution: bool = False, node_limit: int = 0, steps_per_launch: int = 256,
                        level_capacity: int = 4096, trail_capacity: int = 1 << 20, max_launches: int = 1 << 30, want_solution: bool = True,

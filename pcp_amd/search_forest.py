@@ -56,3 +56,35 @@ def forest_search_set(ctx, lb0, ub0, base: int = 0, node_limit: int = 0, n_trees
     out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]
     out["error"] = r["error"]; out["launches"] = r["launches"]
     return out
+
+
+def seed_roots_interval(ctx, lb0, ub0, want: int):
+    """Interval mode: breadth-first expansion of the root to at least `want` open nodes.  Returns (lb rows, ub rows, stats)."""
+    from .search_device import DeviceSearch
+    ds = DeviceSearch(ctx, batch=max(want, 1), capacity=4 * max(want, 1) + 64, implicit=True)
+    ds.reset(lb0, ub0)
+    while 0 < ds.size < want:
+        if ds.advance(all_solutions=True, max_rounds=1, keep_solutions=0):
+            break
+    ds.compact()
+    k = ds.size
+    return ds.lb[:k].clone(), ds.ub[:k].clone(), ds.stats
+
+
+def forest_search(ctx, lb0, ub0, node_limit: int = 0, n_trees: int = 768, steps_per_launch: int = 512, rank: int = 0, world: int = 1, capacity: int = 0) -> dict:
+    """Interval mode, all-XNeqY models: expansion + one in-kernel DFS per open node (pcp_dfs_forest_device).  The node limit is checked
+    between launches (each tree may also stop at its share of it), so `nodes` can exceed it by less than one launch; it is the exact count."""
+    rl, ru, st = seed_roots_interval(ctx, lb0, ub0, n_trees * world)
+    ml, mu = rl[rank::world].contiguous(), ru[rank::world].contiguous()
+    out = {"seeded_nodes": st.num_nodes if rank == 0 else 0, "trees": int(ml.shape[0]), "launches": 0,
+           "nodes": st.num_nodes if rank == 0 else 0, "solutions": st.num_solution if rank == 0 else 0, "failed": st.num_failed_node if rank == 0 else 0, "error": 0}
+    budget = share_of_budget(node_limit, st.num_nodes, rank, world) if node_limit else 0
+    if (node_limit and budget == 0) or ml.shape[0] == 0:
+        return out
+    per_tree = -(-budget // ml.shape[0]) if budget else 0
+    if not capacity:  # a tree's stack grows by one row per open node it explores: its share of the budget, or 2048 rows without one
+        capacity = per_tree + 64 if per_tree else 2048
+    r = ctx.dfs_forest(ml, mu, node_limit_per_tree=per_tree, steps_per_launch=steps_per_launch, capacity=capacity, node_budget=budget)
+    out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]
+    out["error"] = r["error"]; out["launches"] = r["launches"]
+    return out

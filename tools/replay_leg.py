@@ -2,7 +2,7 @@
 batches are built by thousands of one-node launches, which made the PMC passes of round 2 abort):
    python tools/replay_leg.py save deep500 deep3000     # build the batches once, un-profiled, into /tmp on the GPU box
    python tools/replay_leg.py run deep500 [launches]    # load and launch: in place on fresh copies, HIP-event time per launch
-   python tools/replay_leg.py run c3 | c4 | frontier | search   # these build their input with a handful of launches"""
+   python tools/replay_leg.py run c3 | c4 | frontier | search | setforest   # these build their input with a handful of launches"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -69,6 +69,18 @@ else:
         ds.reset(np.ones(n, np.int32), np.full(n, n, np.int32))
         ds.advance(max_rounds=40)   # ~30 full rounds of 4096 nodes: propagate + branch per round
         print(json.dumps({"leg": nm, "nodes": ds.stats.num_nodes, "rounds": ds.stats.rounds}))
+        sys.exit(0)
+    elif nm == "setforest":
+        # the set-mode forest (pcp_dfs_forest_device_set): 512 trees, launches of 256 nodes per tree, 200 000 nodes
+        import time
+        from pcp_amd.search_forest import forest_search_set
+        sw = (n + 63) // 64
+        ctx.set_model(n, M.nqueens_props(n), set_words=sw); ctx.set_hull(1, n)
+        t0 = time.perf_counter()
+        r = forest_search_set(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), 1, node_limit=200_000, n_trees=512, steps_per_launch=256, trail_capacity=1 << 19)
+        torch.cuda.synchronize()
+        print(json.dumps({"leg": nm, "nodes": r["nodes"], "trees": r["trees"], "launches": r["launches"], "seconds_incl_expansion_and_allocation": time.perf_counter() - t0,
+                          "last_kernel_ms": ctx.last_kernel_ms(), "plan": ctx.last_plan()}))
         sys.exit(0)
     else:
         raise SystemExit(nm)
