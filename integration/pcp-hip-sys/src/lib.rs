@@ -155,6 +155,8 @@ extern "C" {
     pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
                                  status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
                                  hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains
+    pub fn pcp_dfs_forest_device(ctx: *mut pcp_ctx, st: *const pcp_dfs_state, n_trees: u32, n_steps: u32, stop_on_solution: u32, node_limit: u64,
+                                 hip_stream: *mut c_void) -> i32; // st's arrays are [n_trees]-strided: tree t is a pcp_dfs_device instance
     pub fn pcp_dfs_forest_device_set(ctx: *mut pcp_ctx, st: *const pcp_forest_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
                                      hip_stream: *mut c_void) -> i32;
     pub fn pcp_dfs_device(ctx: *mut pcp_ctx, st: *const pcp_dfs_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,

@@ -70,6 +70,17 @@ else:
         ds.advance(max_rounds=40)   # ~30 full rounds of 4096 nodes: propagate + branch per round
         print(json.dumps({"leg": nm, "nodes": ds.stats.num_nodes, "rounds": ds.stats.rounds}))
         sys.exit(0)
+    elif nm == "neqforest":
+        # the interval-mode forest (pcp_dfs_forest_device): 2048 trees, 256 nodes per tree and launch, 500 000 nodes
+        import time
+        from pcp_amd.search_forest import forest_search
+        nq()
+        t0 = time.perf_counter()
+        r = forest_search(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), node_limit=500_000, n_trees=2048, steps_per_launch=256)
+        torch.cuda.synchronize()
+        print(json.dumps({"leg": nm, "nodes": r["nodes"], "trees": r["trees"], "launches": r["launches"], "seconds_incl_expansion_and_allocation": time.perf_counter() - t0,
+                          "last_kernel_ms": ctx.last_kernel_ms(), "plan": ctx.last_plan()}))
+        sys.exit(0)
     elif nm == "setforest":
         # the set-mode forest (pcp_dfs_forest_device_set): 512 trees, launches of 256 nodes per tree, 200 000 nodes
         import time
