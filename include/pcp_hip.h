@@ -272,7 +272,7 @@ int32_t pcp_dfs_forest_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_
  * produce one), searched concurrently; n_trees = 1 with the root in bits[0] IS the reference's search.  One call runs at most
  * n_steps nodes per tree; the caller repeats it until every tree is finished, `stop` is raised, or the budget is spent.
  *   bits        : [n_trees][n_vars][set_words] device: in = each tree's root, afterwards each tree's current node
- *   tree        : [n_trees][4] device uint32 = { levels, trail length, pending variable, finished }; the caller initialises every
+ *   tree        : [n_trees][4] device uint32 = { levels, trail length, pending variable, finished | given << 8 }; the caller initialises every
  *                 tree to { 0, 0, PCP_DFS_FULL, 0 } (PCP_DFS_FULL: the current node has not been propagated at all)
  *   levels      : [n_trees][level_capacity][4] device uint32: the branch decisions whose right child is still open
  *   trail       : [n_trees][trail_capacity][4] device uint32
@@ -297,6 +297,13 @@ typedef struct {
   uint32_t* solution_flag;
 } pcp_forest_state;
 int32_t pcp_dfs_forest_device_set(pcp_ctx* ctx, const pcp_forest_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
+/* Between two calls of pcp_dfs_forest_device_set: finished trees take over work from trees that still have some.  pairs = n_pairs x
+ * (donor, receiver) tree indices (device uint32).  For every pair whose receiver is finished and whose donor has an open right branch
+ * left, the donor's OLDEST open right branch (the subtree nearest its root) becomes the receiver's new root — built from the donor's
+ * current node and its trail — and done[pair] = 1; otherwise done[pair] = 0 and nothing changes.  The donor skips that branch when it
+ * backtracks to it; counters are untouched, so the sum over the trees stays the search's.  A tree may appear in one pair per call.
+ * tree[t][3] = finished (bit 0) | number of levels given away (bits 8..). */
+int32_t pcp_dfs_forest_split_set(pcp_ctx* ctx, const pcp_forest_state* st, uint32_t n_pairs, const uint32_t* pairs, uint32_t* done, void* hip_stream);
 
 /* Counters accumulate on the device across pcp_propagate_device calls.  pcp_stats_reset also clears the sticky hull-violation word;
  * pcp_stats_read is the only call that reports (and then clears) it. */

@@ -1152,6 +1152,21 @@ int32_t pcp_dfs_forest_device_set(pcp_ctx* c, const pcp_forest_state* st, uint32
   return PCP_OK;
 }
 
+int32_t pcp_dfs_forest_split_set(pcp_ctx* c, const pcp_forest_state* st, uint32_t n_pairs, const uint32_t* pairs, uint32_t* done, void* hip_stream) {
+  if (!c || !st) return PCP_ERR_ARG;
+  if (!c->set_words) return fail(c, PCP_ERR_ARG, "pcp_dfs_forest_split_set needs a set-mode model");
+  if (!st->n_trees || !st->bits || !st->tree || !st->levels || !st->trail || (n_pairs && (!pairs || !done))) return fail(c, PCP_ERR_ARG, "null buffer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  SetDfsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m.n_vars = c->n_vars; a.m.n_slots = c->n_slots;
+  a.set_words = c->set_words; a.base = c->hull_lo;
+  a.n_trees = st->n_trees; a.level_cap = st->level_capacity; a.trail_cap = st->trail_capacity;
+  a.bits = st->bits; a.tree = st->tree; a.levels = reinterpret_cast<uint4*>(st->levels); a.trail = reinterpret_cast<uint4*>(st->trail);
+  HIP_TRY(c, launch_setdfs_split(a, n_pairs, pairs, done, reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
+}
+
 // The search loop of an all-XNeqY model inside the kernel (neqfix_kernel<.., DFS>): workgroup t runs tree t, n_steps nodes per launch.
 // Returns 1 when launched, 0 when this model / store cannot take the path, < 0 on error.
 static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_trees, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, hipStream_t stream) {

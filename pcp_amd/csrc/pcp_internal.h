@@ -194,6 +194,7 @@ struct SetDfsArgs {
 };
 size_t lds_bytes_set_dfs(uint32_t n_vars, uint32_t n_slots, uint32_t set_words, uint32_t list_cap);
 hipError_t launch_setdfs(const SetDfsArgs& a, hipStream_t stream);
+hipError_t launch_setdfs_split(const SetDfsArgs& a, uint32_t n_pairs, const uint32_t* pairs, uint32_t* done, hipStream_t stream);
 
 hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t* child_base, uint32_t* counts, hipStream_t stream);
 // Set-mode branching: FirstSmallestVar by CARDINALITY, MiddleVal on the bounds, BinarySplit on the sets.

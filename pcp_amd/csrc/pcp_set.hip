@@ -608,12 +608,13 @@ __global__ void __launch_bounds__(kSetThreads) set_derive_active_kernel(const Se
 constexpr uint32_t kDfsFull = 0xFFFFFFFFu;
 constexpr uint32_t kDfsChunk = 8;  // nodes a tree reserves from the forest's counter at a time
 
-struct SetDfsCarve { SetCarve c; size_t touched, total; };
+struct SetDfsCarve { SetCarve c; size_t touched, adjo, total; };
 __host__ __device__ inline SetDfsCarve set_dfs_carve(uint32_t V, uint32_t S, uint32_t sw, uint32_t cap) {
   SetDfsCarve d;
   d.c = set_carve(V, S, sw, cap);
   d.touched = d.c.total;
-  d.total = (d.touched + ((size_t)(S + 31) / 32) * 4 + 15) & ~(size_t)15;
+  d.adjo = (d.touched + ((size_t)(S + 31) / 32) * 4 + 15) & ~(size_t)15;   // a copy of adj_off[V + 1]: no global load in a node's chains for it
+  d.total = (d.adjo + ((size_t)V + 1) * 4 + 15) & ~(size_t)15;
   return d;
 }
 
@@ -634,11 +635,13 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
   uint32_t* list_deg = reinterpret_cast<uint32_t*>(smem + cv.list_deg);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
   uint32_t* touched = reinterpret_cast<uint32_t*>(smem + dcv.touched);
+  uint32_t* adjo = reinterpret_cast<uint32_t*>(smem + dcv.adjo);
   const uint32_t t = blockIdx.x;
   pcp_stats* const st_slot = a.stats + (blockIdx.x & (kStatSlots - 1));
   uint32_t* const tree = a.tree + (size_t)t * 4;
   uint32_t n_levels = tree[0], pending = tree[2];
-  if (tree[3]) return;  // this tree is finished
+  if (tree[3] & 1u) return;  // this tree is finished
+  const uint32_t given0 = tree[3] >> 8;  // its oldest levels whose right branch went to another tree (setdfs_split_kernel)
   uint4* const trail = a.trail + (size_t)t * a.trail_cap;
   uint4* const levels = a.levels + (size_t)t * a.level_cap;
   unsigned long long* const gbits = reinterpret_cast<unsigned long long*>(a.bits) + (size_t)t * V * sw;
@@ -646,6 +649,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
   // ---- the tree's current node into LDS, its bounds ------------------------------------------------------------------------
   if (tid < 32) misc[tid] = 0;
   for (uint32_t i = tid; i < Wv; i += nth) { cur[i] = 0; nxt[i] = 0; touched[i] = 0; }
+  for (uint32_t v = tid; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
   {
     const uint32_t nwords = V * sw;
     if (!(nwords & 1u) && !((size_t)gbits & 15)) {
@@ -675,6 +679,20 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
   bool res_has_last = false;   // ... the last of which is the node that reaches the limit
   const bool neq_only = a.m.uniform_kind == PCP_NEQ && S == V;
   using DM = SetDomT<true>;
+  // a record as seen from variable v's list, entry idx: binary models rebuild it from the 8-byte adjacency payload (one coalesced load
+  // instead of an index load and the gather that depends on it)
+  const bool use_pay = a.m.adjp != nullptr && !a.m.has_ternary;
+  auto rec_at = [&](uint32_t v, uint32_t idx) -> Rec {
+    if (use_pay) {
+      const uint2 q = a.m.adjp[idx];
+      const uint32_t other = q.x & kSlotMask, kind = (q.x >> 28) & 7u;
+      const bool is_y = (q.x >> 31) != 0;
+      Rec rc;
+      rc.xk = (is_y ? other : v) | (kind << 28); rc.y = is_y ? v : other; rc.z = 0; rc.d = (int32_t)q.y;
+      return rc;
+    }
+    return a.m.recs[a.m.adj[idx]];
+  };
 
   // a branch constraint folded into the variable's set: the values lo..hi leave it — one lane per word (one thread doing the up
   // to set_words atomics and trail entries in turn was a quarter of a cheap node)
@@ -745,8 +763,8 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
         bulk = ns <= C;
         if (bulk)
           for (uint32_t e = 0; e < ns; ++e) {
-            const uint32_t v = list_id[e], o0 = a.m.adj_off[v], o1 = a.m.adj_off[v + 1];
-            for (uint32_t i = o0 + tid; i < o1; i += nth) { (void)eval_set(a.m.recs[a.m.adj[i]], dm, false); ++ev; }
+            const uint32_t v = list_id[e], o0 = adjo[v], o1 = adjo[v + 1];
+            for (uint32_t i = o0 + tid; i < o1; i += nth) { (void)eval_set(rec_at(v, i), dm, false); ++ev; }
           }
       }
       if (!bulk)
@@ -773,7 +791,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
           if (v < V && neq_only) { const int2 b = bnd[v]; if (b.x != b.y) { dropped |= 1u << (v & 31); continue; } }
           const uint32_t pos = atomicAdd(&misc[m_total], 1u);
           if (pos < C) {
-            const uint32_t o0 = (v < V) ? a.m.adj_off[v] : 0u, o1 = (v < V) ? a.m.adj_off[v + 1] : 0u;
+            const uint32_t o0 = (v < V) ? adjo[v] : 0u, o1 = (v < V) ? adjo[v + 1] : 0u;
             list_id[pos] = v; list_off[pos] = o0; list_deg[pos] = o1 - o0;
           }
         }
@@ -784,8 +802,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
       if (total == 0 || misc[S_FAIL]) break;
       if (tid == 0) misc[(round & 1u) ? S_TOTAL : S_TOTAL2] = 0;
       const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
-      auto run = [&](uint32_t v, uint32_t r) {  // FIFO dedup as in setfix_kernel: the lowest changed variable of a record runs it
-        const Rec rec = a.m.recs[r];
+      auto run = [&](uint32_t v, const Rec rec) {  // FIFO dedup as in setfix_kernel: the lowest changed variable of a record runs it
         const uint32_t x = rec.xk & kSlotMask;
         const bool tern = (rec.xk >> 28) > PCP_LT;
         if (x < v && ((cur[x >> 5] >> (x & 31)) & 1u)) return;
@@ -797,7 +814,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
       if (total <= C) {
         for (uint32_t e = 0; e < total; ++e) {
           const uint32_t v = list_id[e], deg = list_deg[e], off = list_off[e];
-          for (uint32_t i = tid; i < deg; i += nth) run(v, a.m.adj[off + i]);
+          for (uint32_t i = tid; i < deg; i += nth) run(v, rec_at(v, off + i));
         }
       } else {
         for (uint32_t r = tid; r < P; r += nth) {
@@ -808,7 +825,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
           if ((cur[x >> 5] >> (x & 31)) & 1u) vmin = x;
           if (((cur[rec.y >> 5] >> (rec.y & 31)) & 1u) && rec.y < vmin) vmin = rec.y;
           if (tern && ((cur[rec.z >> 5] >> (rec.z & 31)) & 1u) && rec.z < vmin) vmin = rec.z;
-          if (vmin != 0xFFFFFFFFu) run(vmin, r);
+          if (vmin != 0xFFFFFFFFu) run(vmin, rec);
         }
       }
       __syncthreads();
@@ -836,11 +853,11 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
       for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
       const DM dm{bits, bnd, a.m.const_val, V, sw, a.base, nxt, misc, &narrow, trail, &misc[S_TRAILLEN], a.trail_cap};
       if (key != ~0ull) {
-        const uint32_t u = (uint32_t)key, o0 = a.m.adj_off[u], o1 = a.m.adj_off[u + 1];
+        const uint32_t u = (uint32_t)key, o0 = adjo[u], o1 = adjo[u + 1];
         for (uint32_t i0 = o0 + wv * 64; i0 < o1; i0 += nth) {
           if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&misc[S_OPEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
           bool open_rec = false;
-          if (i0 + lane < o1) open_rec = !eval_set(a.m.recs[a.m.adj[i0 + lane]], dm, true);
+          if (i0 + lane < o1) open_rec = !eval_set(rec_at(u, i0 + lane), dm, true);
           if (__ballot(open_rec) != 0 && lane == 0) atomicOr(&misc[S_OPEN], 1u);
         }
       }
@@ -889,18 +906,24 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
       descend = true;
     }
     if (!descend) {
-      // ---- backtrack: the deepest level whose right branch is still open --------------------------------------------------
-      if (n_levels == 0) { finished = true; break; }
-      --n_levels;
-      const uint4 lv = levels[n_levels];
-      const uint32_t T = lv.z;
-      for (uint32_t i = T + tid; i < tlen; i += nth) {
-        const uint4 e = trail[i];
-        atomicOr(&bits[e.x], ((unsigned long long)e.w << 32) | e.z);
-        atomicOr(&touched[e.y >> 5], 1u << (e.y & 31u));
+      // ---- backtrack: the deepest level whose right branch is still open (a level whose right branch was given to another tree
+      // is undone like any other and skipped) ------------------------------------------------------------------------------
+      uint4 lv = make_uint4(0u, 0u, 0u, 1u);
+      uint32_t from = tlen;
+      while (n_levels) {
+        --n_levels;
+        lv = levels[n_levels];
+        for (uint32_t i = lv.z + tid; i < from; i += nth) {
+          const uint4 e = trail[i];
+          atomicOr(&bits[e.x], ((unsigned long long)e.w << 32) | e.z);
+          atomicOr(&touched[e.y >> 5], 1u << (e.y & 31u));
+        }
+        from = lv.z;
+        if (!lv.w) break;
       }
+      if (lv.w) { finished = true; break; }  // nothing left that is this tree's
       __syncthreads();
-      if (tid == 0) { misc[S_TRAILLEN] = T; misc[S_FAIL] = 0; }
+      if (tid == 0) { misc[S_TRAILLEN] = from; misc[S_FAIL] = 0; }
       for (uint32_t v = tid; v < V; v += nth)
         if ((touched[v >> 5] >> (v & 31u)) & 1u) bnd[v] = scan_bounds(bits + (size_t)v * sw, sw, a.base);
       __syncthreads();
@@ -932,7 +955,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
     if (ev) { atomicAdd((unsigned long long*)&st_slot->evaluated, (unsigned long long)ev); atomicAdd((unsigned long long*)&st_slot->full_evals, (unsigned long long)ev); }
   }
   if (tid == 0) {
-    tree[0] = n_levels; tree[1] = misc[S_TRAILLEN]; tree[2] = pending; tree[3] = finished ? 1u : 0u;
+    tree[0] = n_levels; tree[1] = misc[S_TRAILLEN]; tree[2] = pending; tree[3] = (finished ? 1u : 0u) | (min(given0, n_levels) << 8);
     unsigned long long* cn = a.counters + (size_t)t * 4;
     cn[0] += c_nodes; cn[1] += c_sols; cn[2] += c_fail;
     if (c_err) cn[3] = c_err;
@@ -941,6 +964,44 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
     atomicAdd((unsigned long long*)&st_slot->nodes, c_nodes);
     if (c_fail) atomicAdd((unsigned long long*)&st_slot->failed_nodes, c_fail);
     if (c_err) atomicExch(a.stop, 1u);
+  }
+}
+
+// A finished tree takes over the OLDEST open right branch of a tree that still has some (the subtree nearest the donor's root: the
+// largest it can give).  That node = the donor's current node with its trail undone down to the level's mark (the parent's fixpoint)
+// and the right branch applied; it is built straight into the receiver's row.  The donor's level is marked as given (levels[..].w):
+// its search loop undoes it like any other level and does not take the right branch.  Runs BETWEEN launches of setdfs_kernel.
+__global__ void __launch_bounds__(256) setdfs_split_kernel(const SetDfsArgs a, const uint32_t* __restrict__ pairs, uint32_t* __restrict__ done) {
+  const uint32_t d = pairs[2 * blockIdx.x], r = pairs[2 * blockIdx.x + 1], tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t V = a.m.n_vars, sw = a.set_words;
+  uint32_t* const td = a.tree + (size_t)d * 4;
+  uint32_t* const tr = a.tree + (size_t)r * 4;
+  const uint32_t n_levels = td[0], tlen = td[1], given = td[3] >> 8;
+  const bool ok = !(td[3] & 1u) && (tr[3] & 1u) && given < n_levels && d != r;
+  if (!ok) { if (tid == 0) done[blockIdx.x] = 0; return; }
+  uint4* const lvp = a.levels + (size_t)d * a.level_cap + given;
+  const uint4 lv = *lvp;
+  const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.bits) + (size_t)d * V * sw;
+  unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.bits) + (size_t)r * V * sw;
+  for (uint32_t i = tid; i < V * sw; i += nth) dst[i] = src[i];
+  __syncthreads();
+  const uint4* trail = a.trail + (size_t)d * a.trail_cap;
+  for (uint32_t i = lv.z + tid; i < tlen; i += nth) {
+    const uint4 e = trail[i];
+    atomicOr(&dst[e.x], ((unsigned long long)e.w << 32) | e.z);
+  }
+  __syncthreads();
+  // the right child x > val: the values up to val leave the variable's set (binary_split.rs:52-57)
+  for (uint32_t k = tid; k < sw; k += nth) {
+    const long long t = (long long)(int)lv.y - ((long long)a.base + 64ll * (long long)k);
+    const unsigned long long le = t < 0 ? 0ull : (t >= 63 ? ~0ull : ((2ull << t) - 1ull));
+    dst[(size_t)lv.x * sw + k] &= ~le;
+  }
+  if (tid == 0) {
+    lvp->w = 1u;
+    td[3] = (td[3] & 0xFFu) | ((given + 1) << 8);
+    tr[0] = 0; tr[1] = 0; tr[2] = lv.x; tr[3] = 0;
+    done[blockIdx.x] = 1;
   }
 }
 
@@ -954,6 +1015,12 @@ hipError_t launch_setdfs(const SetDfsArgs& a, hipStream_t stream) {
   hipError_t e;
   if (lds > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(setdfs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
   hipLaunchKernelGGL(setdfs_kernel, dim3(a.n_trees), dim3(kSetThreads), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_setdfs_split(const SetDfsArgs& a, uint32_t n_pairs, const uint32_t* pairs, uint32_t* done, hipStream_t stream) {
+  if (!n_pairs) return hipSuccess;
+  hipLaunchKernelGGL(setdfs_split_kernel, dim3(n_pairs), dim3(256), 0, stream, a, pairs, done);
   return hipGetLastError();
 }
 

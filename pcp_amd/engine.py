@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library():
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
+    L.pcp_dfs_forest_split_set.argtypes = [vp, C.POINTER(ForestState), u32, vp, vp, vp]
     L.pcp_dfs_forest_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, u32, C.c_uint64, vp]
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
@@ -124,7 +125,7 @@ def load_library():
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -367,7 +368,7 @@ class Context:
 
     def dfs_forest_set(self, root_bits, stop_on_solution: bool = False, node_limit: int = 0, steps_per_launch: int = 256,
                        level_capacity: int = 4096, trail_capacity: int = 1 << 20, max_launches: int = 1 << 30, want_solution: bool = True,
-                       info: dict | None = None):
+                       info: dict | None = None, rebalance: bool = True):
         """pcp_dfs_forest_device_set: the reference's search loop over FDSpace on the device, one tree per workgroup, the current
         node in LDS, an undo trail in HBM.  root_bits: [n_trees, n_vars, set_words] uint64 (numpy or a CUDA int64 tensor): the roots,
         not yet propagated.  Launches of steps_per_launch nodes per tree are repeated until every tree is finished, the forest
@@ -392,19 +393,32 @@ class Context:
         st = ForestState(T, level_capacity, trail_capacity, 0, bits.data_ptr(), tree.data_ptr(), levels.data_ptr(), trail.data_ptr(), counters.data_ptr(),
                          glob.data_ptr(), glob.data_ptr() + 8, sol.data_ptr() if want_solution else None, glob.data_ptr() + 16 if want_solution else None)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        launches = 0
+        launches = splits = 0
         while launches < max_launches:
             self._check(self._L.pcp_dfs_forest_device_set(self._h, C.byref(st), int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit), C.c_void_p(stream)))
             launches += 1
             g = glob.cpu().tolist()  # (the launch's only synchronisation)
-            if (g[1] & 0xFFFFFFFF) or (node_limit and g[0] >= node_limit) or int(tree[:, 3].sum().item()) == T:
+            ts = tree.cpu().numpy()
+            fin = (ts[:, 3] & 1) != 0
+            if (g[1] & 0xFFFFFFFF) or (node_limit and g[0] >= node_limit) or fin.all():
                 break
+            if rebalance and fin.any():
+                # finished trees take the oldest open right branch of the trees with the most levels left (pcp_dfs_forest_split_set)
+                left = np.where(fin, 0, ts[:, 0].astype(np.int64) - (ts[:, 3] >> 8))
+                donors = [int(i) for i in np.argsort(-left) if left[i] > 0]
+                recv = [int(i) for i in np.nonzero(fin)[0]]
+                k = min(len(donors), len(recv))
+                if k:
+                    pairs = torch.tensor(np.stack([donors[:k], recv[:k]], axis=1).astype(np.int32).ravel(), dtype=torch.int32, device=dev)
+                    done = torch.zeros(k, dtype=torch.int32, device=dev)
+                    self._check(self._L.pcp_dfs_forest_split_set(self._h, C.byref(st), k, C.c_void_p(pairs.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(stream)))
+                    splits += int(done.sum().item())
         cn = counters.cpu().numpy()
         g = glob.cpu().tolist()
         if info is not None:
-            info.update(trail_max=int(tree[:, 1].max().item()), levels_max=int(tree[:, 0].max().item()), trees=T)
+            info.update(trail_max=int(tree[:, 1].max().item()), levels_max=int(tree[:, 0].max().item()), trees=T, splits=splits)
         return {"nodes": int(cn[:, 0].sum()), "solutions": int(cn[:, 1].sum()), "failed": int(cn[:, 2].sum()), "error": int(cn[:, 3].max()),
-                "finished_trees": int(tree[:, 3].sum().item()), "stopped": bool(g[1] & 0xFFFFFFFF), "launches": launches, "total_nodes": int(g[0]),
+                "finished_trees": int((tree[:, 3] & 1).sum().item()), "splits": splits, "stopped": bool(g[1] & 0xFFFFFFFF), "launches": launches, "total_nodes": int(g[0]),
                 "first_solution": sol.cpu().numpy() if (want_solution and (g[2] & 0xFFFFFFFF)) else None, "per_tree": cn}
 
     def stats_reset(self, stream_ptr: int = 0):

@@ -151,3 +151,28 @@ def test_forest_search_driver_single_and_two_ranks(ctx, n, trees):
     parts = [forest_search_set(ctx, lb0, ub0, 1, n_trees=trees, steps_per_launch=32, rank=r, world=2) for r in range(2)]
     assert all(p["error"] == 0 for p in parts) and all(p["trees"] > 0 for p in parts)
     assert tuple(sum(p[k] for p in parts) for k in ("nodes", "solutions", "failed")) == want
+
+
+@pytest.mark.parametrize("n,rounds,steps", [(9, 2, 6), (10, 3, 10), (11, 2, 25)])
+def test_finished_trees_take_work_from_the_others(ctx, n, rounds, steps):
+    """pcp_dfs_forest_split_set: with few trees of very different sizes and short launches, finished trees take over the oldest open right
+    branch of the others; the union is still exactly the oracle's tree, and it takes fewer launches than without re-balancing."""
+    from pcp_amd.search_device import DeviceSearch
+    props, sw, lb0, ub0 = nqueens(ctx, n)
+    ss, _, _, _ = orc.OracleModel(n, props).search_set(lb0, ub0, sw, 1, all_solutions=True)
+    ds = DeviceSearch(ctx, batch=4096, capacity=8192, implicit=True)
+    ds.reset(lb0, ub0, 1)
+    for _ in range(rounds):
+        if ds.advance(all_solutions=True, max_rounds=1, keep_solutions=0):
+            break
+    ds.compact()
+    k = ds.size
+    roots, st = ds.bits[:k].clone(), ds.stats
+    want = (ss["num_nodes"] - st.num_nodes, ss["num_solution"] - st.num_solution, ss["num_failed_node"] - st.num_failed_node)
+    info = {}
+    r = ctx.dfs_forest_set(roots, steps_per_launch=steps, info=info)
+    assert r["error"] == 0 and (r["nodes"], r["solutions"], r["failed"]) == want
+    assert info["splits"] > 0
+    plain = ctx.dfs_forest_set(roots, steps_per_launch=steps, rebalance=False)
+    assert (plain["nodes"], plain["solutions"], plain["failed"]) == want and plain["splits"] == 0
+    assert r["launches"] < plain["launches"]
