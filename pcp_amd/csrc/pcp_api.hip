@@ -68,6 +68,7 @@ struct pcp_ctx {
   uint32_t trusted_epoch = 0;   // epoch of the last packed launch without a retry launch (hull declared)
   uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
   uint32_t* d_child_base = nullptr; size_t cap_child_base = 0;  // branching scratch
+  uint32_t* d_deep = nullptr; size_t cap_deep = 0;              // two-pass all-XNeqY launches: [0] = length, [4..] = the deep nodes' indices
   uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
   // host-buffer path staging
   void* d_stage = nullptr; size_t cap_stage = 0;
@@ -98,6 +99,10 @@ struct pcp_ctx {
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
+  int64_t opt_neq_wave = 0;         // 1 = batches of >= 1024 implicit nodes of an all-XNeqY model run two passes (one wavefront per shallow node, then tiles for the deep ones), 0 (default: the first pass is 4x slower than the tiles, pcp_neq.hip) = tiles only
+  int64_t opt_neq_wave_block = 256;  // threads per block of the wave-per-node pass (64..1024)
+  int64_t opt_neq_wave_per_cu = 4;   // blocks of it per CU the grid is sized for
+  int64_t opt_neq_wave_max = 4;     // a node with more assigned variables than this is a deep one
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
@@ -548,8 +553,28 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.status = bt->status;
   a.stats = c->d_stats;
   c->dfs_team_words = 0;
-  c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
+  // Two passes for large batches: one wavefront per node finishes the shallow nodes (at most neq_wave_max assigned variables) with no
+  // workgroup barrier at all and lists the others; the tile kernel then runs over that list (its workgroups beyond the list's length
+  // exit at once).  Nothing is asked of the host: the split is made on the device, per node.
+  const bool two_pass = c->opt_neq_wave && !c->dfs_sp && !(a.debug & ~0x700u) && n_nodes >= 1024 && S < 65536u;
+  uint32_t wgrid = 0, wblock = (uint32_t)c->opt_neq_wave_block;
+  size_t wlds = 0;
+  if (two_pass) {
+    int32_t rcd = ensure(c, c->d_deep, c->cap_deep, (size_t)n_nodes + 4);
+    if (rcd) return rcd;
+    a.wave_cache_entries = std::min<uint32_t>(c->max_deg, 4096u);
+    wlds = lds_bytes_neqwave(S, packed, wblock / 64, a.wave_cache_entries, c->have_adjp4);
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)c->opt_neq_wave_per_cu, c->lds_max / std::max<size_t>(wlds, 1)));
+    wgrid = std::min<uint32_t>((n_nodes + wblock / 64 - 1) / (wblock / 64), (uint32_t)c->num_cu * per_cu);
+    a.deep_count = c->d_deep; a.deep_list = c->d_deep + 4; a.wave_max_assigned = (uint32_t)c->opt_neq_wave_max;
+  }
+  c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, two_pass ? 1u : 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
+  if (two_pass) HIP_TRY(c, hipMemsetAsync(c->d_deep, 0, 4, stream));
   if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (two_pass) {
+    HIP_TRY(c, launch_neqwave(a, wgrid, wblock, wlds, stream));
+    a.node_index = c->d_deep + 4; a.n_index = c->d_deep;
+  }
   HIP_TRY(c, launch_neqfix(a, plan, stream));
   if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (bt->active_out && P) {
@@ -621,7 +646,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -808,6 +833,18 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;
+  } else if (k == "neq_wave") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_wave must be 0 or 1");
+    c->opt_neq_wave = value;
+  } else if (k == "neq_wave_block") {
+    if (value != 64 && value != 128 && value != 256) return fail(c, PCP_ERR_ARG, "neq_wave_block must be 64, 128 or 256");
+    c->opt_neq_wave_block = value;
+  } else if (k == "neq_wave_per_cu") {
+    if (value < 1 || value > 32) return fail(c, PCP_ERR_ARG, "neq_wave_per_cu must be in [1,32]");
+    c->opt_neq_wave_per_cu = value;
+  } else if (k == "neq_wave_max") {
+    if (value < 0 || value > 65535) return fail(c, PCP_ERR_ARG, "neq_wave_max must be in [0,65535]");
+    c->opt_neq_wave_max = value;
   } else if (k == "neq_dfs") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_dfs must be 0 or 1");
     c->opt_neq_dfs = value;

@@ -29,6 +29,15 @@ struct NeqArgs {
     uint32_t stop_on_solution;
     unsigned long long node_limit;
   } dfs;
+  // Two-pass launches (pcp_neq.hip, neqwave_kernel): pass 1 — one wavefront per node — finishes the nodes with at most
+  // wave_max_assigned assigned variables and appends the others to deep_list / *deep_count; pass 2 — this tile kernel — then runs
+  // with node_index = that list and n_index = its length (a workgroup beyond the length exits at once).
+  const uint32_t* node_index;   // null: the tile's nodes are node0 .. node0 + nb - 1
+  const uint32_t* n_index;      // device word: entries of node_index (with node_index only)
+  uint32_t* deep_list;
+  uint32_t* deep_count;
+  uint32_t wave_max_assigned;
+  uint32_t wave_cache_entries;  // payload entries of one list a block of neqwave_kernel keeps in LDS (0: none)
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -38,6 +47,9 @@ struct NeqArgs {
 };
 size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, uint32_t wgs = 2);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
+// pass 1 of a two-pass launch: grid x block threads, one wavefront per node (persistent: a wavefront takes nodes gw, gw + waves, ...)
+size_t lds_bytes_neqwave(uint32_t n_slots, bool packed, uint32_t waves_per_block, uint32_t cache_entries, bool pay4);
+hipError_t launch_neqwave(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream);
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
 // per workgroup (pcp_big.hip).

@@ -49,7 +49,8 @@ namespace pcp {
 namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
-       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19 };
+       N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
+       N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */ };
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
@@ -83,7 +84,7 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   c.chg = o; o = up(o + (size_t)B * Wv * 4);
   c.list = o; o = up(o + (size_t)kListCap * 16);
   c.adj = o; o = up(o + ((size_t)V + 1) * 4);
-  c.misc = o; o = up(o + 32 * 4);
+  c.misc = o; o = up(o + 48 * 4);
   // the windows take what is left of the CU's LDS divided by the workgroups that are to share it (two by default; one when the
   // tile needs more than its share)
   // (256 bytes short of an even share: __syncthreads_or and friends take a few bytes of static LDS on top of the dynamic carve)
@@ -268,7 +269,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint4* const list = reinterpret_cast<uint4*>(smem + cv.list);  // (v | M << 16, list offset, degree, windows w0 | w1 << 16)
   Win* const win = reinterpret_cast<Win*>(smem + cv.win);
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
-  const uint32_t node0 = DFS ? 0u : blockIdx.x * B, nb = DFS ? 1u : min(B, a.n_nodes - node0);
+  const uint32_t n_eff = (!DFS && a.node_index) ? *a.n_index : a.n_nodes;  // (pass 2 of a two-pass launch: the length of the deep list)
+  const uint32_t node0 = DFS ? 0u : blockIdx.x * B;
+  if (!DFS && node0 >= n_eff) return;
+  const uint32_t nb = DFS ? 1u : min(B, n_eff - node0);
   auto dom_of = [&](uint32_t b, Ctr* c) { return TDom{dom + b, B, sh, chg + (size_t)b * Wv, misc, 1u << b, c}; };
 
   // ---- phase 0: stage the domains (16-byte row loads), find the assigned variables ------------------------------------------
@@ -307,6 +311,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     resume = dfs_resume_var != 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
+  if (tid < nb) misc[N_NID + tid] = (!DFS && a.node_index) ? a.node_index[node0 + tid] : node0 + tid;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   __syncthreads();
   // DFS rows may have been written by this very workgroup a moment ago: they are read past the L1 (relaxed agent-scope loads)
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         for (int j = 0; j < UF; ++j) {
           const uint32_t t = min(t0 + j * nth, tasks - 1);
           bq[j] = t / SQ; qq[j] = t - bq[j] * SQ;
-          const size_t row = (size_t)(node0 + bq[j]) * V;
+          const size_t row = (size_t)misc[N_NID + bq[j]] * V;
           L[j] = reinterpret_cast<const int4*>(a.lb_in + row)[qq[j]];
           U[j] = reinterpret_cast<const int4*>(a.ub_in + row)[qq[j]];
         }
@@ -364,7 +369,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     } else {
       for (uint32_t t = tid; t < tasks; t += nth) {
         const uint32_t b = t / SQ, q = t - b * SQ, v0 = 4 * q, cnt = min(4u, V - v0);
-        const size_t row = (size_t)(node0 + b) * V;
+        const size_t row = (size_t)misc[N_NID + b] * V;
         int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -771,8 +776,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       if ((refused >> b) & 1u) continue;                   // a refused node's outputs are left alone
       if (in_place && !((dirty >> b) & 1u)) continue;      // the rows in HBM already hold the result
       auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
-      int32_t* lbp = a.lb_out + (size_t)(node0 + b) * V;
-      int32_t* ubp = a.ub_out + (size_t)(node0 + b) * V;
+      int32_t* lbp = a.lb_out + (size_t)misc[N_NID + b] * V;
+      int32_t* ubp = a.ub_out + (size_t)misc[N_NID + b] * V;
       bool bad = false;
       if (vec_out) {
         for (uint32_t q = tid; q < (V >> 2); q += nth) {
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   if (tid < nb) {
     const bool failed = (misc[N_FAIL] >> tid) & 1u, refused = (misc[N_OOB] >> tid) & 1u;
     const bool none_open = !((misc[N_UNK] >> tid) & 1u);
-    a.status[node0 + tid] = refused ? kStatusRetry : failed ? (uint8_t)PCP_FALSE : (none_open ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
+    a.status[misc[N_NID + tid]] = refused ? kStatusRetry : failed ? (uint8_t)PCP_FALSE : (none_open ? (uint8_t)PCP_TRUE : (uint8_t)PCP_UNKNOWN);
   }
   if (tid == 0) {
     const uint32_t active_nodes = (uint32_t)__popc(((nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)) & ~misc[N_OOB]));
@@ -935,6 +940,324 @@ hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stre
     return launch_neq_d<true>(a, p, stream);
   }
   return launch_neq_d<false>(a, p, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pass 1 of a two-pass launch: ONE WAVEFRONT owns a node.  A node with one or two assigned variables (a breadth-first frontier) needs
+// its rows staged, one or two lists walked and a status scan; in the tile kernel that little work is spread over three workgroup
+// barriers, and the two workgroups of a CU stage and compute in lockstep, so HBM idles while they compute.  Here a wavefront stages
+// its node into its own LDS slice and runs the whole fixpoint alone — the same rounds (round 0 = the lists of the assigned variables,
+// round r = the lists of the variables changed in round r-1), the same filter (eval_record), the same status rule — with no
+// workgroup barrier anywhere: sixteen wavefronts per CU at sixteen different points keep HBM streaming.  It is correct for any node
+// and slow for a deep one (64 lanes per list instead of 512 and no node quads), so a node with more than wave_max_assigned assigned
+// variables is not run: its index goes to deep_list and the tile kernel (pass 2) takes it.
+// MEASURED AND NOT USED BY DEFAULT ("neq_wave" = 0): bit-exact (tests/test_neq_path.py::test_two_pass_launches), but on the bench
+// frontier this pass takes 250 us where the tile kernel takes 65 us for everything, whatever the block size (64..1024 threads) and
+// blocks per CU; with the rounds and the status scan compiled out it still takes 117-173 us for the staging alone (the tile kernel
+// stages the same rows in 36 us).  Its s_memtime phase timers (neq_debug 1024, tools/wave_probe.py) add up to each wavefront's lifetime
+// but not to an explanation: every phase, down to a handful of shuffles, is several times slower than the same code in the tile
+// kernel.  Kept as an option, with its tests, for whoever finds out why.
+// ------------------------------------------------------------------------------------------------
+enum { W_FAIL = N_FAIL, W_OOB = N_OOB, W_DIRTY = N_DIRTY, W_UNK = N_UNK, W_WORDS = 16 };
+// payload sources of a list walk: two TYPES, so that the walk is instantiated per address space (one pointer type for both makes the
+// loads flat: they wait on both counters and were most of a node's time)
+template <class P> struct PayLds { const P* p; __device__ __forceinline__ P at(uint32_t i) const { return p[i]; } };
+template <class P> struct PayGlobal { const P* p; __device__ __forceinline__ P at(uint32_t i) const { return p[i]; } };
+constexpr uint32_t kWaveStatusCache = 256;  // entries of the status scan's list kept in LDS (its first chunks decide almost every node)
+
+__host__ __device__ inline size_t neqwave_slice(uint32_t S, bool packed) {
+  const size_t Wv = (S + 31) / 32;
+  return (((size_t)S * (packed ? 4 : 8) + 15) & ~(size_t)15) + 2 * ((Wv * 4 + 15) & ~(size_t)15) + W_WORDS * 4;
+}
+
+template <bool PACKED, bool PAY4>
+__global__ void __launch_bounds__(256) neqwave_kernel(const NeqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  using Cell = typename NeqCell<PACKED>::type;
+  using TDom = typename TileDomOf<PACKED>::type;
+  using Pay = typename std::conditional<PAY4, uint32_t, uint2>::type;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5;
+  unsigned char* const mine = smem + (size_t)wv * neqwave_slice(S, PACKED);
+  Cell* const dom = reinterpret_cast<Cell*>(mine);
+  uint32_t* chgA = reinterpret_cast<uint32_t*>(mine + (((size_t)S * sizeof(Cell) + 15) & ~(size_t)15));
+  uint32_t* chgB = chgA + (((Wv * 4 + 15) & ~15u) >> 2);
+  uint32_t* const misc = chgB + (((Wv * 4 + 15) & ~15u) >> 2);
+  const Pay* const pay = PAY4 ? reinterpret_cast<const Pay*>(a.adjp4) : reinterpret_cast<const Pay*>(a.m.adjp);
+  const uint32_t* const adjo = a.m.adj_off;
+  const int lim = PACKED ? kPackedMax : kBoundMax;
+  const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
+  const bool vec = (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in | (size_t)a.lb_out | (size_t)a.ub_out) & 15u) == 0;
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+  // ---- prologue (the kernel's only workgroup barriers): the nodes of a frontier share their assigned variables, so the list of the
+  // FIRST assigned variable of this block's first node, and the head of the list of its first unassigned variable (the status scan's),
+  // go to LDS once; a wavefront that walks one of them reads the payloads from there.  Every node re-reading 12 KB from L2 with four
+  // loads in flight per lane was four times slower than the tile kernel, which decodes a list once for sixteen nodes.
+  const unsigned long long tk_start = __builtin_amdgcn_s_memtime();
+  Pay* const cacheA = reinterpret_cast<Pay*>(smem + (size_t)nwv * neqwave_slice(S, PACKED));
+  Pay* const cacheU = cacheA + a.wave_cache_entries;
+  __shared__ uint32_t tagA, tagU, lenA, lenU;
+  if (tid == 0) { tagA = tagU = 0xFFFFFFFFu; lenA = lenU = 0; }
+  __syncthreads();
+  {
+    const uint32_t n0 = blockIdx.x * nwv;
+    if (wv == 0 && n0 < a.n_nodes) {
+      uint32_t fa = 0xFFFFFFFFu, fu = 0xFFFFFFFFu;
+      for (uint32_t base = 0; base < V && (fa == 0xFFFFFFFFu || fu == 0xFFFFFFFFu); base += 64) {
+        const uint32_t v = base + lane;
+        int l = 0, u = 1;
+        if (v < V) { l = a.lb_in[(size_t)n0 * V + v]; u = a.ub_in[(size_t)n0 * V + v]; }
+        const uint64_t ba = __ballot(v < V && l == u), bu = __ballot(v < V && l < u);
+        if (fa == 0xFFFFFFFFu && ba) fa = base + (uint32_t)__builtin_ctzll(ba);
+        if (fu == 0xFFFFFFFFu && bu) fu = base + (uint32_t)__builtin_ctzll(bu);
+      }
+      if (lane == 0) {
+        if (fa != 0xFFFFFFFFu && adjo[fa + 1] - adjo[fa] <= a.wave_cache_entries) { tagA = fa; lenA = adjo[fa + 1] - adjo[fa]; }
+        if (fu != 0xFFFFFFFFu) { tagU = fu; lenU = min(adjo[fu + 1] - adjo[fu], kWaveStatusCache); }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t cA = tagA, cU = tagU, nA = lenA, nU = lenU;
+  if (cA != 0xFFFFFFFFu) {
+    const Pay* src = pay + adjo[cA];
+    for (uint32_t i0 = tid; i0 < nA; i0 += 4 * blockDim.x) {
+      Pay q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q[j] = src[min(i0 + j * blockDim.x, nA - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (i0 + j * blockDim.x < nA) cacheA[i0 + j * blockDim.x] = q[j];
+    }
+  }
+  if (cU != 0xFFFFFFFFu) { const Pay* src = pay + adjo[cU]; for (uint32_t i = tid; i < nU; i += blockDim.x) cacheU[i] = src[i]; }
+  __syncthreads();
+  const bool wtime = (a.debug & 1024u) != 0;  // profiling: s_memtime ticks per phase in the counters (results wrong)
+  unsigned long long tk_pro = 0, tk_load = 0, tk_put = 0, tk_rest = 0, tk_a = 0, tk_b = 0, tk_c = 0, tk0 = 0;
+  if (wtime) tk_pro = __builtin_amdgcn_s_memtime() - tk_start;
+  // counters of this wavefront, handed over once
+  unsigned long long acc_steps = 0, acc_ev = 0, acc_full = 0, acc_narrow = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;
+  const uint32_t gw = blockIdx.x * nwv + wv, nw = gridDim.x * nwv;
+
+  for (uint32_t node = gw; node < a.n_nodes; node += nw) {
+    const size_t row = (size_t)node * V;
+    if (wtime) tk0 = __builtin_amdgcn_s_memtime();
+    // ---- stage: rows -> cells, the assigned variables marked ------------------------------------------------------------------
+    for (uint32_t w = lane; w < Wv; w += 64) { chgA[w] = 0; chgB[w] = 0; }
+    if (lane < (uint32_t)W_WORDS) misc[lane] = 0;
+    wave_sync();
+    uint32_t n_assigned = 0;
+    bool bad = false, oob = false;
+    auto put = [&](uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) {
+      uint32_t nib = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((uint32_t)i >= cnt) continue;
+        bad |= l[i] > u[i];
+        oob |= (l[i] < -lim) | (l[i] > lim) | (u[i] < -lim) | (u[i] > lim);
+        if (l[i] == u[i]) { nib |= 1u << i; ++n_assigned; }
+        if constexpr (PACKED) dom[v0 + i] = pack16(l[i], u[i]); else dom[v0 + i] = make_int2(-l[i], u[i]);
+      }
+      if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
+      if (nib) atomicOr(&chgA[v0 >> 5], nib << (v0 & 31u));
+    };
+    if (vec) {
+      const int4* L4 = reinterpret_cast<const int4*>(a.lb_in + row);
+      const int4* U4 = reinterpret_cast<const int4*>(a.ub_in + row);
+      const uint32_t Q = V >> 2;
+      for (uint32_t q0 = lane; q0 < Q; q0 += 4 * 64) {
+        int4 L[4], U[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t q = min(q0 + j * 64, Q - 1); L[j] = L4[q]; U[j] = U4[q]; }
+        if (wtime) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_load += t - tk0; tk0 = t; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (q0 + j * 64 >= Q) break;
+          const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
+          put(4 * (q0 + j * 64), l, u, 4);
+        }
+      }
+    } else {
+      for (uint32_t v0 = 4 * lane; v0 < V; v0 += 4 * 64) {
+        const uint32_t cnt = min(4u, V - v0);
+        int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < cnt; ++i) { l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i]; }
+        put(v0, l, u, cnt);
+      }
+    }
+    for (uint32_t s_ = V + lane; s_ < S; s_ += 64) {  // interned constants: singleton pseudo-variables behind the variables
+      const int c = a.m.const_val[s_ - V];
+      if constexpr (PACKED) dom[s_] = pack16(c, c); else dom[s_] = make_int2(-c, c);
+    }
+    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_put += t - tk0; tk0 = t; }
+    for (int o = 32; o > 0; o >>= 1) n_assigned += __shfl_xor(n_assigned, o);
+    const bool any_bad = __ballot(bad) != 0, any_oob = __ballot(oob) != 0;
+    if (n_assigned > a.wave_max_assigned && !any_bad && !any_oob) {  // a deep node: the tile kernel's (pass 2)
+      if (lane == 0) a.deep_list[atomicAdd(a.deep_count, 1u)] = node;
+      continue;
+    }
+    if (lane == 0) { if (any_bad) misc[W_FAIL] = 1u; if (any_oob) misc[W_OOB] = 1u; }
+    wave_sync();
+    Ctr ctr;
+    uint32_t my_ev = 0, ev0 = 0, waves = 0;
+    const TDom dmA{dom, 1u, 31u, chgA, misc, 1u, &ctr}, dmB{dom, 1u, 31u, chgB, misc, 1u, &ctr};
+
+    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_a += t - tk0; tk0 = t; }
+    // ---- rounds (wave-local): the lists of the marked variables; narrowings mark into the other mask ----------------------------
+#ifndef PCP_WAVE_STRIP  // (experiment builds: the rounds compiled out, to price the kernel's code size)
+    if (!any_bad && !any_oob && !(a.debug & 256u))  // (neq_debug 256 / 512: profiling only — no rounds / no status scan)
+      for (uint32_t round = 0;; ++round) {
+        uint32_t* const cur = (round & 1u) ? chgB : chgA;
+        const TDom& dmn = (round & 1u) ? dmA : dmB;
+        bool any = false;
+        for (uint32_t w = 0; w < Wv; ++w) {
+          uint32_t m = __builtin_amdgcn_readfirstlane(cur[w]);
+          if (!m) continue;
+          any = true;
+          while (m) {
+            const uint32_t v = (w << 5) + (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            if (v >= V) continue;
+            const uint32_t o0 = adjo[v], deg = adjo[v + 1] - o0;
+            auto walk = [&](const auto src) {
+              for (uint32_t k0 = 0; k0 < deg; k0 += 4 * 64) {
+                Pay q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = src.at(min(k0 + u * 64 + lane, deg - 1));
+                const Cell c0 = dom[v];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (k0 + u * 64 + lane >= deg) continue;
+                  const uint32_t other = pay_other(q[u]);
+                  const int t = pay_t(q[u]);
+                  const Cell oc = dom[other];
+                  bool hit;
+                  if constexpr (PACKED) hit = zero_half(neq_terms16(c0, oc, pack_mt(t)));
+                  else hit = (c0.x + oc.y == t) | (c0.y + oc.x == -t);
+                  ++my_ev;
+                  if (hit) {
+                    const bool is_y = pay_is_y(q[u]);
+                    Rec rec;
+                    rec.xk = (is_y ? other : v) | ((uint32_t)PCP_NEQ << 28);
+                    rec.y = is_y ? v : other;
+                    rec.z = 0;
+                    rec.d = is_y ? t : -t;
+                    ++ctr.full;
+                    eval_record(rec, dmn);
+                  }
+                }
+              }
+            };
+            if (v == cA) walk(PayLds<Pay>{cacheA}); else walk(PayGlobal<Pay>{pay + o0});
+          }
+          if (lane == 0) cur[w] = 0;
+        }
+        wave_sync();
+        if (round == 0) ev0 = my_ev;
+        if (!any) break;
+        if (round) ++waves;
+        if (__builtin_amdgcn_readfirstlane(misc[W_FAIL])) break;
+      }
+#endif
+    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_b += t - tk0; tk0 = t; }
+    // ---- status: an open record sits in the list of an unassigned variable (see the tile kernel) --------------------------------
+    const bool failed = __builtin_amdgcn_readfirstlane(misc[W_FAIL]) != 0, refused = __builtin_amdgcn_readfirstlane(misc[W_OOB]) != 0;
+    bool open = false;
+    if (!failed && !refused && !(a.debug & 512u)) {
+      for (uint32_t base = 0; base < V && !open; base += 64) {
+        const uint32_t vv = base + lane;
+        bool wide = false;
+        if (vv < V) { const int2 d = cell_bounds<PACKED>(dom[vv]); wide = d.x < d.y; }
+        uint64_t bal = __ballot(wide);
+        while (bal && !open) {
+          const uint32_t u = base + (uint32_t)__builtin_ctzll(bal);
+          bal &= bal - 1;
+          const int2 Ud = cell_bounds<PACKED>(dom[u]);
+          const uint32_t o0 = adjo[u], deg = adjo[u + 1] - o0;
+          for (uint32_t k = 0; k < deg && !open; k += 64) {
+            bool op = false;
+            if (k + lane < deg) {
+              Pay q;
+              if (u == cU && k + 64 <= nU) q = cacheU[k + lane];  // (wave-uniform: a whole chunk from the cached head, or from memory)
+              else q = pay[o0 + k + lane];
+              const int t = pay_t(q);
+              const int2 O = cell_bounds<PACKED>(dom[pay_other(q)]);
+              op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));
+            }
+            open = __ballot(op) != 0;
+          }
+        }
+      }
+    }
+    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_c += t - tk0; tk0 = t; }
+    // ---- write back, status, counters -----------------------------------------------------------------------------------------
+    bool emptied = false;
+    if (!refused && (!in_place || __builtin_amdgcn_readfirstlane(misc[W_DIRTY]))) {
+      int32_t* lbp = a.lb_out + row;
+      int32_t* ubp = a.ub_out + row;
+      if (vec) {
+        for (uint32_t q = lane; q < (V >> 2); q += 64) {
+          int l[4], u[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const int2 d = cell_bounds<PACKED>(dom[4 * q + i]); l[i] = d.x; u[i] = d.y; emptied |= d.x > d.y; }
+          reinterpret_cast<int4*>(lbp)[q] = make_int4(l[0], l[1], l[2], l[3]);
+          reinterpret_cast<int4*>(ubp)[q] = make_int4(u[0], u[1], u[2], u[3]);
+        }
+      } else {
+        for (uint32_t v = lane; v < V; v += 64) { const int2 d = cell_bounds<PACKED>(dom[v]); emptied |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
+      }
+    }
+    const bool is_failed = failed || __ballot(emptied) != 0;
+    for (int o = 32; o > 0; o >>= 1) { my_ev += __shfl_xor(my_ev, o); ev0 += __shfl_xor(ev0, o); ctr.full += __shfl_xor(ctr.full, o); ctr.narrow += __shfl_xor(ctr.narrow, o); }
+    if (lane == 0) {
+      a.status[node] = refused ? kStatusRetry : is_failed ? (uint8_t)PCP_FALSE : (open ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
+      if (refused) atomicMax(a.violation, 1u);
+    }
+    // reference-equivalent steps: every propagator of the node once (init_scheduler) + the wake-ups of the later rounds
+    acc_steps += (refused ? 0ull : (unsigned long long)a.m.n_recs) + (unsigned long long)(my_ev - ev0);
+    if (wtime) tk_rest += __builtin_amdgcn_s_memtime() - tk0;
+    acc_ev += my_ev; acc_full += ctr.full; acc_narrow += ctr.narrow; acc_waves += 1 + waves; acc_nodes += 1; acc_failed += is_failed && !refused ? 1 : 0;
+  }
+  if (lane == 0 && wtime) { acc_steps = acc_narrow = acc_ev = acc_full = acc_waves = acc_failed = acc_nodes = 0; }
+  if (lane == 0) {
+    if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
+    if (acc_narrow) atomicAdd((unsigned long long*)&a.stats->narrowings, acc_narrow);
+    if (acc_ev) atomicAdd((unsigned long long*)&a.stats->evaluated, acc_ev);
+    if (acc_full) atomicAdd((unsigned long long*)&a.stats->full_evals, acc_full);
+    if (acc_waves) atomicAdd((unsigned long long*)&a.stats->waves, acc_waves);
+    if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
+    if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
+    if (wtime) {
+      atomicAdd((unsigned long long*)&a.stats->steps3, tk_pro);
+      atomicAdd((unsigned long long*)&a.stats->narrowings, tk_load);
+      atomicAdd((unsigned long long*)&a.stats->full_evals, tk_put);
+      atomicAdd((unsigned long long*)&a.stats->failed_nodes, tk_rest);
+      atomicAdd((unsigned long long*)&a.stats->waves, tk_a);
+      atomicAdd((unsigned long long*)&a.stats->evaluated, tk_b);
+      atomicAdd((unsigned long long*)&a.stats->steps, tk_c);
+      atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)(__builtin_amdgcn_s_memtime() - tk_start));  // the wavefront's lifetime
+    }
+  }
+}
+
+size_t lds_bytes_neqwave(uint32_t n_slots, bool packed, uint32_t waves_per_block, uint32_t cache_entries, bool pay4) {
+  return neqwave_slice(n_slots, packed) * waves_per_block + (((size_t)(cache_entries + kWaveStatusCache) * (pay4 ? 4 : 8) + 15) & ~(size_t)15);
+}
+
+template <bool PACKED, bool PAY4>
+static hipError_t launch_neqwave_k(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqwave_kernel<PACKED, PAY4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((neqwave_kernel<PACKED, PAY4>), dim3(grid), dim3(block), lds, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_neqwave(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream) {
+  if (!a.m.adjp || !a.deep_list || !a.deep_count || a.m.n_slots >= 65536u) return hipErrorInvalidValue;
+  if (a.adjp4) return a.packed ? launch_neqwave_k<true, true>(a, grid, block, lds, stream) : launch_neqwave_k<false, true>(a, grid, block, lds, stream);
+  return a.packed ? launch_neqwave_k<true, false>(a, grid, block, lds, stream) : launch_neqwave_k<false, false>(a, grid, block, lds, stream);
 }
 
 }  // namespace pcp

@@ -170,3 +170,37 @@ def test_counters(ctx):
     st = got[4]
     assert st["nodes"] == 7 and st["steps"] >= 7 * len(props) and st["evaluated"] >= 7 * 3 * (n - 1) and st["full_evals"] <= st["evaluated"]
     assert st["narrowings"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+@pytest.mark.parametrize("hull", [True, False])
+def test_two_pass_launches(ctx, seed, hull):
+    """With "neq_wave" = 1, batches of >= 1024 nodes run two passes on the device: one wavefront per shallow node (neqwave_kernel), the tile kernel over the
+    list of deep ones.  Mixed depths, 16- and 32-bit cells, Constant operands, failures and cascades, in place and out of place; the
+    threshold at both ends — 0: every node with an assigned variable goes through the gather list, 65535: every node is a wavefront's."""
+    V, P, dom = 36 + 5 * (seed % 5), 180 + 30 * (seed % 5), (0, 10 + seed % 4)
+    props = neq_model(seed, V, P, dom)
+    om = orc.OracleModel(V, props)
+    ctx.set_model(V, props)
+    if hull:
+        ctx.set_hull(dom[0], dom[1])
+    L, U = nodes_with_assignments(300 + seed, V, 1500, dom, p_assign=0.35, p_narrow=0.4)
+    ref = om.consistency(L, U, None)
+    assert (ref[3] == 0).any() and (ref[3] == 2).any()
+    try:
+        ctx.set_option("neq_wave", 1)  # (off by default: bit-exact but slower than the tiles alone)
+        for wmax in (4, 0, 3, 65535):
+            ctx.set_option("neq_wave_max", wmax)
+            for in_place in (True, False):
+                got = ctx.propagate_implicit(L, U, in_place=in_place)
+                pl = ctx.last_plan()
+                assert pl["path"] == 1 and pl["compact"] == 1, pl  # (compact = 1: the launch was two passes)
+                assert_parity(ref[:4], got[:4], f"two-pass seed={seed} hull={hull} wave_max={wmax} in_place={in_place}")
+        ctx.set_option("neq_wave", 0)
+        got = ctx.propagate_implicit(L, U)
+        assert ctx.last_plan()["compact"] == 0
+        assert_parity(ref[:4], got[:4], f"tiles only seed={seed} hull={hull}")
+    finally:
+        ctx.set_option("neq_wave", 0)
+        ctx.set_option("neq_wave_max", 4)
