@@ -159,6 +159,8 @@ extern "C" {
                                  hip_stream: *mut c_void) -> i32; // st's arrays are [n_trees]-strided: tree t is a pcp_dfs_device instance
     pub fn pcp_dfs_forest_device_set(ctx: *mut pcp_ctx, st: *const pcp_forest_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
                                      hip_stream: *mut c_void) -> i32;
+    pub fn pcp_dfs_forest_split_set(ctx: *mut pcp_ctx, st: *const pcp_forest_state, n_pairs: u32, pairs: *const u32, done: *mut u32,
+                                    hip_stream: *mut c_void) -> i32; // pairs = n_pairs x (donor, receiver), device memory
     pub fn pcp_dfs_device(ctx: *mut pcp_ctx, st: *const pcp_dfs_state, n_steps: u32, stop_on_solution: u32, node_limit: u64,
                           hip_stream: *mut c_void) -> i32; // OneSolution/AllSolution<Propagation<Brancher<..>>> under StopNode, n_steps nodes
     pub fn pcp_stats_reset(ctx: *mut pcp_ctx, hip_stream: *mut c_void) -> i32;
