@@ -954,9 +954,9 @@ hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stre
 // MEASURED AND NOT USED BY DEFAULT ("neq_wave" = 0): bit-exact (tests/test_neq_path.py::test_two_pass_launches), but on the bench
 // frontier this pass takes 250 us where the tile kernel takes 65 us for everything, whatever the block size (64..1024 threads) and
 // blocks per CU; with the rounds and the status scan compiled out it still takes 117-173 us for the staging alone (the tile kernel
-// stages the same rows in 36 us).  Its s_memtime phase timers (neq_debug 1024, tools/wave_probe.py) add up to each wavefront's lifetime
-// but not to an explanation: every phase, down to a handful of shuffles, is several times slower than the same code in the tile
-// kernel.  Kept as an option, with its tests, for whoever finds out why.
+// stages the same rows in 36 us).  PMC: 1.4x the tile kernel's VALU instructions, but its wavefronts live six times longer and issue
+// a VALU instruction in 6.6 % of their cycles: one wavefront doing a node alone is a long chain of dependent LDS and memory reads, and
+// four such wavefronts per SIMD do not hide each other ("measured and rejected").  Kept as an option, with its tests.
 // ------------------------------------------------------------------------------------------------
 enum { W_FAIL = N_FAIL, W_OOB = N_OOB, W_DIRTY = N_DIRTY, W_UNK = N_UNK, W_WORDS = 16 };
 // payload sources of a list walk: two TYPES, so that the walk is instantiated per address space (one pointer type for both makes the

@@ -20,6 +20,8 @@ ctx = E.Context(0)
 
 def nq():
     ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
+    if os.environ.get("PCP_NEQ_WAVE"):  # the two-pass launch (off by default), for profiling it
+        ctx.set_option("neq_wave", int(os.environ["PCP_NEQ_WAVE"]))
 
 
 def launches(lb, ub, act, k):
