@@ -214,7 +214,7 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
     the counters at the end.  Subtrees are not re-balanced (N-queens-1000: no subtree ends within the budget)."""
     from pcp_amd.search_forest import forest_search, forest_search_set
     n = args.n
-    trees = args.trees if args.trees else (512 if set_mode else 2048)
+    trees = args.trees if args.trees else (512 if set_mode else 4096)
     spl = args.steps_per_launch if args.steps_per_launch else (2048 if set_mode else 1024)
     info = {}
 
@@ -295,7 +295,7 @@ def main():
     ap.add_argument("--engine", choices=["forest", "worklist"], default="forest",
                     help="--mode search: forest = one in-kernel DFS per open node of a frontier, no exchange (default; the only engine for --domains set); "
                          "worklist = batched rounds with the open-node stacks balanced GPU-to-GPU over RCCL")
-    ap.add_argument("--trees", type=int, default=0, help="--mode search, forest: trees (workgroups) per GPU (0 = 2048 for intervals, 512 for sets)")
+    ap.add_argument("--trees", type=int, default=0, help="--mode search, forest: trees (workgroups) per GPU (0 = 4096 for intervals, 512 for sets)")
     ap.add_argument("--steps-per-launch", type=int, default=0, help="--mode search, forest: nodes per tree and launch (0 = 1024 for intervals, 2048 for sets)")
     ap.add_argument("--domains", choices=["interval", "set"], default="interval",
                     help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
