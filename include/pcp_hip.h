@@ -277,7 +277,7 @@ int32_t pcp_dfs_forest_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_
  *   levels      : [n_trees][level_capacity][4] device uint32: the branch decisions whose right child is still open
  *   trail       : [n_trees][trail_capacity][4] device uint32
  *   counters    : [n_trees][4] device uint64 = { nodes, solutions, failed nodes, error (1 level stack full — the node stays current,
- *                 uncounted; 3 an Unknown node without a variable to branch on; 4 trail full: the tree cannot be restored) }, accumulated
+ *                 uncounted; 3 an Unknown node without a variable to branch on; 4 trail full: the tree cannot be restored; 5 internal round cap) }, accumulated
  *   total_nodes : device uint64: nodes of all trees; with node_limit != 0 no node beyond it is run (StopNode, stop_node.rs:57-62)
  *   stop        : device uint32: raised on a solution (stop_on_solution), at the node limit, on an error; the caller zeroes it
  *   first_solution / solution_flag : [n_vars] device int32 and a device uint32 (zeroed by the caller), or both NULL: the first solution

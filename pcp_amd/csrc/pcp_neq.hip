@@ -51,6 +51,7 @@ namespace {
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
        N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */ };
+constexpr uint32_t kMaxRounds = 1u << 22;  // a round that runs narrows something, so a fixpoint has far fewer; the cap only makes a runaway impossible
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
@@ -409,6 +410,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const bool one_piece = a.m.max_deg <= 64u * U4;
   bool cascade = false;  // the round before narrowed in many threads at once (workgroup-uniform)
   for (uint32_t round = 0;; ++round) {
+    if (round >= kMaxRounds) { if (tid == 0) { atomicOr(&misc[N_OOB], nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)); atomicMax(a.violation, 1u); } __syncthreads(); break; }  // (refused, not hung)
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
     const uint32_t narrow_before = ctr.narrow;
@@ -1107,6 +1109,7 @@ __global__ void __launch_bounds__(256) neqwave_kernel(const NeqArgs a) {
 #ifndef PCP_WAVE_STRIP  // (experiment builds: the rounds compiled out, to price the kernel's code size)
     if (!any_bad && !any_oob && !(a.debug & 256u))  // (neq_debug 256 / 512: profiling only — no rounds / no status scan)
       for (uint32_t round = 0;; ++round) {
+        if (round >= kMaxRounds) { if (lane == 0) misc[W_OOB] = 1u; wave_sync(); break; }  // (refused, not hung)
         uint32_t* const cur = (round & 1u) ? chgB : chgA;
         const TDom& dmn = (round & 1u) ? dmA : dmB;
         bool any = false;

@@ -771,7 +771,9 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
         for (uint32_t r = tid; r < P; r += nth) { (void)eval_set(a.m.recs[r], dm, false); ++ev; }
       __syncthreads();
     }
+    bool runaway = false;
     for (uint32_t round = 0;; ++round) {
+      if (round >= (1u << 22)) { runaway = true; break; }  // (a round that runs narrows something: the cap only makes a runaway impossible)
       const uint32_t m_total = (round & 1u) ? S_TOTAL2 : S_TOTAL;
       for (uint32_t v = tid; v < V; v += nth) {
         if (!((cur[v >> 5] >> (v & 31)) & 1u)) continue;
@@ -878,6 +880,7 @@ __global__ void __launch_bounds__(kSetThreads) setdfs_kernel(const SetDfsArgs a)
     const bool open = misc[S_OPEN] != 0;
     const uint32_t tlen = misc[S_TRAILLEN];
     if (misc[S_TRAILOVF]) { c_err = 4; break; }  // the trail is full: the tree cannot be restored any more (terminal)
+    if (runaway) { c_err = 5; break; }
     ++c_nodes;
     bool descend = false;
     if (failed) {
