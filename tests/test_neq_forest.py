@@ -73,3 +73,20 @@ def test_contract(ctx):
     ctx.set_hull(0, 5)
     with pytest.raises(E.PcpError):
         ctx.dfs_forest(np.zeros((2, V), np.int32), np.full((2, V), 5, np.int32), capacity=16)
+
+
+@pytest.mark.parametrize("n,trees,steps", [(10, 4, 6), (11, 6, 12), (12, 3, 40)])
+def test_finished_trees_take_the_oldest_open_node_of_the_others(ctx, n, trees, steps):
+    """dfs_forest's refill between launches (the bottom row of a donor's stack moves to a finished tree): with few trees of very
+    different sizes and short launches the union is still exactly the oracle's tree, and it takes fewer launches than without."""
+    from pcp_amd.search_forest import seed_roots_interval
+    props, lb0, ub0 = nqueens(ctx, n)
+    want = oracle_tree(n, props, lb0, ub0)
+    rl, ru, st = seed_roots_interval(ctx, lb0, ub0, trees)
+    rest = (want[0] - st.num_nodes, want[1] - st.num_solution, want[2] - st.num_failed_node)
+    r = ctx.dfs_forest(rl, ru, steps_per_launch=steps, capacity=256)
+    assert r["error"] == 0 and r["open"] == 0 and (r["nodes"], r["solutions"], r["failed"]) == rest
+    assert r["steals"] > 0
+    plain = ctx.dfs_forest(rl, ru, steps_per_launch=steps, capacity=256, rebalance=False)
+    assert (plain["nodes"], plain["solutions"], plain["failed"]) == rest and plain["steals"] == 0
+    assert r["launches"] < plain["launches"]
