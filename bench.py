@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,setsearch,c3,c4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,setsearch,c3,c4,f4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -462,7 +462,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "explicit,c2,deep500,deep3000,set,setsearch,c3,c4" if world == 1 else "none"
+            legs_req = "explicit,c2,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -706,6 +706,43 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                   torch.from_numpy(A4.view(np.int64)).to(dev), L4.shape[0] * node_bytes(V4, ctx.words, True),
                   f"{L4.shape[0]} open nodes of the BinarySplit expansion, V={V4}, {len(p4)} elementary filters in {ctx.n_units} units (one Distinct of 990)")
         legs.append(leg.run(launches=5, warmup=1))
+        del leg
+    if "f4" in want:
+        # the reified layer: Cumulative (propagators/cumulative.rs:59-114) = Booleans, equivalences over conjunctions, XEqYMulZ, Sum views —
+        # formula units, formfix_kernel (plan.path 3).  Nodes: the start windows narrowed at random (a scheduler's open nodes); everything else is derived by the propagation.
+        reset_opts()
+        T4, H4, N4 = 8, 15, 4096
+        vs4, cs4 = M.VStore(), M.CStore()
+        rng4 = np.random.default_rng(0xF4)
+        starts = [vs4.alloc((0, H4)) for _ in range(T4)]
+        durs = [M.Constant(int(d)) for d in rng4.integers(1, 6, size=T4)]
+        ress = [M.Constant(int(r)) for r in rng4.integers(1, 4, size=T4)]
+        cap4 = vs4.alloc((5, 5))
+        M.Cumulative(starts, durs, ress, cap4).join(vs4, cs4)
+        V4f = len(vs4)
+        M.push_model(ctx, cs4, V4f)
+        lb0f, ub0f = vs4.bounds()
+        Lf = np.tile(lb0f, (N4, 1)); Uf = np.tile(ub0f, (N4, 1))
+        pick = rng4.random((N4, V4f)) < 0.7
+        pick[:, T4:] = False  # only the start windows: the Booleans and intermediates are what the propagation derives
+        a_ = rng4.integers(lb0f, ub0f + 1, size=(N4, V4f)); b_ = rng4.integers(lb0f, ub0f + 1, size=(N4, V4f))
+        Lf = np.where(pick, np.minimum(a_, b_), Lf).astype(np.int32); Uf = np.where(pick, np.maximum(a_, b_), Uf).astype(np.int32)
+        leg = Leg(ctx, torch, "F4-cumulative-reified-layer", torch.from_numpy(Lf).to(dev), torch.from_numpy(Uf).to(dev), None, N4 * node_bytes(V4f, ctx.words, False),
+                  f"{N4} nodes with random start windows over Cumulative with {T4} tasks (V={V4f}, {ctx.n_units} units: formula trees of equivalences, XEqYMulZ, sums over Sum views), implicit nodes")
+        res = leg.run(launches=5, warmup=1)
+        res["plan_path"] = ctx.last_plan()["path"]
+        if args.cpu_budget > 0:  # parity of the launch on its first nodes
+            from oracle import oracle as orc
+            om4 = orc.OracleModel(V4f)
+            M.push_model(om4, cs4, V4f)
+            k4 = 64
+            ref4 = om4.consistency(Lf[:k4], Uf[:k4], None)
+            got4 = ctx.propagate_implicit(Lf[:k4], Uf[:k4])
+            ok = np.array_equal(ref4[3], got4[3]) and all(ref4[3][i] == 0 or (np.array_equal(ref4[0][i], got4[0][i]) and np.array_equal(ref4[1][i], got4[1][i])) for i in range(k4))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (cumulative leg): the launch differs from the oracle")
+            res["parity_checked_nodes"] = k4
+        legs.append(res)
         del leg
     # back to the headline model for anything that follows
     ctx.set_model(n, props)
