@@ -120,6 +120,7 @@ class Leg:
             ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream)
             ms.append(ctx.last_kernel_ms())
         st = ctx.stats_read(stream)
+        self.last_out = copies[-1][:2]  # the rows the LAST timed launch left behind (parity checks compare these, not a re-run)
         per = {k: v / launches for k, v in st.items()}
         med = float(np.median(ms))
         steps = per["steps"] + per["steps3"]
@@ -696,7 +697,21 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         ctx.set_hull(0, 999)  # the variables are allocated with Interval(0, 999): 10-bit LDS cells instead of HBM-resident domains
         leg = Leg(ctx, torch, "C3-random-binary-csp-50k-vars-500k-props", torch.from_numpy(L3).to(dev), torch.from_numpy(U3).to(dev), None,
                   N3 * node_bytes(V3, ctx.words, False), "4096 nodes, planted solution, unit-narrowing prefixes; 400 KB of bounds per node, kept in LDS as 10-bit cells (declared hull [0, 999])")
-        legs.append(leg.run(launches=3, warmup=1))
+        res3 = leg.run(launches=3, warmup=1)
+        res3["plan_path"] = ctx.last_plan()["path"]
+        if res3["plan_path"] != 2:
+            raise SystemExit("config 3 leg: the launch did not take the 10-bit-cell kernel (plan.path != 2)")
+        if args.cpu_budget > 0:  # parity of the TIMED launch on its first nodes (the oracle needs ~10 s for the model + ~1 s per node)
+            from oracle import oracle as orc
+            k3 = 8
+            ref3 = orc.OracleModel(V3, p3).consistency(L3[:k3], U3[:k3], None)
+            g_lb, g_ub = leg.last_out[0][:k3].cpu().numpy(), leg.last_out[1][:k3].cpu().numpy()
+            g_st = leg.status[:k3].cpu().numpy()
+            ok = np.array_equal(ref3[3], g_st) and all(ref3[3][i] == 0 or (np.array_equal(ref3[0][i], g_lb[i]) and np.array_equal(ref3[1][i], g_ub[i])) for i in range(k3))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (config 3 leg): the timed launch differs from the oracle")
+            res3["parity_checked_nodes"] = k3
+        legs.append(res3)
         del leg
     if "c4" in want:
         reset_opts()

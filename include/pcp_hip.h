@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 5
+#define PCP_ABI_VERSION 6
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -309,6 +309,19 @@ int32_t pcp_dfs_forest_split_set(pcp_ctx* ctx, const pcp_forest_state* st, uint3
  * pcp_stats_read is the only call that reports (and then clears) it. */
 int32_t pcp_stats_reset(pcp_ctx* ctx, void* hip_stream);
 int32_t pcp_stats_read(pcp_ctx* ctx, pcp_stats* out, void* hip_stream); /* synchronises hip_stream */
+
+/* Diagnostics (ABI v6): kernel-internal event counters accumulated since the last pcp_stats_reset.  They describe HOW a launch got
+ * to its result, never the result (the reference has no counterpart); tests use them to prove that a code path was taken.
+ * out[0 .. n) receives the first n of PCP_DBG_COUNT counters (n <= PCP_DBG_COUNT); synchronises hip_stream. */
+typedef enum {
+  PCP_DBG_BIG_DENSE = 0,   /* path 2: wake-up rounds that streamed the record table again (one per node and round)            */
+  PCP_DBG_BIG_SPARSE = 1,  /* path 2: wake-up rounds that walked the adjacency lists of the changed variables                  */
+  PCP_DBG_NEQ_TILES = 2,   /* path 1: tiles run (a persistent workgroup runs several)                                         */
+  PCP_DBG_NEQ_OVERLAP = 3, /* path 1: tiles whose rows were already in flight while the previous tile's rounds ran            */
+  PCP_DBG_SMALL_NODES = 4, /* path 4: nodes run by the small-store kernel                                                     */
+  PCP_DBG_COUNT = 16
+} pcp_dbg_counter;
+int32_t pcp_debug_counters(pcp_ctx* ctx, uint64_t* out, uint32_t n, void* hip_stream);
 
 /* Timing of the LAST pcp_propagate_device call's kernels, measured with HIP events recorded on the
  * stream the kernels were launched on (bench.py's roofline leg).  Synchronises on the stop event. */

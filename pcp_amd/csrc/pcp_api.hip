@@ -62,6 +62,7 @@ struct pcp_ctx {
 
   // scratch
   pcp_stats* d_stats = nullptr;
+  unsigned long long* d_dbg = nullptr;  // [PCP_DBG_COUNT] diagnostic counters (pcp_debug_counters)
   uint32_t* d_retry = nullptr;   // packed launches: stamped with `epoch` by a tile that has to be re-run with 32-bit cells
   uint32_t epoch = 0;
   bool hull_set = false; int32_t hull_lo = 0, hull_hi = 0;  // pcp_model_set_hull
@@ -97,7 +98,9 @@ struct pcp_ctx {
   int64_t opt_implicit = 1;         // 1 = active_in == NULL runs without live rows (liveness derived), 0 = materialise all-ones rows
   int64_t opt_neq_path = 1;         // 1 = all-XNeqY models with implicit nodes run the assignment-driven kernel (pcp_neq.hip), 0 = the generic sweep kernels
   int64_t opt_neq_block = 0;        // threads per workgroup of that kernel (0 = auto)
+  int64_t opt_neq_persist = 1;      // 1 = the tile kernel's workgroups are persistent (at most what the chip holds at once; each runs several tiles)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
+  int64_t opt_neq_trace = 0;        // profiling only: device pointer of NeqArgs::trace
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_wave = 0;         // 1 = batches of >= 1024 implicit nodes of an all-XNeqY model run two passes (one wavefront per shallow node, then tiles for the deep ones), 0 (default: the first pass is 4x slower than the tiles, pcp_neq.hip) = tiles only
   int64_t opt_neq_wave_block = 256;  // threads per block of the wave-per-node pass (64..1024)
@@ -106,6 +109,7 @@ struct pcp_ctx {
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
+  int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
 
@@ -540,6 +544,11 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
   // staging overlaps the other's list walk
   plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
+  if (c->opt_neq_persist) {
+    // persistent tiles: no more workgroups than the chip holds at once (LDS and threads per CU); each runs the tiles g, g + grid, ...
+    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / plan.lds_bytes), 2048u / plan.block));
+    plan.grid = std::min<uint32_t>(plan.grid, per_cu * (uint32_t)c->num_cu);
+  }
   NeqArgs a;
   memset(&a, 0, sizeof(a));
   a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
@@ -547,8 +556,8 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
   a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u;
-  a.violation = c->d_retry + 1;
-  a.debug = (uint32_t)c->opt_neq_debug;
+  a.violation = c->d_retry + 1; a.dbg = c->d_dbg;
+  a.debug = (uint32_t)c->opt_neq_debug; a.trace = reinterpret_cast<unsigned long long*>(c->opt_neq_trace);
   a.lds_wgs = (uint32_t)c->opt_neq_wgs;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
@@ -636,6 +645,7 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
   if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
       hipMemset(c->d_stats, 0, kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->d_retry), 8) != hipSuccess || hipMemset(c->d_retry, 0, 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_dbg), kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess || hipMemset(c->d_dbg, 0, kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
     delete c;
     return PCP_ERR_HIP;
@@ -648,7 +658,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -832,6 +842,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "big_round") {
+    if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "big_round must be 0 (auto), 1 (dense rounds only) or 2 (sparse rounds only)");
+    c->opt_big_round = value;
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;
@@ -853,8 +866,13 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_dfs") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_dfs must be 0 or 1");
     c->opt_neq_dfs = value;
+  } else if (k == "neq_persist") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_persist must be 0 or 1");
+    c->opt_neq_persist = value;
   } else if (k == "neq_debug") {
     c->opt_neq_debug = value;
+  } else if (k == "neq_trace_ptr") {
+    c->opt_neq_trace = value;
   } else if (k == "neq_block") {
     if (value < 0 || value > 1024 || (value & 63)) return fail(c, PCP_ERR_ARG, "neq_block must be 0 or a multiple of 64 up to 1024");
     c->opt_neq_block = value;
@@ -894,6 +912,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     a.m.recs = c->d_recs; a.m.const_val = c->d_const; a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S;
     a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
     a.nodes = c->d_fnodes; a.unit_root = c->d_unit_root; a.n_units = c->n_units; a.n_nodes = n_nodes; a.violation = c->d_retry + 1;
+    a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
     a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
     a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;
     LaunchPlan plan;
@@ -929,7 +948,8 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     a.recs_by_kind = c->d_recs_by_kind;
     a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
     a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
-    a.n_nodes = n_nodes; a.lo10 = c->hull_lo; a.violation = c->d_retry + 1;
+    a.n_nodes = n_nodes; a.lo10 = c->hull_lo; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.round_mode = (uint32_t)c->opt_big_round;
+    a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
     a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out; a.status = bt->status; a.stats = c->d_stats;
     LaunchPlan plan;
     plan.grid = n_nodes; plan.block = 1024; plan.lds_bytes = lds_bytes_big(c->n_vars, S);
@@ -1225,7 +1245,7 @@ static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_tr
   a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
   a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
   a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
-  a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.lds_wgs = 2;
+  a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.lds_wgs = 2;
   a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
   a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
   a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
@@ -1319,6 +1339,23 @@ int32_t pcp_stats_reset(pcp_ctx* c, void* hip_stream) {
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipMemsetAsync(c->d_stats, 0, kStatSlots * sizeof(pcp_stats), reinterpret_cast<hipStream_t>(hip_stream)));
   HIP_TRY(c, hipMemsetAsync(c->d_retry + 1, 0, 4, reinterpret_cast<hipStream_t>(hip_stream)));  // and the sticky hull-violation word
+  HIP_TRY(c, hipMemsetAsync(c->d_dbg, 0, kStatSlots * PCP_DBG_COUNT * 8, reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
+}
+
+int32_t pcp_debug_counters(pcp_ctx* c, uint64_t* out, uint32_t n, void* hip_stream) {
+  if (!c || !out || n > PCP_DBG_COUNT) return PCP_ERR_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  // striped like the counters of pcp_stats (workgroup b adds to stripe b % kStatSlots); slots 5..7 are maxima (a launch's timeline)
+  unsigned long long slots[kStatSlots][PCP_DBG_COUNT];
+  HIP_TRY(c, hipMemcpyAsync(slots, c->d_dbg, sizeof(slots), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(c, hipStreamSynchronize(stream));
+  for (uint32_t i = 0; i < n; ++i) {
+    uint64_t v = 0;
+    for (uint32_t s = 0; s < kStatSlots; ++s) v = (i >= 5 && i <= 7) ? std::max<uint64_t>(v, slots[s][i]) : v + slots[s][i];
+    out[i] = v;
+  }
   return PCP_OK;
 }
 

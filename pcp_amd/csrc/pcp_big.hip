@@ -35,7 +35,7 @@ namespace pcp {
 
 namespace {
 
-enum { G_FAIL = 0, G_OOB = 1, G_TOTAL0 = 2, G_TOTAL1 = 3, G_UNK = 4, G_WAVES = 5, G_NARROW = 6, G_EV = 8, G_FULL = 10, G_WORDS = 12 };
+enum { G_FAIL = 0, G_OOB = 1, G_TOTAL0 = 2, G_TOTAL1 = 3, G_UNK = 4, G_WAVES = 5, G_NARROW = 6, G_EV = 8, G_FULL = 10, G_DENSE = 12, G_SPARSE = 13, G_WORDS = 14 };
 
 struct BigCarve {
   size_t cells, cdom, chg_a, chg_b, misc, total;
@@ -140,6 +140,13 @@ __device__ __forceinline__ void propagate_binary(const uint32_t kind, const uint
 __global__ void __launch_bounds__(1024) bigfix_kernel(const BigArgs a_in) {
   BigArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
+  if (a.dbg) a.dbg += (size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT;
+  if (a.sp_ptr) {  // host-stepped device-side DFS (pcp_dfs_device): the node on top of the stack, as in fixpoint_kernel
+    const uint32_t sp = *a.sp_ptr;
+    if (sp == 0 || *a.stop_ptr) return;
+    const size_t off = (size_t)(sp - 1) * a.m.n_vars;
+    a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
@@ -225,8 +232,9 @@ __global__ void __launch_bounds__(1024) bigfix_kernel(const BigArgs a_in) {
     __syncthreads();
     const uint32_t total = misc[m_total];
     if (total == 0 || misc[G_FAIL]) break;
-    if (tid == 0) { misc[G_WAVES] += 1; misc[(round & 1u) ? G_TOTAL0 : G_TOTAL1] = 0; }
-    if (total * 8u >= V) {
+    const bool dense = a.round_mode ? a.round_mode == 1u : total * 8u >= V;
+    if (tid == 0) { misc[G_WAVES] += 1; misc[(round & 1u) ? G_TOTAL0 : G_TOTAL1] = 0; misc[dense ? G_DENSE : G_SPARSE] += 1; }
+    if (dense) {
       stream(std::true_type{}, cur, nxt);
     } else {
       const Dom10 dm{cells, cdom, V, a.lo10, nxt, misc, &ctr};
@@ -324,6 +332,10 @@ __global__ void __launch_bounds__(1024) bigfix_kernel(const BigArgs a_in) {
     atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(1 + misc[G_WAVES]));
     atomicAdd((unsigned long long*)&a.stats->nodes, 1ull);
     if (failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, 1ull);
+    if (a.dbg) {
+      if (misc[G_DENSE]) atomicAdd(&a.dbg[PCP_DBG_BIG_DENSE], (unsigned long long)misc[G_DENSE]);
+      if (misc[G_SPARSE]) atomicAdd(&a.dbg[PCP_DBG_BIG_SPARSE], (unsigned long long)misc[G_SPARSE]);
+    }
   }
 }
 

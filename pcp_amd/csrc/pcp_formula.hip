@@ -168,6 +168,12 @@ __device__ void f_propagate(FormCtx& c, uint32_t at) {
 __global__ void __launch_bounds__(256) formfix_kernel(const FormArgs a_in) {
   FormArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
+  if (a.sp_ptr) {  // host-stepped device-side DFS (pcp_dfs_device): the node on top of the stack, as in fixpoint_kernel
+    const uint32_t sp = *a.sp_ptr;
+    if (sp == 0 || *a.stop_ptr) return;
+    const size_t off = (size_t)(sp - 1) * a.m.n_vars;
+    a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, U = a.n_units, Wu = (U + 31) >> 5;

@@ -17,6 +17,8 @@ struct NeqArgs {
   uint32_t lds_wgs;             // workgroups meant to share a CU's LDS (sizes the jump-window area; must match lds_bytes_neq's argument)
   uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL
+  unsigned long long* dbg;      // [PCP_DBG_COUNT] diagnostic counters of the context (pcp_debug_counters); slots 5..15: phase timers under debug & 32
+  unsigned long long* trace;    // profiling (option "neq_trace_ptr"): [grid][16 wavefronts][16 events] s_memtime stamps, or null
   const uint32_t* sp_ptr;       // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
   const uint32_t* stop_ptr;
   struct {                      // n_steps > 0: the search loop itself runs in ONE workgroup (grid 1, nodes_per_block 1): pcp_dfs_device
@@ -58,7 +60,11 @@ struct BigArgs {
   const Rec* recs_by_kind;  // [padded like m.recs] the records sorted by kind (stable)
   uint32_t n_nodes;
   int32_t lo10;        // the hull's lower bound
+  uint32_t round_mode; // option "big_round": 0 = every wake-up round takes the cheaper form, 1 = always dense, 2 = always sparse (tests)
   uint32_t* violation; // sticky device word: a node was refused with PCP_STATUS_HULL
+  unsigned long long* dbg;  // [PCP_DBG_COUNT] diagnostic counters of the context (pcp_debug_counters)
+  const uint32_t* sp_ptr;   // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
+  const uint32_t* stop_ptr;
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -78,6 +84,8 @@ struct FormArgs {
   uint32_t n_units;
   uint32_t n_nodes;
   uint32_t* violation;
+  const uint32_t* sp_ptr;    // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
+  const uint32_t* stop_ptr;
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;

@@ -44,6 +44,13 @@
 #include "pcp_device.hpp"
 #include "pcp_neq.h"
 
+// Profiling builds only (tools/build_variant.py 0 <out.so> -DPCP_NEQ_PROFILE=1): the s_memtime phase timers ("neq_debug" bits 8 and 32)
+// and the per-wavefront event trace ("neq_trace_ptr").  They hold a dozen registers across the whole kernel, which the product build
+// needs for its row loads.
+#ifndef PCP_NEQ_PROFILE
+#define PCP_NEQ_PROFILE 0
+#endif
+
 namespace pcp {
 
 namespace {
@@ -85,7 +92,7 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   c.chg = o; o = up(o + (size_t)B * Wv * 4);
   c.list = o; o = up(o + (size_t)kListCap * 16);
   c.adj = o; o = up(o + ((size_t)V + 1) * 4);
-  c.misc = o; o = up(o + 48 * 4);
+  c.misc = o; o = up(o + (2 * 48 + 16) * 4);  // two copies: a persistent workgroup's next tile clears ITS copy while stragglers still read the last tile's; then seven u64 sums over the workgroup's tiles
   // the windows take what is left of the CU's LDS divided by the workgroups that are to share it (two by default; one when the
   // tile needs more than its share)
   // (256 bytes short of an even share: __syncthreads_or and friends take a few bytes of static LDS on top of the dynamic carve)
@@ -95,6 +102,23 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   c.win = o; o = up(o + (size_t)c.wcap * sizeof(Win));
   c.total = o;
   return c;
+}
+
+// Sum over the 64 lanes of a wavefront, in every lane's... lane 63, handed out wave-uniform: six DPP adds (row_shr 1, 2, 4, 8 inside the rows
+// of 16 lanes, row_bcast 15 and 31 across them) and one readlane — VALU only.  __shfl_down is a ds_bpermute, i.e. an LDS-pipeline
+// round trip per step, and this kernel's LDS pipeline is where a frontier tile's serial steps queue up.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8  -> lane 15 of a row holds the row's sum
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the sum
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// the same for counters that may be large: the halves are summed separately, so nothing can wrap
+__device__ __forceinline__ unsigned long long wave_sum64(uint32_t x) {
+  return (unsigned long long)wave_sum(x & 0xffffu) + ((unsigned long long)wave_sum(x >> 16) << 16);
 }
 
 __device__ __forceinline__ bool zero_half(uint32_t u) { return (u & 0xffffu) == 0u || (u >> 16) == 0u; }
@@ -247,6 +271,7 @@ template <bool PACKED, bool PAY4, bool DFS>
 __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
+  if (a.dbg) a.dbg += (size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT;
   if (!DFS && a.sp_ptr) {  // host-stepped device-side DFS: the node on top of the stack
     const uint32_t sp = *a.sp_ptr;
     if (sp == 0 || *a.stop_ptr) return;
@@ -263,17 +288,26 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = a.nodes_per_block;
   const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
-  const uint32_t sh = cv.sh, wcap = cv.wcap;
+  const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
+  const uint32_t sh = cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
+  unsigned long long* const trbuf = reinterpret_cast<unsigned long long*>(smem + cv.win + (size_t)wcap * sizeof(Win));
+#define PCP_TR(k) do { if (tr_on && lane == 0) trbuf[wv * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+  PCP_TR(0);
   auto rowof = [&](uint32_t slot) { return neq_row(slot, B, sh); };  // index of node 0's cell of a slot
   Cell* const dom = reinterpret_cast<Cell*>(smem + cv.dom);
   uint32_t* const chg = reinterpret_cast<uint32_t*>(smem + cv.chg);
   uint4* const list = reinterpret_cast<uint4*>(smem + cv.list);  // (v | M << 16, list offset, degree, windows w0 | w1 << 16)
   Win* const win = reinterpret_cast<Win*>(smem + cv.win);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
+  uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);  // (the copy of the current tile: see the loop's end)
   const uint32_t n_eff = (!DFS && a.node_index) ? *a.n_index : a.n_nodes;  // (pass 2 of a two-pass launch: the length of the deep list)
-  const uint32_t node0 = DFS ? 0u : blockIdx.x * B;
-  if (!DFS && node0 >= n_eff) return;
-  const uint32_t nb = DFS ? 1u : min(B, n_eff - node0);
+  // PERSISTENT tiles: workgroup g runs the tiles g, g + gridDim.x, ... (the host launches at most as many workgroups as fit the chip at
+  // once).  The kernel's entry (arguments, the lists' offsets) is paid once per workgroup, not per tile, and nothing drains between
+  // a tile's last barrier and the next tile's first loads.
+  const uint32_t n_tiles = DFS ? 1u : (n_eff + B - 1) / B;
+  uint32_t tile = blockIdx.x;
+  if (!DFS && tile >= n_tiles) return;
+  uint32_t node0 = DFS ? 0u : tile * B;
+  uint32_t nb = DFS ? 1u : min(B, n_eff - node0);
   auto dom_of = [&](uint32_t b, Ctr* c) { return TDom{dom + b, B, sh, chg + (size_t)b * Wv, misc, 1u << b, c}; };
 
   // ---- phase 0: stage the domains (16-byte row loads), find the assigned variables ------------------------------------------
@@ -281,14 +315,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint32_t* const adjo = reinterpret_cast<uint32_t*>(smem + cv.adj);
   // (the first four offsets per thread are only LOADED here and stored behind the staging loads below: one memory round trip
   // for both instead of two in a row)
-  const bool ptime = (a.debug & 32u) != 0;  // profiling: s_memtime ticks per phase, summed over workgroups into the counters
-  const uint64_t pt0 = ptime ? __builtin_amdgcn_s_memtime() : 0;
-  uint64_t pt1 = 0, pt2 = 0, pt3 = 0;
-  uint32_t adj_pre[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; adj_pre[j] = a.m.adj_off[min(v, V)]; }
-  for (uint32_t v = tid + 4 * nth; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
-  bool adj_stored = false;
+  const bool ptime = PCP_NEQ_PROFILE && (a.debug & 32u) != 0;  // profiling: s_memtime ticks per phase, summed over workgroups into the counters
+  uint64_t pt0 = ptime ? __builtin_amdgcn_s_memtime() : 0;
+  uint64_t rt0 = ptime ? __builtin_amdgcn_s_memrealtime() : 0;  // (100 MHz: the launch's timeline across workgroups)
+  uint64_t pt1 = 0, pt2 = 0, pt3 = 0, pta = 0, ptb = 0, ptc = 0;
+  // (loaded behind the first tile's zeroing barrier, together with its row loads — hipcc drains outstanding loads at a barrier)
+  uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
+  bool adj_loaded = false, adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
@@ -303,8 +336,14 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint32_t c_err = 0;
   if constexpr (DFS) { dfs_sp = *a.dfs.sp; dfs_stop = *a.dfs.stop; c_nodes = a.dfs.counters[0]; c_sols = a.dfs.counters[1]; c_fail = a.dfs.counters[2]; }
   const int lim = PACKED ? kPackedMax : kBoundMax;
-  for (uint32_t dfs_it = 0;; ++dfs_it) {
+  uint32_t* const misc_base = misc;
+  // a persistent workgroup's counters over its tiles: seven u64 in LDS behind the two copies of the status words, touched by thread 0 only
+  // (in registers they cost the tile loop fourteen VGPRs it does not have)
+  unsigned long long* const accl = reinterpret_cast<unsigned long long*>(misc_base + 2 * 48);
+  if (!DFS && tid == 0) { for (int i = 0; i < 7; ++i) accl[i] = 0ull; }
+  for (uint32_t dfs_it = 0;; ++dfs_it) {  // DFS: the search loop's nodes; otherwise this workgroup's tiles
   bool resume = false;
+  if constexpr (!DFS) misc = misc_base + (dfs_it & 1u) * 48u;
   if constexpr (DFS) {
     if (dfs_sp == 0 || dfs_stop || dfs_it >= a.dfs.n_steps) break;
     const size_t off = (tree_row0 + (dfs_sp - 1)) * V;
@@ -315,6 +354,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   if (tid < nb) misc[N_NID + tid] = (!DFS && a.node_index) ? a.node_index[node0 + tid] : node0 + tid;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   __syncthreads();
+  PCP_TR(1);
+  if (!adj_loaded) {
+    adj_loaded = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; adj_pre[j] = a.m.adj_off[min(v, V)]; }
+    for (uint32_t v = tid + 4 * nth; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
+  }
   // DFS rows may have been written by this very workgroup a moment ago: they are read past the L1 (relaxed agent-scope loads)
   const bool vec = !DFS && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0;
   if (resume) {
@@ -343,29 +389,55 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     };
     const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
     if (vec) {
-      constexpr int UF = 4;  // row loads in flight per lane: 2 * UF * 16 bytes
+      // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight
+      // 16-byte pairs per lane = 64 VGPRs): one memory round trip per tile instead of two in a row
+      constexpr int UF = 8;
+      // task t = (node t / SQ, quad t % SQ); a lane's tasks are nth apart: one division per lane, then (node, quad) move by a fixed step
+      const uint32_t dq = nth % SQ, db = nth / SQ;
+      uint32_t bs = tid / SQ, qs = tid - bs * SQ;
+      auto step = [&](uint32_t& bq, uint32_t& qq) { qq += dq; bq += db; if (qq >= SQ) { qq -= SQ; ++bq; } };
+      const bool gather = !DFS && a.node_index != nullptr;  // (pass 2 of a two-pass launch: the tile's nodes come through a list)
+      // (a tile's rows are contiguous otherwise: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
+      // pair of loads, which lb and ub share; sixteen 64-bit addresses would take 32 of the VGPRs the loaded rows need)
+      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
       for (uint32_t t0 = tid; t0 < tasks; t0 += UF * nth) {
         int4 L[UF], U[UF];
-        uint32_t bq[UF], qq[UF];
+        uint32_t bq = bs, qq = qs;
+        if (!gather) {
 #pragma unroll
-        for (int j = 0; j < UF; ++j) {
-          const uint32_t t = min(t0 + j * nth, tasks - 1);
-          bq[j] = t / SQ; qq[j] = t - bq[j] * SQ;
-          const size_t row = (size_t)misc[N_NID + bq[j]] * V;
-          L[j] = reinterpret_cast<const int4*>(a.lb_in + row)[qq[j]];
-          U[j] = reinterpret_cast<const int4*>(a.ub_in + row)[qq[j]];
+          for (int j = 0; j < UF; ++j) {
+            const uint32_t off = t0 + j * nth < tasks ? (bq * V + 4u * qq) * 4u : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
+            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
+            L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
+            U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
+            step(bq, qq);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < UF; ++j) {
+            const bool on = t0 + j * nth < tasks;
+            const size_t row = (size_t)a.node_index[node0 + (on ? bq : 0u)] * V;
+            L[j] = reinterpret_cast<const int4*>(a.lb_in + row)[on ? qq : 0u];
+            U[j] = reinterpret_cast<const int4*>(a.ub_in + row)[on ? qq : 0u];
+            step(bq, qq);
+          }
         }
         if (!adj_stored) {
           adj_stored = true;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
         }
+        bq = bs; qq = qs;
 #pragma unroll
         for (int j = 0; j < UF; ++j) {
           if (t0 + j * nth >= tasks) break;
           const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
-          put(bq[j], 4 * qq[j], l, u, 4);
+          put(bq, 4 * qq, l, u, 4);
+          step(bq, qq);
         }
+        bs = bq; qs = qq;
       }
     } else {
       for (uint32_t t = tid; t < tasks; t += nth) {
@@ -399,7 +471,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
   }
+  PCP_TR(2);
   __syncthreads();
+  PCP_TR(3);
   if (ptime) pt1 = __builtin_amdgcn_s_memtime();
   if (misc[N_OOB] && tid == 0) atomicMax(a.violation, 1u);  // sticky: reported by pcp_stats_read
 
@@ -436,61 +510,73 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
     // here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
     // marks and are listed by the next round.
-    // One WAVEFRONT per mask word, lane b = node b: a ballot per bit gives the node mask of a variable directly (one thread per
-    // word read the B words of every bit one after the other: a chain of dependent LDS reads that was most of a shallow tile's
-    // round).
+    // One WAVEFRONT per mask word, lane b = node b.  Four words per step with their LDS reads in flight together; the variables of
+    // a word come out of ballots and readlanes alone: the lanes that still hold an unlisted bit are balloted, the first of them names
+    // a bit, a second ballot over that bit is the variable's node mask.  (One ballot per bit position of every non-empty word, each
+    // behind a dependent LDS read, made this pass 10 000 cycles of a frontier tile's 45 000 for ONE listed variable.)
     {
       uint32_t rm = 0;
-      for (uint32_t w = wv; w < Wv; w += nwv) {
-        uint32_t x = 0;
-        if (lane < nb) {
-          x = chg[lane * Wv + w];
-          if ((inert >> lane) & 1u) { if (x) chg[lane * Wv + w] = 0; x = 0; }  // a failed or refused node is inert
-        }
-        if (__ballot(x != 0) == 0) continue;
-        uint32_t taken = 0;
-        for (uint32_t i = 0; i < 32; ++i) {
-          const uint32_t M = (uint32_t)__ballot((x >> i) & 1u);  // (lanes >= nb hold 0)
-          if (!M) continue;
-          // lane 0 emits the entry (wave-uniform values: every lane computes them, one writes)
-          uint32_t pos = 0;
-          if (lane == 0) pos = atomicAdd(&misc[m_count], 1u);
-          pos = __builtin_amdgcn_readfirstlane(pos);
-          if (pos >= kListCap) {  // full: this variable and the rest wait for the next round
-            if (lane == 0) { atomicSub(&misc[m_count], 1u); misc[N_MORE] = round + 1; }
-            break;
-          }
-          taken |= 1u << i;
-          const uint32_t v = (w << 5) + i;
-          const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
-          // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
-          uint32_t wsel = kNoWin | (kNoWin << 16);
-          if (round && wcap && __popc(M) <= 2) {
-            uint32_t k = 0;
-            for (uint32_t m = M; m; m &= m - 1, ++k) {
-              const uint32_t b = (uint32_t)__builtin_ctz(m);
-              const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
-              if (d.x >= d.y) continue;
-              uint32_t wi = 0;
-              if (lane == 0) wi = atomicAdd(&misc[m_win], 1u);
-              wi = __builtin_amdgcn_readfirstlane(wi);
-              if (wi >= wcap) continue;
-              if (lane == 0) {
-                Win nw;
-                nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
-                win[wi] = nw;
-              }
-              wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
+      bool list_full = false;
+      for (uint32_t w0 = wv; w0 < Wv && !list_full; w0 += 4 * nwv) {
+        uint32_t xs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t w = w0 + j * nwv; xs[j] = (lane < nb && w < Wv) ? chg[lane * Wv + w] : 0u; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t w = w0 + j * nwv;
+          uint32_t x = xs[j];
+          if ((inert >> lane) & 1u) { if (x) chg[lane * Wv + w] = 0; x = 0; }  // a failed or refused node is inert  (lanes >= nb hold 0)
+          uint32_t taken = 0;  // wave-uniform: the bits of this word listed so far
+          while (!list_full) {
+            const unsigned long long holders = __ballot((x & ~taken) != 0u);
+            if (!holders) break;
+            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)(x & ~taken), (int)__builtin_ctzll(holders));
+            const uint32_t i = (uint32_t)__builtin_ctz(xf);
+            const uint32_t M = (uint32_t)__ballot((x >> i) & 1u);
+            // lane 0 emits the entry (wave-uniform values: every lane computes them, one writes)
+            uint32_t pos = 0;
+            if (lane == 0) pos = atomicAdd(&misc[m_count], 1u);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            if (pos >= kListCap) {  // full: this variable and the rest wait for the next round
+              if (lane == 0) { atomicSub(&misc[m_count], 1u); misc[N_MORE] = round + 1; }
+              list_full = true;
+              break;
             }
+            taken |= 1u << i;
+            const uint32_t v = (w << 5) + i;
+            const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
+            // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
+            uint32_t wsel = kNoWin | (kNoWin << 16);
+            if (round && wcap && __popc(M) <= 2) {
+              uint32_t k = 0;
+              for (uint32_t m = M; m; m &= m - 1, ++k) {
+                const uint32_t b = (uint32_t)__builtin_ctz(m);
+                const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
+                if (d.x >= d.y) continue;
+                uint32_t wi = 0;
+                if (lane == 0) wi = atomicAdd(&misc[m_win], 1u);
+                wi = __builtin_amdgcn_readfirstlane(wi);
+                if (wi >= wcap) continue;
+                if (lane == 0) {
+                  Win nw;
+                  nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
+                  win[wi] = nw;
+                }
+                wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
+              }
+            }
+            if (lane == 0) list[pos] = make_uint4(v | (M << 16), o0, dg, wsel);
+            rm |= M;
           }
-          if (lane == 0) list[pos] = make_uint4(v | (M << 16), o0, dg, wsel);
-          rm |= M;
+          if (lane < nb && (x & taken)) chg[lane * Wv + w] = x & ~taken;
         }
-        if (lane < nb && (x & taken)) chg[lane * Wv + w] = x & ~taken;
       }
       if (rm && lane == 0) atomicOr(&misc[m_rmask], rm);
     }
+    if (round == 0) PCP_TR(4);
     __syncthreads();
+    if (round == 0) PCP_TR(5);
+    if (ptime && round == 0) pta = __builtin_amdgcn_s_memtime();
     const uint32_t total = min(misc[m_count], kListCap);
     const uint32_t nwin = min(misc[m_win], wcap);
     if (total == 0 || (a.debug & 1u) || ((a.debug & 4u) && round == 1)) break;
@@ -531,7 +617,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         }
       };
       uint32_t my_ev = 0;
-      const bool timing = (a.debug & 8u) != 0;  // profiling: s_memtime ticks of the walk / of the node loops, pieces (counters overloaded)
+      const bool timing = PCP_NEQ_PROFILE && (a.debug & 8u) != 0;  // profiling: s_memtime ticks of the walk / of the node loops, pieces (counters overloaded)
       uint64_t t_walk0 = 0, t_inner = 0, n_pieces = 0;
       if (timing) t_walk0 = __builtin_amdgcn_s_memtime();
       auto process = [&](const Piece& pc, const Pay (&q)[4]) {
@@ -672,6 +758,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       Piece pa = next_piece(), pb, pc3;
       Pay qA[4], qB[4], qC[4];
       load(pa, qA);
+      if (round == 0) PCP_TR(6);
       pb = next_piece(); load(pb, qB);
       while (pa.deg) {
         pc3 = next_piece(); load(pc3, qC);
@@ -694,7 +781,11 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     // (the barrier also answers "did this round narrow anything?": if not — the usual case of a shallow tile's sweep round — no
     // variable is marked and the next round's list pass and barrier are skipped)
     // (the count of narrowing threads also says whether this round was a cascade: only then is the next round's cover priced)
+    if (ptime && round == 0) ptb = __builtin_amdgcn_s_memtime();
+    if (round == 0) PCP_TR(7);
     const uint32_t n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
+    if (round == 0) PCP_TR(8);
+    if (ptime && round == 0) ptc = __builtin_amdgcn_s_memtime();
     const bool narrowed = n_narrowing != 0;
     cascade = n_narrowing >= kCascadeThreads;
     if (!narrowed && !nwin && misc[N_MORE] != round + 1) break;
@@ -730,44 +821,62 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   }
 
   if (ptime) pt2 = __builtin_amdgcn_s_memtime();
+  PCP_TR(9);
   // ---- status: is any record NOT entailed under the final domains? (store.rs:250-256) ------------------------
   // Records of two assigned variables are entailed at a fixpoint that did not fail (two different values: disjoint), so only the
   // lists of unassigned variables can hold an open record; x != y + d is entailed iff the intervals are disjoint
   // (x_neq_y.rs:71-73 via x_eq_y.rs:87-93).
+  // Two nodes per wavefront at a time, one per 32-lane half: a node's scan is a chain of dependent LDS and memory reads (cells -> the
+  // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
+  // chains one after the other in every wavefront.
   {
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
-    for (uint32_t b = wv; b < nb; b += nwv) {
-      if (((inert >> b) & 1u) || (a.debug & 2u)) continue;
-      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
+    for (uint32_t b0 = wv; b0 < nb; b0 += 2 * nwv) {
+      // (a wavefront with one node left gives it all 64 lanes: the search loop's single node, the odd node of a ragged tile)
+      const bool pair = !DFS && b0 + nwv < nb;                            // wave-uniform (the search loop has one node: folded away)
+      const uint32_t hw = pair ? 32u : 64u, hl = lane & (hw - 1u), hb = pair ? lane >> 5 : 0u;
+      const uint32_t b = b0 + hb * nwv;                                   // this half's node
+      bool done = ((inert >> b) & 1u) || (a.debug & 2u);                  // (uniform within a half)
       bool open = false;
-      for (uint32_t base = 0; base < V && !open; base += 64) {
-        const uint32_t vv = base + lane;
+      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
+      auto mine = [&](unsigned long long bal) { return pair ? (unsigned long long)(uint32_t)(bal >> (32u * hb)) : bal; };
+      for (uint32_t base = 0; base < V; base += hw) {
+        if (!__ballot(!done)) break;
+        const uint32_t vv = base + hl;
         bool wide = false;
-        if (vv < V) { const int2 d = cellb(vv); wide = d.x < d.y; }
-        uint64_t bal = __ballot(wide);
-        while (bal && !open) {
-          const uint32_t u = base + (uint32_t)__builtin_ctzll(bal);
-          bal &= bal - 1;
-          const int2 Ud = cellb(u);
-          const uint32_t o0 = adjo[u], deg = adjo[u + 1] - o0;
-          for (uint32_t k = 0; k < deg && !open; k += 64) {
+        if (!done && vv < V) { const int2 d = cellb(vv); wide = d.x < d.y; }
+        unsigned long long cand = mine(__ballot(wide));                   // this half's unassigned variables among these
+        for (;;) {
+          const bool has = !done && cand != 0ull;
+          if (!__ballot(has)) break;
+          const uint32_t u = has ? base + (uint32_t)__builtin_ctzll(cand) : 0u;
+          cand &= cand - 1ull;
+          int2 Ud = make_int2(0, 0);
+          uint32_t o0 = 0, deg = 0;
+          if (has) { Ud = cellb(u); o0 = adjo[u]; deg = adjo[u + 1] - o0; }
+          for (uint32_t k = 0;; k += hw) {
+            const bool go = has && !open && k < deg;
+            if (!__ballot(go)) break;
             bool op = false;
-            if (k + lane < deg) {
-              const Pay q = pay[o0 + k + lane];
+            if (go && k + hl < deg) {
+              const Pay q = pay[o0 + k + hl];
               const int t = pay_t(q);
               const int2 O = cellb(pay_other(q));
               op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));  // not disjoint
             }
-            open = __ballot(op) != 0;
+            if (mine(__ballot(op))) open = true;
           }
+          if (open) done = true;
         }
       }
-      if (open && lane == 0) atomicOr(&misc[N_UNK], 1u << b);
+      if (open && hl == 0) atomicOr(&misc[N_UNK], 1u << b);
     }
   }
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
+  PCP_TR(10);
   __syncthreads();
+  PCP_TR(11);
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
   {
     const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
@@ -796,14 +905,21 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
     if (badm) atomicOr(&misc[N_FAIL], badm);
   }
-  for (int o = 32; o > 0; o >>= 1) { ctr.narrow += __shfl_down(ctr.narrow, o); ctr.ev += __shfl_down(ctr.ev, o); ctr.full += __shfl_down(ctr.full, o); ev0 += __shfl_down(ev0, o); }
-  if (lane == 0) {
-    if (ctr.narrow) atomicAdd(&misc[N_NARROW], ctr.narrow);
-    if (ctr.ev) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_EV]), (unsigned long long)ctr.ev);
-    if (ctr.full) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_FULL]), (unsigned long long)ctr.full);
-    if (ctr.ev - ev0) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_STEPS]), (unsigned long long)(ctr.ev - ev0));
+  // the counters: wave sums by DPP (VALU only), then one lane adds them to the tile's LDS words.  (The wave reductions that used to
+  // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
+  // address were tried instead and cost 8 800.)
+  {
+    const unsigned long long s_narrow = wave_sum64(ctr.narrow), s_ev = wave_sum64(ctr.ev), s_full = wave_sum64(ctr.full), s_ev0 = wave_sum64(ev0);
+    if (lane == 0) {
+      if (s_narrow) atomicAdd(&misc[N_NARROW], (uint32_t)s_narrow);
+      if (s_ev) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_EV]), s_ev);
+      if (s_full) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_FULL]), s_full);
+      if (s_ev - s_ev0) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_STEPS]), s_ev - s_ev0);
+    }
   }
+  PCP_TR(12);
   __syncthreads();
+  PCP_TR(13);
   if (tid < nb) {
     const bool failed = (misc[N_FAIL] >> tid) & 1u, refused = (misc[N_OOB] >> tid) & 1u;
     const bool none_open = !((misc[N_UNK] >> tid) & 1u);
@@ -816,10 +932,12 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const unsigned long long sev = *reinterpret_cast<unsigned long long*>(&misc[N_EV]), sfu = *reinterpret_cast<unsigned long long*>(&misc[N_FULL]);
     const uint32_t nf = __popc(misc[N_FAIL] & (nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)));
     if constexpr (DFS) {
-      // the search loop adds its counters up in registers and hands them over once per launch: six same-address atomics per node
-      // are nothing for one tree and serialise a forest of hundreds (pcp_dfs_forest_device)
+      // the counters are added up in registers and handed over once per launch: six same-address atomics per node are nothing for one
+      // tree and serialise a forest of hundreds (pcp_dfs_forest_device)
       acc_steps += s2; acc_narrow += misc[N_NARROW]; acc_ev += sev; acc_full += sfu; acc_waves += nb + misc[N_WAVES]; acc_nodes += nb; acc_failed += nf;
-    } else {
+    } else if (!PCP_NEQ_PROFILE || !(a.debug & (8u | 32u))) {
+      accl[0] += s2; accl[1] += misc[N_NARROW]; accl[2] += sev; accl[3] += sfu; accl[4] += nb + misc[N_WAVES]; accl[5] += nb; accl[6] += nf;
+    } else {  // (profiling builds of a launch: the counters carry timers, per tile)
       atomicAdd((unsigned long long*)&a.stats->steps, s2);
       if (misc[N_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[N_NARROW]);
       if (sev) atomicAdd((unsigned long long*)&a.stats->evaluated, sev);
@@ -828,7 +946,15 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(pt1 - pt0));        // staging
         atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)(pt2 - pt1));  // rounds
         atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(pt3 - pt2));         // status scan
-        atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)(__builtin_amdgcn_s_memtime() - pt3));  // write-back, counters
+        const uint64_t pt4 = __builtin_amdgcn_s_memtime();
+        atomicAdd((unsigned long long*)&a.stats->full_evals, (unsigned long long)(pt4 - pt3));  // write-back, counters
+        if (a.dbg && !((a.debug & 2048u) && blockIdx.x >= gridDim.x / 2) && !((a.debug & 4096u) && blockIdx.x < gridDim.x / 2)) {  // (2048 / 4096: first / second half of the grid only) the same, finer, and the launch's timeline (100 MHz ticks): pcp_debug_counters slots 5..15
+          if (pta == 0) pta = ptb = ptc = pt2;  // (the tile never reached round 0's walk)
+          if (ptb == 0) ptb = ptc = pt2;
+          atomicAdd(&a.dbg[8], pt1 - pt0); atomicAdd(&a.dbg[9], pta - pt1); atomicAdd(&a.dbg[10], ptb - pta); atomicAdd(&a.dbg[11], ptc - ptb);
+          atomicAdd(&a.dbg[12], pt2 - ptc); atomicAdd(&a.dbg[13], pt3 - pt2); atomicAdd(&a.dbg[14], pt4 - pt3); atomicAdd(&a.dbg[15], 1ull);
+          atomicMax(&a.dbg[5], ~rt0); atomicMax(&a.dbg[6], (unsigned long long)__builtin_amdgcn_s_memrealtime()); atomicMax(&a.dbg[7], rt0);
+        }
       }
       if (!(a.debug & (8u | 32u))) atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)(nb + misc[N_WAVES]));
       atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)nb);
@@ -836,7 +962,15 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
   }
   if constexpr (!DFS) {
-    break;
+    PCP_TR(14);
+    if (tr_on && lane < 16) a.trace[((size_t)tile * 16 + wv) * 16 + lane] = lane == 15 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : trbuf[wv * 16 + lane];
+    // the next tile of this workgroup.  No barrier here: the next tile clears the OTHER copy of the status words, its cells are not
+    // written before its own first barrier, and every wavefront left the last tile's cells behind the barrier above.
+    tile += gridDim.x;
+    if (tile >= n_tiles) break;
+    node0 = tile * B; nb = min(B, n_eff - node0);
+    if (ptime) { pt0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); pta = ptb = ptc = 0; }
+    PCP_TR(0);
   } else {
     // ---- the search step on the node just propagated (what dfs_step_kernel does for the generic kernels) ---------------------
     __syncthreads();
@@ -898,20 +1032,22 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     dfs_sp = new_sp;
     __syncthreads();
   }
-  }  // the DFS loop (one pass otherwise)
-  if constexpr (DFS) {
-    if (tid == 0) {
-      if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
-      if (acc_narrow) atomicAdd((unsigned long long*)&a.stats->narrowings, acc_narrow);
-      if (acc_ev) atomicAdd((unsigned long long*)&a.stats->evaluated, acc_ev);
-      if (acc_full) atomicAdd((unsigned long long*)&a.stats->full_evals, acc_full);
-      if (acc_waves) atomicAdd((unsigned long long*)&a.stats->waves, acc_waves);
-      if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
-      if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
+  }  // the DFS loop / the tile loop
+  if (tid == 0) {
+    if constexpr (!DFS) { acc_steps = accl[0]; acc_narrow = accl[1]; acc_ev = accl[2]; acc_full = accl[3]; acc_waves = accl[4]; acc_nodes = accl[5]; acc_failed = accl[6]; }
+    if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
+    if (acc_narrow) atomicAdd((unsigned long long*)&a.stats->narrowings, acc_narrow);
+    if (acc_ev) atomicAdd((unsigned long long*)&a.stats->evaluated, acc_ev);
+    if (acc_full) atomicAdd((unsigned long long*)&a.stats->full_evals, acc_full);
+    if (acc_waves) atomicAdd((unsigned long long*)&a.stats->waves, acc_waves);
+    if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
+    if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
+    if constexpr (DFS) {
       *a.dfs.sp = dfs_sp; *a.dfs.stop = dfs_stop;
       a.dfs.counters[0] = c_nodes; a.dfs.counters[1] = c_sols; a.dfs.counters[2] = c_fail;
       if (c_err) a.dfs.counters[3] = c_err;
     }
+    if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : (n_tiles - 1 - blockIdx.x) / gridDim.x + 1));
   }
 }
 

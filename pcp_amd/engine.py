@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -121,11 +121,12 @@ def load_library():
     L.pcp_dfs_forest_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, u32, C.c_uint64, vp]
     L.pcp_stats_reset.argtypes = [vp, vp]
     L.pcp_stats_read.argtypes = [vp, C.POINTER(PcpStats), vp]
+    L.pcp_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), u32, vp]
     L.pcp_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -441,6 +442,16 @@ class Context:
         st = PcpStats()
         self._check(self._L.pcp_stats_read(self._h, C.byref(st), C.c_void_p(stream_ptr)))
         return st.as_dict()
+
+    DBG = {"big_dense": 0, "big_sparse": 1, "neq_tiles": 2, "neq_overlap": 3, "small_nodes": 4}
+
+    def debug_counters(self, stream_ptr: int = 0) -> dict:
+        """Kernel-internal diagnostic counters since the last stats_reset (pcp_debug_counters, ABI v6): which code paths ran."""
+        out = (C.c_uint64 * 16)()
+        self._check(self._L.pcp_debug_counters(self._h, out, 16, C.c_void_p(stream_ptr)))
+        d = {k: int(out[i]) for k, i in self.DBG.items()}
+        d["raw"] = [int(x) for x in out]
+        return d
 
     def last_plan(self) -> dict:
         """pcp_last_plan: the launch geometry of the last propagate call."""

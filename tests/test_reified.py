@@ -205,3 +205,68 @@ def test_formula_contract(ctx):
         ctx.push_formula(nodes, two)      # a leaf nobody uses
     ctx.truncate(0)
     assert ctx.n_units == 0
+
+
+@pytest.mark.gpu
+def test_device_dfs_on_a_cumulative_model(ctx):
+    """pcp_dfs_device on a store with formula units: every step must propagate the node on TOP of the stack — the
+    formula kernel used to run row 0 whatever the stack pointer said, so left subtrees were silently skipped.  Whole search (first
+    solution, then all solutions) == the oracle's DFS over the same model, counter for counter."""
+    vs, cs = M.VStore(), M.CStore()
+    starts = [vs.alloc((0, 5)) for _ in range(4)]
+    durations = [M.Constant(d) for d in (3, 2, 2, 1)]
+    resources = [M.Constant(r) for r in (2, 1, 2, 1)]
+    cap = vs.alloc((3, 3))
+    M.Cumulative(starts, durations, resources, cap).join(vs, cs)
+    V = len(vs)
+    om = orc.OracleModel(V)
+    M.push_model(om, cs, V)
+    M.push_model(ctx, cs, V)
+    lb0, ub0 = vs.bounds()
+    ss1, _, _, sol1 = om.search(lb0, ub0, all_solutions=False)
+    one = ctx.dfs_device(lb0, ub0, 100000, capacity=256, stop_on_solution=True, chunk=32)
+    assert ctx.last_plan()["path"] == 3
+    assert ss1["num_nodes"] > 3
+    assert (one["nodes"], one["solutions"], one["failed"], one["error"]) == (ss1["num_nodes"], ss1["num_solution"], ss1["num_failed_node"], 0)
+    if ss1["num_solution"]:
+        assert np.array_equal(one["first_solution"], sol1)
+    ssa, _, _, _ = om.search(lb0, ub0, all_solutions=True, node_limit=3000)
+    al = ctx.dfs_device(lb0, ub0, 100000, capacity=256, stop_on_solution=False, node_limit=3000, chunk=97)
+    assert (al["nodes"], al["solutions"], al["failed"]) == (ssa["num_nodes"], ssa["num_solution"], ssa["num_failed_node"])
+    assert ssa["num_failed_node"] > 0 and ssa["num_solution"] > 0
+
+
+@pytest.mark.gpu
+def test_formula_at_the_depth_limit(ctx):
+    """A unit nested to the eight levels lower_formula accepts (alternating Or / And down to a leaf at level 8), next to plain
+    units: the kernel's tree walk at its deepest."""
+    rng = splitmix64(4242)
+    vs, cs = M.VStore(), M.CStore()
+    xs = [vs.alloc((0, 7)) for _ in range(10)]
+    bs = [vs.alloc((0, 1)) for _ in range(4)]
+
+    def leaf():
+        a, b = (xs[i] for i in rng.choice(10, size=2, replace=False))
+        k = int(rng.integers(0, 3))
+        off = int(rng.integers(-2, 3))
+        return (M.XNeqY, M.XEqY, M.XLessY)[k](a, M.Addition(b, off))
+
+    def nest(depth):  # a tree of exactly `depth` levels
+        if depth == 1:
+            return leaf()
+        side = M.Boolean(bs[int(rng.integers(0, 4))]) if depth % 2 == 0 else leaf()
+        kids = (nest(depth - 1), side) if rng.random() < 0.5 else (side, nest(depth - 1))
+        return M.Or(kids) if depth % 2 == 0 else M.And(kids)
+
+    for _ in range(6):
+        f = nest(8)
+        nodes, _ = M.lower_formula(f, len(vs))
+        assert len(nodes) >= 15
+        cs.alloc(f)
+    for _ in range(4):
+        cs.alloc(leaf())
+    with pytest.raises(M.ContractViolation):
+        M.lower_formula(M.Or((nest(8), leaf())), len(vs))  # nine levels: refused by the host mirror
+    L, U = random_boxes(4243, vs, 300)
+    ref, _ = gpu_vs_oracle(ctx, vs, cs, L, U, "depth-8 formulas")
+    assert (ref[3] == 0).any() and (ref[3] != 0).any()

@@ -43,6 +43,13 @@ def timeit(lb, ub, opts, reps=5):
         s = ctx.stats_read()
         g_ = pl["grid"]
         print(f"    phase ticks per workgroup (avg): staging {s['steps3']/g_:.0f}  rounds {s['failed_nodes']/g_:.0f}  status {s['waves']/g_:.0f}  write-back+counters {s['full_evals']/g_:.0f}")
+        r = ctx.debug_counters()["raw"]
+        if r[15]:
+            k = r[15]
+            names = ["staging", "r0 list build", "r0 walk (wave 0)", "r0 end barrier", "later rounds", "status", "write-back+counters"]
+            print("    finer (avg ticks per workgroup): " + "  ".join(f"{nm} {r[8 + i] / k:.0f}" for i, nm in enumerate(names)))
+            first = (~r[5]) & 0xFFFFFFFFFFFFFFFF
+            print(f"    timeline (100 MHz): first workgroup start 0, last start {(r[7] - first) / 100:.2f} us, last end {(r[6] - first) / 100:.2f} us; workgroups {k}")
     if opts.get("neq_debug", 0) & 8:
         ctx.stats_reset()
         l, u = lb.clone(), ub.clone()
@@ -53,7 +60,10 @@ def timeit(lb, ub, opts, reps=5):
         print(f"    timers (round 0, per wavefront avg): walk {s['steps3']/nw:.0f} ticks, node loops {s['failed_nodes']/nw:.0f} ticks, pieces {(s['waves']-N)/nw:.1f}; evaluated {s['evaluated']:.3e}")
     return float(np.median(ms)), pl
 
-configs = [{}, {"neq_debug": 32}, {"neq_debug": 3}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "neq_block": 512}, {"nodes_per_block": 16, "neq_block": 1024}, {"neq_path": 0}]
+configs = [{}, {"neq_block": 256}, {"neq_block": 384}, {"neq_block": 320}, {"neq_persist": 0}, {"neq_debug": 3}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "neq_block": 512}, {"nodes_per_block": 16, "neq_block": 1024}, {"neq_path": 0}]
+if "frontier" in batches:  # one generation of tiles only (512 tiles = two per CU): what the first wave of workgroups costs by itself
+    l8, u8 = batches["frontier"]
+    batches["frontier-half"] = (l8[:8192].contiguous(), u8[:8192].contiguous())
 for name, (lb, ub) in batches.items():
     for c in configs:
         ms, pl = timeit(lb, ub, c)

@@ -1,0 +1,51 @@
+"""Per-wavefront event stamps of the headline launch (option neq_trace_ptr, pcp_neq.hip PCP_TR): where does a frontier tile's time go,
+and which wavefront does every barrier wait for?  usage: python tools/neq_trace.py [nodes]"""
+import sys, os, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as g
+g.build()
+import pcp_amd.engine as E
+from pcp_amd import model as M, workloads as W
+
+n = 1000
+N = int(sys.argv[1]) if len(sys.argv) > 1 and "=" not in sys.argv[1] else 16384
+OPTS = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+ctx = E.Context(0)
+ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
+for k_, v_ in OPTS.items():
+    ctx.set_option(k_, v_)
+print("options", OPTS)
+dev = torch.device("cuda", 0)
+L, U, _ = W.nqueens_frontier(ctx, n, N, share=0, shares=8, implicit=True)
+lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+st = torch.zeros(N, dtype=torch.uint8, device=dev)
+names = ["entry", "zeroed", "staged (arrive)", "staged (released)", "list built (arrive)", "list built (released)", "first payload loads issued",
+         "walk done (arrive)", "round end (released)", "rounds done", "status done (arrive)", "status (released)", "counters (arrive)", "counters (released)", "end"]
+for rep in range(3):
+    l, u = lb.clone(), ub.clone()
+    tiles = (N + 15) // 16
+    tr = torch.zeros((tiles, 16, 16), dtype=torch.int64, device=dev)
+    ctx.set_option("neq_trace_ptr", tr.data_ptr())
+    torch.cuda.synchronize()
+    ctx.propagate_device(N, l, u, l, u, None, None, st)
+    torch.cuda.synchronize()
+    ms = ctx.last_kernel_ms()
+    ctx.set_option("neq_trace_ptr", 0)
+    pl = ctx.last_plan()
+    nwv = pl["block"] // 64
+    t = tr.cpu().numpy()[:, :nwv, :]
+    rel = t[:, :, :15] - t[:, :1, :1]           # ticks since wavefront 0's entry
+    if rep < 2:
+        continue
+    print(f"kernel {ms * 1e3:.1f} us, grid {pl['grid']} x {pl['block']} threads")
+    rt = t[:, 0, 15]
+    print(f"realtime (100 MHz) end stamps: first {(rt.min() - rt.min()) / 100:.1f} us ... last {(rt.max() - rt.min()) / 100:.1f} us")
+    half = tiles // 2
+    for lo, hi, what in ((0, half, "first half of the grid"), (half, tiles, "second half")):
+        r = rel[lo:hi]
+        print(f"-- {what}: ticks since wavefront 0 entered, mean over tiles: [wavefront 0] [earliest wavefront] [latest wavefront] (latest - earliest)")
+        for k, nm in enumerate(names):
+            col = r[:, :, k]
+            print(f"  {k:2d} {nm:28s} w0 {col[:, 0].mean():8.0f}   min {col.min(axis=1).mean():8.0f}   max {col.max(axis=1).mean():8.0f}   spread {(col.max(axis=1) - col.min(axis=1)).mean():7.0f}   latest wave (mode) {np.bincount(col.argmax(axis=1)).argmax()}")

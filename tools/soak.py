@@ -15,6 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = E.Context(0)
 t0, it, checked = time.time(), 0, 0
+paths = {0: 0, 1: 0, 2: 0, 3: 0}
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed0 + it)
     n = int(rng.integers(20, 110))
@@ -70,5 +71,38 @@ while time.time() - t0 < budget:
             assert_parity(ref_i[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} {opts} [implicit]")
             checked += 1
         ctx.set_option("force_path", 0)
+    # ---- the specialised implicit-node kernels, path drawn and ASSERTED: 1 = assignment-driven (all-XNeqY), 2 = 10-bit cells (any
+    # binary model under a declared hull of <= 1024 values), 0 = the generic kernels under the same options
+    want = int(rng.choice([0, 1, 2]))
+    for k, v in {"nodes_per_block": 0, "force_path": 0, "block_threads": 1024, "global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0}.items():
+        ctx.set_option(k, v)
+    ctx.set_model(n, props)
+    ctx.set_hull(lo, hi)
+    if want == 2:
+        ctx.set_option("global_dom", 2); ctx.set_option("big_round", int(rng.integers(0, 3)))
+    elif want == 0:
+        ctx.set_option("neq_path", 0); ctx.set_option("big_path", 0)
+    got = ctx.propagate_implicit(L, U)
+    path = ctx.last_plan()["path"]
+    expect = 2 if want == 2 else (1 if (want == 1 and kinds == [M.NEQ]) else 0)
+    assert path == expect, (path, expect, want, kinds)
+    assert_parity(ref_i[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} path={path} [implicit]")
+    paths[path] += 1
+    checked += 1
+    for k, v in {"global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0}.items():
+        ctx.set_option(k, v)
+    if rng.random() < 0.3:  # path 3: a random store of formula units (the reified layer), explicit rows and implicit nodes
+        from test_reified import random_formula_store, random_boxes
+        vs, cs = random_formula_store(seed0 + 13 * it, n_vars=int(rng.integers(5, 14)), n_units=int(rng.integers(4, 24)), dom=(0, int(rng.integers(3, 9))))
+        Lf, Uf = random_boxes(seed0 + 17 * it, vs, int(rng.integers(1, 200)))
+        omf = orc.OracleModel(len(vs)); M.push_model(omf, cs, len(vs)); M.push_model(ctx, cs, len(vs))
+        reff = omf.consistency(Lf, Uf, None)
+        got = ctx.propagate(Lf, Uf, E.full_active(Lf.shape[0], omf.n_units))
+        has_formula = any(M.is_formula_unit(u) or (isinstance(u, M.Elementary) and u.kind >= M.BOOL) for u in cs.units)
+        assert (ctx.last_plan()["path"] == 3) == has_formula
+        assert_parity(reff[:4], got[:4], f"soak it={it} formula store [explicit]")
+        got = ctx.propagate_implicit(Lf, Uf)
+        assert_parity(reff[:4], got[:4], f"soak it={it} formula store [implicit]")
+        paths[3] += has_formula; checked += 2
     it += 1
-print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s")
+print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s; implicit launches by asserted path {paths}")
