@@ -50,6 +50,9 @@
 #ifndef PCP_NEQ_PROFILE
 #define PCP_NEQ_PROFILE 0
 #endif
+#ifndef PCP_PUT_FAST
+#define PCP_PUT_FAST 1
+#endif
 
 namespace pcp {
 
@@ -267,7 +270,10 @@ __device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type*
 // staged again nor swept again: the only variable whose lists must run is the one branched on (Store::react's argument: at the
 // parent's fixpoint every propagator is a no-op until one of its variables changes).  A node popped from the stack is staged from
 // global memory and swept in full, like any node handed in by a caller.
-template <bool PACKED, bool PAY4, bool DFS>
+// BT = the tile size as a compile-time constant — 16 (the batch default), 1 (the search loop) — or 0: taken from the launch.  With it the
+// cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
+// kernel does not have (it spills scalars into VGPR lanes as it is).
+template <bool PACKED, bool PAY4, bool DFS, int BT>
 __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
@@ -284,12 +290,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const Pay* pay;
   if constexpr (PAY4) pay = a.adjp4; else pay = a.m.adjp;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  uint32_t tid = threadIdx.x, lane = tid & 63;  // (refreshed, opaquely, at the top of every tile: see the loop)
+  const uint32_t nth = blockDim.x;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
-  const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = a.nodes_per_block;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = BT ? (uint32_t)BT : a.nodes_per_block;
   const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
   const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
-  const uint32_t sh = cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
+  const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
   unsigned long long* const trbuf = reinterpret_cast<unsigned long long*>(smem + cv.win + (size_t)wcap * sizeof(Win));
 #define PCP_TR(k) do { if (tr_on && lane == 0) trbuf[wv * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   PCP_TR(0);
@@ -343,7 +350,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   if (!DFS && tid == 0) { for (int i = 0; i < 7; ++i) accl[i] = 0ull; }
   for (uint32_t dfs_it = 0;; ++dfs_it) {  // DFS: the search loop's nodes; otherwise this workgroup's tiles
   bool resume = false;
-  if constexpr (!DFS) misc = misc_base + (dfs_it & 1u) * 48u;
+  if constexpr (!DFS) {
+    misc = misc_base + (dfs_it & 1u) * 48u;
+    // the thread index, made opaque per tile: what depends on it alone (lane masks, task coordinates, cell addresses) is then computed
+    // where it is used instead of being hoisted out of the tile loop into registers that stay occupied — and spill — for the whole kernel
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63u;
+  }
   if constexpr (DFS) {
     if (dfs_sp == 0 || dfs_stop || dfs_it >= a.dfs.n_steps) break;
     const size_t off = (tree_row0 + (dfs_sp - 1)) * V;
@@ -367,7 +380,32 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (tid == 0) chg[dfs_resume_var >> 5] = 1u << (dfs_resume_var & 31u);  // the left child: only the variable branched on has changed
   } else {
     uint32_t badm = 0, oobm = 0;
-    auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) {
+    // returns bit 0 = an empty domain among the four, bit 1 = a bound out of range (the callers collect them per node)
+    auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) -> uint32_t {
+      if (PCP_PUT_FAST && cnt == 4) {
+        // Four whole slots — every put of a store whose size is a multiple of four.  The kernel is bound by instruction issue (four
+        // wavefronts share a SIMD), so this is counted in instructions: the range check is a minimum and a maximum over the eight
+        // bounds (v_min3 / v_max3) instead of sixteen compares; an empty or a singleton domain shows as min(ub - lb) <= 0, and only
+        // then are the four looked at one by one; a cell is packed by one subtraction and one byte permute.
+        const int mn = min(min(min(l[0], l[1]), min(l[2], l[3])), min(min(u[0], u[1]), min(u[2], u[3])));
+        const int mx = max(max(max(l[0], l[1]), max(l[2], l[3])), max(max(u[0], u[1]), max(u[2], u[3])));
+        const int dmin = min(min(u[0] - l[0], u[1] - l[1]), min(u[2] - l[2], u[3] - l[3]));
+        Cell* const p0 = dom + rowof(v0) + b;  // (v0 is a multiple of four: the four rows are B cells apart, no padding between them)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (PACKED) p0[i * B] = __builtin_amdgcn_perm((uint32_t)u[i], (uint32_t)(-l[i]), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
+          else p0[i * B] = make_int2(-l[i], u[i]);
+        }
+        const uint32_t f_oob = ((mn < -lim) | (mx > lim)) ? 2u : 0u;  // refused, not wrapped (pcp_hip.h)
+        if (dmin <= 0 || a.seed_always) {
+          uint32_t nib = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
+          if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
+          if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+        }
+        return f_oob | (dmin < 0 ? 1u : 0u);        // empty input domain: the node is failed
+      }
       uint32_t nib = 0;
       bool bad = false, oob = false;
       Cell cl[4];
@@ -384,17 +422,20 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         if ((uint32_t)i < cnt) dom[rowof(v0 + i) + b] = cl[i];
       if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
       if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
-      if (bad) badm |= 1u << b;
-      if (oob) oobm |= 1u << b;
+      return (bad ? 1u : 0u) | (oob ? 2u : 0u);
     };
+    auto note = [&](uint32_t f, uint32_t b) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; };
     const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
     if (vec) {
       // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight
       // 16-byte pairs per lane = 64 VGPRs): one memory round trip per tile instead of two in a row
-      constexpr int UF = 8;
+      constexpr int UF = PACKED ? 8 : 6;  // (the int2-cell instantiations have fewer registers to spare)
       // task t = (node t / SQ, quad t % SQ); a lane's tasks are nth apart: one division per lane, then (node, quad) move by a fixed step
       const uint32_t dq = nth % SQ, db = nth / SQ;
-      uint32_t bs = tid / SQ, qs = tid - bs * SQ;
+      // (opaque per tile: everything below depends on the thread index alone, and hoisted out of the tile loop it would sit in two dozen
+      // registers — spilled — for the whole kernel)
+      const uint32_t tid_o = tid;
+      uint32_t bs = tid_o / SQ, qs = tid_o - bs * SQ;
       auto step = [&](uint32_t& bq, uint32_t& qq) { qq += dq; bq += db; if (qq >= SQ) { qq -= SQ; ++bq; } };
       const bool gather = !DFS && a.node_index != nullptr;  // (pass 2 of a two-pass launch: the tile's nodes come through a list)
       // (a tile's rows are contiguous otherwise: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
@@ -402,7 +443,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
-      for (uint32_t t0 = tid; t0 < tasks; t0 += UF * nth) {
+      for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
         int4 L[UF], U[UF];
         uint32_t bq = bs, qq = qs;
         if (!gather) {
@@ -434,7 +475,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         for (int j = 0; j < UF; ++j) {
           if (t0 + j * nth >= tasks) break;
           const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
-          put(bq, 4 * qq, l, u, 4);
+          note(put(bq, 4 * qq, l, u, 4), bq);
           step(bq, qq);
         }
         bs = bq; qs = qq;
@@ -454,7 +495,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
               l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i];
             }
           }
-        put(b, v0, l, u, cnt);
+        note(put(b, v0, l, u, cnt), b);
       }
     }
     // interned constants: singleton pseudo-variables behind the variables (term/constant.rs:43-68)
@@ -880,12 +921,14 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
   {
     const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
-    const uint32_t dirty = misc[N_DIRTY], refused = misc[N_OOB];
+    const uint32_t all_nodes = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+    const uint32_t dirty = __builtin_amdgcn_readfirstlane(misc[N_DIRTY]), refused = __builtin_amdgcn_readfirstlane(misc[N_OOB]);
     uint32_t badm = 0;
     const bool vec_out = (V & 3u) == 0 && (((size_t)a.lb_out | (size_t)a.ub_out) & 15u) == 0;
-    for (uint32_t b = 0; b < nb; ++b) {
-      if ((refused >> b) & 1u) continue;                   // a refused node's outputs are left alone
-      if (in_place && !((dirty >> b) & 1u)) continue;      // the rows in HBM already hold the result
+    // a refused node's outputs are left alone; in place, the rows of an unchanged node already hold the result in HBM: a frontier
+    // tile writes nothing and does not even look at its sixteen nodes one by one
+    for (uint32_t need = (in_place ? dirty : all_nodes) & ~refused & all_nodes; need; need &= need - 1u) {
+      const uint32_t b = (uint32_t)__builtin_ctz(need);
       auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
       int32_t* lbp = a.lb_out + (size_t)misc[N_NID + b] * V;
       int32_t* ubp = a.ub_out + (size_t)misc[N_NID + b] * V;
@@ -909,12 +952,18 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
   // address were tried instead and cost 8 800.)
   {
-    const unsigned long long s_narrow = wave_sum64(ctr.narrow), s_ev = wave_sum64(ctr.ev), s_full = wave_sum64(ctr.full), s_ev0 = wave_sum64(ev0);
+    // (a counter nobody touched — narrowings and full filter runs of a frontier tile — costs one ballot; the high halves likewise)
+    auto total = [&](uint32_t x) -> unsigned long long {
+      if (!__ballot(x != 0u)) return 0ull;
+      const unsigned long long lo = wave_sum(x & 0xffffu);
+      return __ballot((x >> 16) != 0u) ? lo + ((unsigned long long)wave_sum(x >> 16) << 16) : lo;
+    };
+    const unsigned long long s_narrow = total(ctr.narrow), s_ev = total(ctr.ev), s_full = total(ctr.full), s_later = total(ctr.ev - ev0);
     if (lane == 0) {
       if (s_narrow) atomicAdd(&misc[N_NARROW], (uint32_t)s_narrow);
       if (s_ev) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_EV]), s_ev);
       if (s_full) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_FULL]), s_full);
-      if (s_ev - s_ev0) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_STEPS]), s_ev - s_ev0);
+      if (s_later) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[N_STEPS]), s_later);
     }
   }
   PCP_TR(12);
@@ -1056,28 +1105,28 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4, bool DFS>
+template <bool PACKED, bool PAY4, bool DFS, int BT>
 static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
-template <bool DFS>
+template <bool DFS, int BT>
 static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
-  if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS>(a, p, stream) : launch_neq_k<false, true, DFS>(a, p, stream);
-  return a.packed ? launch_neq_k<true, false, DFS>(a, p, stream) : launch_neq_k<false, false, DFS>(a, p, stream);
+  if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS, BT>(a, p, stream) : launch_neq_k<false, true, DFS, BT>(a, p, stream);
+  return a.packed ? launch_neq_k<true, false, DFS, BT>(a, p, stream) : launch_neq_k<false, false, DFS, BT>(a, p, stream);
 }
 
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.nodes_per_block == 0 || a.nodes_per_block > 16 || a.m.n_slots >= 65536u || !a.m.adjp) return hipErrorInvalidValue;
   if (a.dfs.n_steps) {
     if (a.nodes_per_block != 1 || p.grid < 1 || !a.dfs.sp || !a.dfs.stop || !a.dfs.counters) return hipErrorInvalidValue;  // (grid = trees)
-    return launch_neq_d<true>(a, p, stream);
+    return launch_neq_d<true, 1>(a, p, stream);
   }
-  return launch_neq_d<false>(a, p, stream);
+  return a.nodes_per_block == 16 ? launch_neq_d<false, 16>(a, p, stream) : launch_neq_d<false, 0>(a, p, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
