@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: explicit,c2,deep500,deep3000,set,setsearch,c3,c4,f4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -463,7 +463,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "explicit,c2,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
+            legs_req = "mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -489,27 +489,27 @@ def main():
             }
         if legs_req != "none":
             legs = side_legs(ctx, torch, dev, n, props, args, set(legs_req.split(",")), L, U)
-        # the ONE JSON line stays short (the driver reads the tail of stdout): per leg its headline figures; everything else
-        # of the legs goes to stderr and to gpurun_out/bench_legs.json
-        def brief(l):
-            b = {"name": l["name"], "nodes": l.get("nodes")}
-            if isinstance(l.get("kernel_ms"), dict):
-                b["kernel_ms"] = round(l["kernel_ms"]["median"], 4)
-            for k in ("us_per_node", "steps_per_s", "nodes_per_s"):
-                if k in l:
-                    b[k] = float(f"{l[k]:.4g}")
-            if "hbm_frac" in l:
-                b["hbm_frac"] = float(f"{l['hbm_frac']:.3g}")
-            return b
-        out["config"]["legs"] = [brief(l) for l in legs]
-        # the same figures as flat scalar keys (a nested list does not survive every JSON-line parser)
-        for l in legs:
-            key = "leg_" + l["name"].replace("-", "_")
-            if isinstance(l.get("kernel_ms"), dict):
-                out["config"][key + "_ms"] = round(l["kernel_ms"]["median"], 4)
-            for k2 in ("us_per_node", "nodes_per_s", "steps_per_s", "evaluated_per_s", "hbm_frac"):
-                if k2 in l:
-                    out["config"][f"{key}_{k2}"] = float(f"{l[k2]:.4g}")
+        # The ONE JSON line carries every BASELINE configuration as SHORT flat scalar keys, most important first and ahead of the long
+        # text fields (a parser that truncates keys or caps their number then still keeps them); the full leg records go to stderr
+        # and to gpurun_out/bench_legs.json.
+        by = {l["name"]: l for l in legs}
+        flat = {}
+        def put_ms(key, name):
+            if name in by and isinstance(by[name].get("kernel_ms"), dict):
+                flat[key] = round(by[name]["kernel_ms"]["median"], 4)
+        def put_k(key, name, field, digits=4):
+            if name in by and by[name].get(field) is not None:
+                flat[key] = float(f"{by[name][field]:.{digits}g}")
+        put_ms("mix_ms", "MIX-nodes-along-the-dfs"); put_k("mix_nps", "MIX-nodes-along-the-dfs", "nodes_per_s"); put_k("mix_sps", "MIX-nodes-along-the-dfs", "evaluated_per_s")
+        put_k("mix_frac", "MIX-nodes-along-the-dfs", "hbm_frac", 3)
+        put_ms("d500_ms", "C2-deep-dive-500"); put_ms("d3000_ms", "C2-deep-dive-3000")
+        put_ms("c3_ms", "C3-random-binary-csp-50k-vars-500k-props"); put_k("c3_sps", "C3-random-binary-csp-50k-vars-500k-props", "evaluated_per_s")
+        put_ms("c4_ms", "C4-golomb-distinct-sum-network"); put_ms("f4_ms", "F4-cumulative-reified-layer")
+        put_ms("set_ms", "C2-set-mode-IntervalSet-frontier"); put_k("set_frac", "C2-set-mode-IntervalSet-frontier", "hbm_frac", 3)
+        put_ms("expl_ms", "C2-frontier-explicit-active-rows"); put_k("expl_frac", "C2-frontier-explicit-active-rows", "hbm_frac", 3)
+        put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
+        put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
+        out["config"] = {**flat, **out["config"]}
         if legs:
             full = json.dumps({"legs": legs})
             print(full, file=sys.stderr, flush=True)
@@ -581,6 +581,43 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                      "steps_per_s": sd["steps"] / dt, "evaluated_per_s": sd["evaluated"] / dt,
                      "note": "pcp_dfs_device: per node a team-scratch memset + the fixpoint kernel + a 1-workgroup branch/stack kernel, no host sync inside a 64-step chunk; "
                              "bound by the kernels (the fixpoint of a node this deep in the dive), not by the enqueue rate"})
+    if "mix" in want:
+        # one launch whose nodes are what a SEARCH hands the engine: 16384 open nodes sampled along the reference's DFS (every 12th of its
+        # first ~200 000 nodes: the dive, then the bottom of the tree) — not one depth, the depths in the proportions a search visits them
+        reset_opts()
+        lbm, ubm, dep = W.nqueens_dfs_samples(ctx, n, args.nodes, 12)
+        reset_opts()
+        assigned = (lbm == ubm).sum(dim=1).float()
+        leg = Leg(ctx, torch, "MIX-nodes-along-the-dfs", lbm, ubm, None, lbm.shape[0] * node_bytes(V, words, False),
+                  f"{lbm.shape[0]} open nodes sampled along the reference's depth-first search (every 12th node of its first {12 * lbm.shape[0]} nodes): stack depth "
+                  f"{int(dep.min())}..{int(dep.max())} (median {int(np.median(dep))}), {assigned.mean().item():.0f} queens assigned on average ({int(assigned.min().item())}..{int(assigned.max().item())})")
+        res = leg.run(launches=5, warmup=1)
+        if args.cpu_budget > 0:  # parity of the TIMED launch on nodes spread over the batch (the deep ones cost the oracle ~0.3 s each)
+            from oracle import oracle as orc
+            pick = np.linspace(0, lbm.shape[0] - 1, 12).astype(np.int64)
+            Lh, Uh = lbm[pick].cpu().numpy(), ubm[pick].cpu().numpy()
+            refm = orc.OracleModel(n, props).consistency(Lh, Uh, None)
+            g_lb, g_ub, g_st = leg.last_out[0][pick].cpu().numpy(), leg.last_out[1][pick].cpu().numpy(), leg.status[pick].cpu().numpy()
+            ok = np.array_equal(refm[3], g_st) and all(refm[3][i] == 0 or (np.array_equal(refm[0][i], g_lb[i]) and np.array_equal(refm[1][i], g_ub[i])) for i in range(len(pick)))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (mix leg): the timed launch differs from the oracle")
+            res["parity_checked_nodes"] = int(len(pick))
+        legs.append(res)
+        del leg, lbm, ubm
+    if "forest" in want:
+        # the search loop itself on the device, interval domains: the root expanded to 2048 open nodes, one in-kernel DFS per node
+        reset_opts()
+        from pcp_amd.search_forest import forest_search
+        lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+        forest_search(ctx, lb0, ub0, node_limit=50_000, n_trees=2048, steps_per_launch=16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fr = forest_search(ctx, lb0, ub0, node_limit=500_000, n_trees=2048, steps_per_launch=256)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        legs.append({"name": "C5-interval-forest", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
+                     "trees": fr["trees"], "launches": fr["launches"], "error": fr["error"],
+                     "note": "pcp_dfs_forest_device: first 500 000 nodes, 2048 trees of 256 threads, 256 nodes per tree and launch; the timed region includes the expansion"})
     for dive in (500, 3000):
         if f"deep{dive}" in want:
             reset_opts()

@@ -52,6 +52,41 @@ def nqueens_deep(ctx, n: int, dive: int, nodes: int, rounds: int = 14, implicit:
     return lb.clone(), ub.clone(), (None if act is None else act.clone())
 
 
+def nqueens_dfs_samples(ctx, n: int, samples: int, stride: int, capacity: int = 8192):
+    """`samples` open nodes taken ALONG the reference's depth-first search of N-queens-n (pcp_dfs_device: OneSolution order, left first):
+    after every `stride` nodes the node on top of the stack — the next one the search would propagate — is copied.  The batch therefore
+    holds the depths of the tree in the proportions the search visits them (a dive of a few thousand nodes, then the bottom of the
+    tree), not one depth.  Returns CUDA tensors (lb, ub) [k, n] with k <= samples (the search may end) and the depth (stack pointer)
+    of every sample."""
+    import ctypes as C
+    import torch
+    from . import engine as E
+    dev = torch.device("cuda", ctx.device)
+    lb = torch.zeros((capacity, n), dtype=torch.int32, device=dev)
+    ub = torch.zeros((capacity, n), dtype=torch.int32, device=dev)
+    lb[0] = 1
+    ub[0] = n
+    state = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+    status = torch.zeros(capacity, dtype=torch.uint8, device=dev)
+    counters = torch.zeros(5, dtype=torch.int64, device=dev)
+    st = E.DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), None)
+    out_lb = torch.empty((samples, n), dtype=torch.int32, device=dev)
+    out_ub = torch.empty((samples, n), dtype=torch.int32, device=dev)
+    depth = np.zeros(samples, np.int32)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    k = 0
+    while k < samples:
+        sp, stop = state.cpu().tolist()
+        if sp == 0 or stop:
+            break
+        out_lb[k].copy_(lb[sp - 1])
+        out_ub[k].copy_(ub[sp - 1])
+        depth[k] = sp
+        k += 1
+        ctx._check(ctx._L.pcp_dfs_device(ctx._h, C.byref(st), stride, 0, 0, C.c_void_p(stream)))
+    return out_lb[:k].clone(), out_ub[:k].clone(), depth[:k]
+
+
 def nqueens_frontier_set(ctx, n: int, nodes: int, max_rounds: int = 64):
     """The N-queens-n frontier over FDSpace (IntervalSet domains, what example/src/nqueens.rs:28-50 really allocates): breadth-first
     from the root with set-mode propagation (`ctx` holds the model with set_words = ceil(n/64) and the hull [1, n]) until `nodes`
