@@ -46,7 +46,10 @@ struct pcp_ctx {
   uint32_t* d_adj = nullptr;
   uint2* d_adjp = nullptr; size_t cap_adjp = 0; bool have_adjp = false;
   int32_t* d_const = nullptr;
-  Rec* d_recs_by_kind = nullptr; size_t cap_recs_by_kind = 0; bool recs_by_kind_valid = false;  // pcp_big.hip: the record table sorted by kind
+  // pcp_big.hip: the records sorted by kind and the adjacency payloads, both with the operands' cell coordinates (BigRec / BigAdj, pcp_neq.h)
+  uint2* d_brec = nullptr; size_t cap_brec = 0; uint2* d_badj = nullptr; size_t cap_badj = 0;
+  bool recs_by_kind_valid = false;  // (built on first use; `big_ok`: the model fits the format — offsets within +-4095, fewer than 98304 variables, no record over two constants)
+  bool big_ok = false;
   uint32_t* d_adjp4 = nullptr; size_t cap_adjp4 = 0; bool have_adjp4 = false;  // 4-byte adjacency payloads (pcp_neq.hip)
   uint32_t* d_seed_always = nullptr; size_t cap_seed_always = 0; bool have_seed_always = false;  // variables with a Constant neighbour (pcp_neq.hip)
   bool neq_model = false;            // every record is an XNeqY with at least one variable operand, payload adjacency, slots < 65536
@@ -109,6 +112,7 @@ struct pcp_ctx {
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
+  int64_t opt_big_dense_k = 2;      // pcp_big.hip: dense iff k * list entries >= records
   int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
@@ -658,7 +662,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_recs_by_kind, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -842,6 +846,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "big_dense_k") {
+    if (value < 1 || value > 64) return fail(c, PCP_ERR_ARG, "big_dense_k must be in [1,64]");
+    c->opt_big_dense_k = value;
   } else if (k == "big_round") {
     if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "big_round must be 0 (auto), 1 (dense rounds only) or 2 (sparse rounds only)");
     c->opt_big_round = value;
@@ -931,21 +938,69 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   // a store too large for (lb, ub) pairs in LDS, binary records only, a declared hull of at most 1024 values, implicit nodes, enough
   // nodes to give every CU one: the 10-bit-cell kernel (pcp_big.hip)
-  if (implicit && c->opt_big_path && c->opt_dom10 && c->opt_global_dom != 1 && c->opt_force_path != 2 && c->have_adjp && !c->n_sum_slots && c->hull_set &&
+  bool big_fits = false;
+  if (implicit && P && c->opt_big_path && c->opt_dom10 && c->opt_global_dom != 1 && c->opt_force_path != 2 && c->have_adjp && !c->n_sum_slots && c->hull_set &&
       (int64_t)c->hull_hi - c->hull_lo <= 1023 && (c->opt_global_dom == 2 || !lds_bytes_for(S, 1, 256, block)) && lds_bytes_big(c->n_vars, S) &&
       lds_bytes_big(c->n_vars, S) <= c->lds_max && (c->opt_global_dom == 2 || n_nodes * 2 > (uint32_t)c->num_cu || words < 64)) {
     if (!c->recs_by_kind_valid) {  // built on first use: only stores that take this path need it
-      std::vector<Rec> all((size_t)P ? ((size_t)P + 255) / 256 * 256 + kStreamPadRecs : 0);
+      const size_t Ppad = (size_t)P ? ((size_t)P + 255) / 256 * 256 + kStreamPadRecs : 0;
+      std::vector<Rec> all(Ppad);
       HIP_TRY(c, hipMemcpy(all.data(), c->d_recs, all.size() * sizeof(Rec), hipMemcpyDeviceToHost));
-      std::stable_sort(all.begin(), all.begin() + P, [](const Rec& p, const Rec& q) { return (p.xk >> 28) < (q.xk >> 28); });
-      for (size_t r = P; r < all.size(); ++r) all[r] = all[P - 1];
-      if ((rc = ensure(c, c->d_recs_by_kind, c->cap_recs_by_kind, all.size()))) return rc;
-      HIP_TRY(c, hipMemcpy(c->d_recs_by_kind, all.data(), all.size() * sizeof(Rec), hipMemcpyHostToDevice));
+      std::vector<uint32_t> adj_off(c->n_vars + 1), adj;
+      HIP_TRY(c, hipMemcpy(adj_off.data(), c->d_adj_off, adj_off.size() * 4, hipMemcpyDeviceToHost));
+      adj.resize(adj_off[c->n_vars]);
+      if (!adj.empty()) HIP_TRY(c, hipMemcpy(adj.data(), c->d_adj, adj.size() * 4, hipMemcpyDeviceToHost));
+      std::vector<int32_t> consts(S - c->n_vars);
+      if (!consts.empty()) HIP_TRY(c, hipMemcpy(consts.data(), c->d_const, consts.size() * 4, hipMemcpyDeviceToHost));
+      c->big_ok = c->n_vars < 98304u;
+      // a record with a Constant operand becomes a unary record  var (op) K:  x (kind) c + d  /  c (kind) y + d  <=>  y (>, =, !=) c - d
+      struct BR { uint2 r; uint32_t key; };
+      std::vector<BR> br(P);
+      auto coord = [](uint32_t slot) { return (slot / 3u) | ((slot % 3u) << 15); };
+      const uint32_t nv = c->n_vars;
+      for (size_t r = 0; r < P && c->big_ok; ++r) {
+        const uint32_t x = all[r].xk & kSlotMask, y = all[r].y, kind = all[r].xk >> 28;
+        const int64_t d = all[r].d;
+        if (kind > PCP_LT || (x >= nv && y >= nv)) { c->big_ok = false; break; }
+        if (y >= nv) {         // x (kind) K,  K = c + d
+          const uint32_t op = kind == PCP_LT ? 0u : kind == PCP_EQ ? 2u : 3u;
+          br[r] = BR{make_uint2(coord(x) | (op << 17) | (3u << 30), (uint32_t)(int32_t)(consts[y - nv] + d)), 3u};
+        } else if (x >= nv) {  // c (kind) y + d:  LT  y > c - d  |  EQ  y = c - d  |  NEQ  y != c - d
+          const uint32_t op = kind == PCP_LT ? 1u : kind == PCP_EQ ? 2u : 3u;
+          br[r] = BR{make_uint2(coord(y) | (op << 17) | (3u << 30), (uint32_t)(int32_t)(consts[x - nv] - d)), 3u};
+        } else {
+          if (d < -4095 || d > 4095) { c->big_ok = false; break; }
+          br[r] = BR{make_uint2(coord(x) | (((uint32_t)(int32_t)d & 0x1fffu) << 17) | (kind << 30), coord(y)), kind};
+        }
+      }
+      if (c->big_ok) {
+        // the adjacency payloads first (they follow ModelDev::adj, which names records of the UNSORTED table)
+        std::vector<uint2> badj(adj.size());
+        for (uint32_t v = 0; v < nv; ++v)
+          for (uint32_t k = adj_off[v]; k < adj_off[v + 1]; ++k) {
+            const Rec& rec = all[adj[k]];
+            const BR& b = br[adj[k]];
+            const uint32_t x = rec.xk & kSlotMask, y = rec.y, kind = rec.xk >> 28;
+            if (b.key == 3u) { badj[k] = make_uint2(0x7fffu | (((b.r.x >> 17) & 3u) << 18) | (1u << 20), b.r.y); continue; }
+            const bool is_y = x != v;
+            badj[k] = make_uint2(coord(is_y ? x : y) | ((is_y ? 1u : 0u) << 17) | (kind << 18), (uint32_t)rec.d);
+          }
+        std::stable_sort(br.begin(), br.end(), [](const BR& p, const BR& q) { return p.key < q.key; });
+        std::vector<uint2> brec(Ppad);
+        for (size_t r = 0; r < Ppad; ++r) brec[r] = br[std::min<size_t>(r, P - 1)].r;
+        if ((rc = ensure(c, c->d_brec, c->cap_brec, brec.size()))) return rc;
+        if ((rc = ensure(c, c->d_badj, c->cap_badj, std::max<size_t>(badj.size(), 1)))) return rc;
+        HIP_TRY(c, hipMemcpy(c->d_brec, brec.data(), brec.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        if (!badj.empty()) HIP_TRY(c, hipMemcpy(c->d_badj, badj.data(), badj.size() * sizeof(uint2), hipMemcpyHostToDevice));
+      }
       c->recs_by_kind_valid = true;
     }
+    big_fits = c->big_ok;
+  }
+  if (big_fits) {
     BigArgs a;
     memset(&a, 0, sizeof(a));
-    a.recs_by_kind = c->d_recs_by_kind;
+    a.brec = c->d_brec; a.badj = c->d_badj; a.has_unary = S != c->n_vars ? 1u : 0u; a.dense_k = (uint32_t)c->opt_big_dense_k;
     a.m.recs = c->d_recs; a.m.adj_off = c->d_adj_off; a.m.adj = c->d_adj; a.m.adjp = c->d_adjp; a.m.const_val = c->d_const;
     a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
     a.n_nodes = n_nodes; a.lo10 = c->hull_lo; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.round_mode = (uint32_t)c->opt_big_round;

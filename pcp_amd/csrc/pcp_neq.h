@@ -55,9 +55,16 @@ hipError_t launch_neqwave(const NeqArgs& a, uint32_t grid, uint32_t block, size_
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
 // per workgroup (pcp_big.hip).
+// The records as that kernel reads them: 8 bytes with the CELL COORDINATES of both operands (slot s lives in word s / 3, field s % 3):
+//   .x = word_x | field_x << 15 | (d & 0x1fff) << 17 | kind << 30        .y = word_y | field_y << 15
+// and the adjacency payload of a variable's list entry (BigAdj), in the order of ModelDev::adj:
+//   .x = word_other | field_other << 15 | (this variable is the record's y) << 17 | kind << 18        .y = d
 struct BigArgs {
-  ModelDev m;          // needs recs (padded), adj_off, adjp, const_val, n_recs, n_vars, n_slots
-  const Rec* recs_by_kind;  // [padded like m.recs] the records sorted by kind (stable)
+  ModelDev m;          // needs adj_off, const_val, n_recs, n_vars, n_slots (< 98304)
+  const uint2* brec;   // [padded like ModelDev::recs] BigRec, sorted by kind (stable)
+  const uint2* badj;   // [adj_off[n_vars]] BigAdj
+  uint32_t dense_k;    // a wake-up round is dense iff dense_k * (list entries of the changed variables) >= records (option "big_dense_k")
+  uint32_t has_unary;  // the model has records with a Constant operand (unary records, kind 3)
   uint32_t n_nodes;
   int32_t lo10;        // the hull's lower bound
   uint32_t round_mode; // option "big_round": 0 = every wake-up round takes the cheaper form, 1 = always dense, 2 = always sparse (tests)
