@@ -112,6 +112,7 @@ struct pcp_ctx {
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
+  int64_t opt_small_path = 1;       // 1 = small stores (<= 128 slots, <= 2048 records) run one wavefront per node (pcp_small.hip)
   int64_t opt_big_dense_k = 2;      // pcp_big.hip: dense iff k * list entries >= records
   int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
@@ -846,6 +847,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "small_path") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_path must be 0 or 1");
+    c->opt_small_path = value;
   } else if (k == "big_dense_k") {
     if (value < 1 || value > 64) return fail(c, PCP_ERR_ARG, "big_dense_k must be in [1,64]");
     c->opt_big_dense_k = value;
@@ -930,6 +934,33 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
     c->ev_valid = true;
     return PCP_OK;
+  }
+  // a small store — at most 128 slots, 2048 records, no formulas: one wavefront per node (pcp_small.hip, plan.path 4).  Explicit rows and
+  // implicit nodes alike.  Any option that asks for a particular geometry of the generic kernels keeps those kernels.
+  if (c->opt_small_path && S <= 128u && P <= 2048u && !c->opt_force_path && !c->opt_nodes_per_block && !c->opt_global_dom && !c->opt_team &&
+      (bt->active_in != nullptr || c->opt_implicit) && !(c->neq_model && c->opt_neq_path && bt->active_in == nullptr && n_nodes >= 64)) {
+    const uint32_t waves = 4;
+    const size_t lds = lds_bytes_small(S, c->n_units, P, waves);
+    if (lds && lds <= c->lds_max) {
+      SmallArgs a;
+      memset(&a, 0, sizeof(a));
+      a.m.recs = c->d_recs; a.m.const_val = c->d_const; a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
+      a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
+      a.rec_unit = c->has_groups ? c->d_rec_unit : nullptr; a.n_units = c->n_units; a.n_nodes = n_nodes;
+      a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
+      a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
+      a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;
+      LaunchPlan plan;
+      plan.block = 64 * waves; plan.lds_bytes = lds;
+      const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / lds), 2048u / plan.block));
+      plan.grid = std::min<uint32_t>((n_nodes + waves - 1) / waves, per_cu * (uint32_t)c->num_cu);
+      c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, bt->active_in ? 0u : 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 4u};
+      if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+      HIP_TRY(c, launch_smallfix(a, plan, stream));
+      if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+      c->ev_valid = !c->dfs_sp;
+      return PCP_OK;
+    }
   }
   const bool implicit = bt->active_in == nullptr && c->opt_implicit;  // see below (a.live == nullptr)
   if (implicit && c->neq_model && c->opt_neq_path && c->opt_force_path != 2 && !c->opt_global_dom) {

@@ -105,4 +105,27 @@ struct FormArgs {
 size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units);
 hipError_t launch_formfix(const FormArgs& a, const LaunchPlan& p, hipStream_t stream);
 
+// Small stores — a few dozen variables, up to a few thousand filters — over explicit `active` rows or implicit nodes: one wavefront per node
+// (pcp_small.hip).
+struct SmallArgs {
+  ModelDev m;                 // needs recs, const_val, sums, n_recs, n_vars, n_slots
+  const uint32_t* rec_unit;   // [n_recs] unit of each record, or null: every record is its own unit
+  uint32_t n_units;
+  uint32_t n_nodes;
+  uint32_t* violation;
+  unsigned long long* dbg;    // [kStatSlots][PCP_DBG_COUNT]
+  const uint32_t* sp_ptr;     // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
+  const uint32_t* stop_ptr;
+  const int32_t* lb_in;
+  const int32_t* ub_in;
+  int32_t* lb_out;
+  int32_t* ub_out;
+  const uint64_t* active_in;  // [n_nodes][ceil(n_units/64)] or null = every unit active
+  uint64_t* active_out;       // or null
+  uint8_t* status;
+  pcp_stats* stats;
+};
+size_t lds_bytes_small(uint32_t n_slots, uint32_t n_units, uint32_t n_recs, uint32_t waves);
+hipError_t launch_smallfix(const SmallArgs& a, const LaunchPlan& p, hipStream_t stream);
+
 }  // namespace pcp

@@ -1,0 +1,167 @@
+// pcp_small.hip — the propagation fixpoint of SMALL stores (gfx950): a few dozen variables, up to a few thousand elementary filters — BASELINE
+// config 4 (the Golomb-ruler network: 55 variables, one Distinct of 990 XNeqY, 45 XEqYPlusZ, 10 XLessY / XEqY), the reference's own test models.
+//
+// Same contract as fixpoint_kernel (pcp_kernels.hip): Store::consistency = prepare() + propagation_loop() (propagation/store.rs:125-164,
+// 247-257) for a batch of nodes, explicit unit-level `active` rows or implicit-active nodes: every active propagator once
+// (init_scheduler, store.rs:144-149), then again while anything changes (Store::react wakes the propagators of a changed variable,
+// store.rs:191-198; on a store this small "all of them" is cheaper than finding out which); an entailed unit is unlinked (store.rs:200-207).
+//
+// MI355X mapping: ONE WAVEFRONT PER NODE.  The generic kernel gives a tile of 16 such nodes a 1024-thread workgroup and runs the machinery
+// it needs for million-record models (packed tiles, bulk range tests, changed-pair lists, workgroup barriers between rounds): 0.70 ms for 4096
+// nodes of 440 bytes, none of it spent on filters.  Here a node's domains are an LDS slice of its wavefront ((-lb, ub) cells: both narrowings
+// are ds_min), the records come from an LDS copy the workgroup shares, a round is every live record once, lane-strided, and rounds are
+// separated by a wavefront barrier only; sixteen wavefronts per CU run sixteen nodes at sixteen different points of their fixpoints.  A round's
+// last pass — the one that narrows nothing — has evaluated every live record on the final domains, so its is_subsumed() results ARE the units'
+// entailment: a unit all of whose members are entailed is unlinked.  Integer bound work: no MFMA.
+#include <algorithm>
+
+#include "pcp_device.hpp"
+#include "pcp_neq.h"
+
+namespace pcp {
+
+namespace {
+
+enum { S_FAIL = 0, S_OOB = 1, S_WORDS = 4 };
+
+__host__ __device__ inline size_t small_wave_bytes(uint32_t S, uint32_t U) {
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  return up((size_t)S * 8) + up((size_t)((S + 31) / 32) * 4) + 2 * up((size_t)((U + 31) / 32) * 4) + up(S_WORDS * 4);
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
+  const uint32_t V = a.m.n_vars, S = a.m.n_slots, P = a.m.n_recs, U = a.n_units, Wu = (U + 31) >> 5, Wv = (S + 31) >> 5, words64 = (U + 63) >> 6;
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  // the workgroup's copy of the records, then one slice per wavefront: cells, a (dummy) changed mask, the live units, the entailed units, flags
+  Rec* const recs = reinterpret_cast<Rec*>(smem);
+  unsigned char* const mine = smem + up((size_t)P * sizeof(Rec)) + (size_t)wv * small_wave_bytes(S, U);
+  int2* const dom = reinterpret_cast<int2*>(mine);
+  uint32_t* const chg = reinterpret_cast<uint32_t*>(mine + up((size_t)S * 8));
+  uint32_t* const live = chg + (up((size_t)Wv * 4) >> 2);
+  uint32_t* const ent = live + (up((size_t)Wu * 4) >> 2);
+  uint32_t* const misc = ent + (up((size_t)Wu * 4) >> 2);
+  for (uint32_t r = tid; r < P; r += blockDim.x) recs[r] = a.m.recs[r];
+  __syncthreads();
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+  pcp_stats* const stats = a.stats + (blockIdx.x & (kStatSlots - 1));
+  unsigned long long acc_s2 = 0, acc_s3 = 0, acc_narrow = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;
+
+  uint32_t first = blockIdx.x * nwv + wv, stride = gridDim.x * nwv, n_nodes = a.n_nodes;
+  size_t row_base = 0;
+  uint32_t st_base = 0;
+  if (a.sp_ptr) {  // host-stepped device-side DFS (pcp_dfs_device): ONE node, the one on top of the stack
+    const uint32_t sp = *a.sp_ptr;
+    if (sp == 0 || *a.stop_ptr) return;
+    row_base = (size_t)(sp - 1) * V; st_base = sp - 1; n_nodes = 1;
+  }
+  for (uint32_t node = first; node < n_nodes; node += stride) {
+    const size_t row = row_base + (size_t)node * V;
+    // ---- stage: the node's domains, its live units -----------------------------------------------------------------------------------------
+    if (lane < (uint32_t)S_WORDS) misc[lane] = 0;
+    for (uint32_t w = lane; w < Wv; w += 64) chg[w] = 0;
+    for (uint32_t w = lane; w < Wu; w += 64) {  // Store::active (one bit per unit): the caller's row, or every unit (implicit-active nodes)
+      uint32_t bits = 0xFFFFFFFFu;
+      if (a.active_in) { const uint64_t q = a.active_in[(size_t)node * words64 + (w >> 1)]; bits = (uint32_t)(q >> (32 * (w & 1))); }
+      if (w == Wu - 1 && (U & 31u)) bits &= (1u << (U & 31u)) - 1u;
+      live[w] = bits;
+    }
+    bool bad = false, wide = false;
+    for (uint32_t v = lane; v < S; v += 64) {
+      int l = 0, u = 0;
+      if (v < V) {
+        l = a.lb_in[row + v]; u = a.ub_in[row + v];
+        bad |= l > u;
+        wide |= (l < -kBoundMax) | (l > kBoundMax) | (u < -kBoundMax) | (u > kBoundMax);
+      } else if (v - V >= a.m.sums.count) {
+        l = u = a.m.const_val[v - V];  // (the Sum slots in between hold nothing: their domain is computed from the members)
+      }
+      dom[v] = make_int2(-l, u);
+    }
+    if (__ballot(wide)) {  // a bound beyond +-(2^29 - 1): refused, not wrapped (pcp_hip.h)
+      if (lane == 0) { a.status[st_base + node] = kStatusRetry; atomicMax(a.violation, 1u); }
+      continue;
+    }
+    if (__ballot(bad) && lane == 0) misc[S_FAIL] = 1u;
+    wave_sync();
+
+    // ---- rounds: every record of a live unit once per round, until a round narrows nothing ------------------------------------------------
+    Ctr ctr;
+    const LdsDom dm{dom, 1u, chg, &misc[S_FAIL], 1u, &ctr, a.m.sums};
+    uint32_t s2 = 0, s3 = 0, rounds = 0;
+    bool failed = __builtin_amdgcn_readfirstlane(misc[S_FAIL]) != 0;
+    while (!failed) {
+      ++rounds;
+      for (uint32_t w = lane; w < Wu; w += 64) ent[w] = live[w];  // a live unit counts as entailed until one of its members says otherwise
+      wave_sync();
+      const uint32_t before = ctr.narrow;
+      for (uint32_t r = lane; r < P; r += 64) {
+        const uint32_t u = a.rec_unit ? a.rec_unit[r] : r;
+        if (!((live[u >> 5] >> (u & 31u)) & 1u)) continue;
+        const Rec rec = recs[r];
+        if ((rec.xk >> 28) >= PCP_LT3) ++s3; else ++s2;
+        if (!eval_record(rec, dm)) atomicAnd(&ent[u >> 5], ~(1u << (u & 31u)));   // propagate_one + is_subsumed (store.rs:166-175)
+      }
+      wave_sync();
+      failed = __builtin_amdgcn_readfirstlane(misc[S_FAIL]) != 0;
+      if (!__ballot(ctr.narrow != before)) break;
+    }
+
+    // ---- write back, unlink the entailed units (store.rs:200-207), status (store.rs:250-256) --------------------------------------------------
+    bool emptied = false;
+    for (uint32_t v = lane; v < V; v += 64) {
+      const int2 d = dom[v];
+      emptied |= -d.x > d.y;
+      a.lb_out[row + v] = -d.x; a.ub_out[row + v] = d.y;
+    }
+    failed = failed || __ballot(emptied) != 0;
+    bool any_live = false;
+    for (uint32_t w = lane; w < Wu; w += 64) {
+      const uint32_t left = failed ? live[w] : live[w] & ~ent[w];
+      live[w] = left;
+      any_live |= left != 0;
+    }
+    wave_sync();
+    if (a.active_out)
+      for (uint32_t w = lane; w < words64; w += 64) {
+        const uint64_t lo = live[2 * w], hi = (2 * w + 1 < Wu) ? live[2 * w + 1] : 0u;
+        a.active_out[(size_t)node * words64 + w] = lo | (hi << 32);
+      }
+    const bool unknown = __ballot(any_live) != 0;
+    if (lane == 0) a.status[st_base + node] = failed ? (uint8_t)PCP_FALSE : (unknown ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
+    for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o); ctr.narrow += __shfl_down(ctr.narrow, o); }
+    acc_s2 += s2; acc_s3 += s3; acc_narrow += ctr.narrow; acc_waves += rounds ? rounds : 1; acc_nodes += 1; acc_failed += failed ? 1 : 0;
+    wave_sync();
+  }
+  if (lane == 0) {
+    if (acc_s2) atomicAdd((unsigned long long*)&stats->steps, acc_s2);
+    if (acc_s3) atomicAdd((unsigned long long*)&stats->steps3, acc_s3);
+    if (acc_s2 + acc_s3) { atomicAdd((unsigned long long*)&stats->evaluated, acc_s2 + acc_s3); atomicAdd((unsigned long long*)&stats->full_evals, acc_s2 + acc_s3); }
+    if (acc_narrow) atomicAdd((unsigned long long*)&stats->narrowings, acc_narrow);
+    if (acc_waves) atomicAdd((unsigned long long*)&stats->waves, acc_waves);
+    if (acc_nodes) atomicAdd((unsigned long long*)&stats->nodes, acc_nodes);
+    if (acc_failed) atomicAdd((unsigned long long*)&stats->failed_nodes, acc_failed);
+    if (a.dbg && acc_nodes) atomicAdd(&a.dbg[(size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT + PCP_DBG_SMALL_NODES], acc_nodes);
+  }
+}
+
+size_t lds_bytes_small(uint32_t n_slots, uint32_t n_units, uint32_t n_recs, uint32_t waves) {
+  const size_t b = (((size_t)n_recs * sizeof(Rec) + 15) & ~(size_t)15) + (size_t)waves * small_wave_bytes(n_slots, n_units);
+  return b <= 160 * 1024 ? b : 0;
+}
+
+hipError_t launch_smallfix(const SmallArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if (!a.m.recs || !a.status) return hipErrorInvalidValue;
+  if (p.lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(smallfix_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(smallfix_kernel, dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace pcp

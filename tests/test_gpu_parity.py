@@ -34,19 +34,29 @@ def both(ctx, n_vars, props, lb, ub, active, what, **opts):
     ctx.set_model(n_vars, props)
     for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1, "group_level": 1, **opts}.items():
         ctx.set_option(k, v)
-    got = ctx.propagate(lb, ub, active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units))
+    ctx.set_option("small_path", 1)
+    act_in = active if active is not None else E.full_active(np.asarray(lb).reshape(-1, n_vars).shape[0], om.n_units)
+    got = ctx.propagate(lb, ub, act_in)
     assert_parity(ref[:4], got[:4], what)
+    if ctx.last_plan()["path"] == 4:
+        # a small store took the one-wavefront-per-node kernel (pcp_small.hip): the generic kernels under the same options too
+        ctx.set_option("small_path", 0)
+        got_g = ctx.propagate(lb, ub, act_in)
+        assert ctx.last_plan()["path"] == 0
+        assert_parity(ref[:4], got_g[:4], what + " [generic kernels]")
+        ctx.set_option("small_path", 1)
     # the same nodes as IMPLICIT-active nodes (domains only, every unit active on entry, liveness derived from the domains;
     # `active` rows materialised on request) under the same launch options
     ref_i = ref if active is None else om.consistency(lb, ub, None)
     got_i = ctx.propagate_implicit(lb, ub)
     assert ctx.last_plan()["implicit_active"] == 1
     assert_parity(ref_i[:4], got_i[:4], what + " [implicit]")
-    if ctx.last_plan()["path"] == 1:
-        # an all-XNeqY model took the assignment-driven kernel (pcp_neq.hip): the generic implicit kernels under the same options too
-        ctx.set_option("neq_path", 0)
+    if ctx.last_plan()["path"] in (1, 4):
+        # an all-XNeqY model took the assignment-driven kernel (pcp_neq.hip), or a small store the one-wavefront-per-node kernel
+        # (pcp_small.hip): the generic implicit kernels under the same options too
+        ctx.set_option("neq_path", 0); ctx.set_option("small_path", 0)
         got_g = ctx.propagate_implicit(lb, ub)
-        ctx.set_option("neq_path", 1)
+        ctx.set_option("neq_path", 1); ctx.set_option("small_path", 1)
         assert ctx.last_plan()["path"] == 0
         assert_parity(ref_i[:4], got_g[:4], what + " [implicit, generic kernels]")
     return ref, got

@@ -64,10 +64,10 @@ def run_both_paths(ctx, om, L, U, what, in_place=True):
     pl = ctx.last_plan()
     assert pl["path"] == 1 and pl["implicit_active"] == 1, pl
     assert_parity(ref[:4], got[:4], what + " [assignment-driven]")
-    ctx.set_option("neq_path", 0)
+    ctx.set_option("neq_path", 0); ctx.set_option("small_path", 0)
     gen = ctx.propagate_implicit(L, U, in_place=in_place)
     assert ctx.last_plan()["path"] == 0
-    ctx.set_option("neq_path", 1)
+    ctx.set_option("neq_path", 1); ctx.set_option("small_path", 1)
     assert_parity(ref[:4], gen[:4], what + " [generic]")
     return ref, got, pl
 

@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = E.Context(0)
 t0, it, checked = time.time(), 0, 0
-paths = {0: 0, 1: 0, 2: 0, 3: 0}
+paths = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed0 + it)
     n = int(rng.integers(20, 110))
@@ -55,7 +55,7 @@ while time.time() - t0 < budget:
     if rng.random() < 0.5:
         ctx.set_hull(lo, hi)
     for opts in ({"nodes_per_block": 16}, {"nodes_per_block": 8}, {"nodes_per_block": 16, "word_level": 0}, {"nodes_per_block": 32}, {}):
-        for k, v in {"nodes_per_block": 0, "packed": 1, "word_level": 1, "block_threads": int(rng.choice([256, 512, 1024])), **opts}.items():
+        for k, v in {"nodes_per_block": 0, "packed": 1, "word_level": 1, "small_path": 0, "block_threads": int(rng.choice([256, 512, 1024])), **opts}.items():
             ctx.set_option(k, v)
         ctx.set_option("solo_cascade", int(rng.integers(0, 2)))
         got = ctx.propagate(L, U, act)
@@ -73,23 +73,38 @@ while time.time() - t0 < budget:
         ctx.set_option("force_path", 0)
     # ---- the specialised implicit-node kernels, path drawn and ASSERTED: 1 = assignment-driven (all-XNeqY), 2 = 10-bit cells (any
     # binary model under a declared hull of <= 1024 values), 0 = the generic kernels under the same options
-    want = int(rng.choice([0, 1, 2]))
-    for k, v in {"nodes_per_block": 0, "force_path": 0, "block_threads": 1024, "global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0}.items():
+    want = int(rng.choice([0, 1, 2, 4]))
+    for k, v in {"nodes_per_block": 0, "force_path": 0, "block_threads": 1024, "global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0, "small_path": 1}.items():
         ctx.set_option(k, v)
     ctx.set_model(n, props)
     ctx.set_hull(lo, hi)
+    small_ok = n <= 128 and P <= 2048
     if want == 2:
         ctx.set_option("global_dom", 2); ctx.set_option("big_round", int(rng.integers(0, 3)))
     elif want == 0:
-        ctx.set_option("neq_path", 0); ctx.set_option("big_path", 0)
+        ctx.set_option("neq_path", 0); ctx.set_option("big_path", 0); ctx.set_option("small_path", 0)
+    elif want == 4:
+        ctx.set_option("neq_path", 0)
     got = ctx.propagate_implicit(L, U)
     path = ctx.last_plan()["path"]
-    expect = 2 if want == 2 else (1 if (want == 1 and kinds == [M.NEQ]) else 0)
-    assert path == expect, (path, expect, want, kinds)
+    if want == 2:
+        expect = 2
+    elif want == 1:
+        expect = 1 if (kinds == [M.NEQ] and (N >= 64 or not small_ok)) else (4 if small_ok else 0)
+    elif want == 4:
+        expect = 4 if small_ok else 0
+    else:
+        expect = 0
+    assert path == expect, (path, expect, want, kinds, n, P, N)
     assert_parity(ref_i[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} path={path} [implicit]")
+    if path == 4:  # the small-store kernel on the explicit rows too
+        got = ctx.propagate(L, U, act)
+        assert ctx.last_plan()["path"] == 4
+        assert_parity(ref[:4], got[:4], f"soak it={it} n={n} P={P} N={N} kinds={kinds} planted={planted} path=4 [explicit]")
+        checked += 1
     paths[path] += 1
     checked += 1
-    for k, v in {"global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0}.items():
+    for k, v in {"global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0, "small_path": 1}.items():
         ctx.set_option(k, v)
     if rng.random() < 0.3:  # path 3: a random store of formula units (the reified layer), explicit rows and implicit nodes
         from test_reified import random_formula_store, random_boxes
