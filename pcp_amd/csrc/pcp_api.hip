@@ -441,7 +441,7 @@ int32_t finalize_model(pcp_ctx* c) {
     // every unit as a tree for pcp_formula.hip: a standalone propagator = one leaf, a Conjunction / Distinct group = an AND over
     // its members, a formula = its own tree with the leaves renumbered to record indices
     std::vector<pcp_fnode> fn;
-    std::vector<uint32_t> root(c->n_units, 0);
+    std::vector<uint32_t> root(c->n_units + 1, 0);
     size_t r = 0;
     while (r < P) {
       const uint32_t u = c->unit_of_prop[r];
@@ -451,6 +451,12 @@ int32_t finalize_model(pcp_ctx* c) {
       const int32_t f = c->formula_of_prop[r];
       if (f >= 0) {
         const auto& tree = c->formulas[(size_t)f];
+        // (the kernel keeps a tree's node statuses in 64-bit masks; only a FLAT Conjunction of leaves may be wider — it is a loop)
+        if (tree.size() > 64) {
+          bool flat = tree[0].type == PCP_F_AND && (size_t)tree[0].n_children + 1 == tree.size();
+          for (size_t i = 1; i < tree.size() && flat; ++i) flat = tree[i].type == PCP_F_LEAF;
+          if (!flat) return fail(c, PCP_ERR_UNSUPPORTED, "a formula of more than 64 nodes (other than a flat Conjunction of propagators)");
+        }
         const uint32_t base = (uint32_t)fn.size();
         for (const pcp_fnode& nd : tree) {
           pcp_fnode q = nd;
@@ -467,6 +473,7 @@ int32_t finalize_model(pcp_ctx* c) {
       }
       r = e;
     }
+    root[c->n_units] = (uint32_t)fn.size();  // (sentinel: a unit's nodes are root[u] .. root[u + 1])
     if ((rc = ensure(c, c->d_fnodes, c->cap_fnodes, fn.size()))) return rc;
     if ((rc = ensure(c, c->d_unit_root, c->cap_unit_root, root.size()))) return rc;
     if (!fn.empty()) HIP_TRY(c, hipMemcpy(c->d_fnodes, fn.data(), fn.size() * sizeof(pcp_fnode), hipMemcpyHostToDevice));
@@ -916,7 +923,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
 
   if (c->has_formulas) {
     // the reified layer: every unit is evaluated as a tree, one lane per unit (pcp_formula.hip); `active` rows are unit-level there
-    const size_t lds = lds_bytes_formula(S, c->n_units);
+    // one wavefront per node, four per workgroup; a store too large for four slices runs with fewer
+    uint32_t fwaves = 4;
+    while (fwaves > 1 && (!lds_bytes_formula(S, c->n_units, fwaves) || lds_bytes_formula(S, c->n_units, fwaves) > c->lds_max / 2)) fwaves /= 2;
+    const size_t lds = lds_bytes_formula(S, c->n_units, fwaves);
     if (!lds || lds > c->lds_max) return fail(c, PCP_ERR_UNSUPPORTED, "a store with formula propagators must fit one CU's LDS (8 bytes per variable)");
     FormArgs a;
     memset(&a, 0, sizeof(a));
@@ -927,7 +937,11 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
     a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;
     LaunchPlan plan;
-    plan.grid = n_nodes; plan.block = 256; plan.lds_bytes = lds;
+    plan.block = 64 * fwaves; plan.lds_bytes = lds;
+    {  // persistent workgroups: what the chip holds at once
+      const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / lds), 2048u / plan.block));
+      plan.grid = std::min<uint32_t>((n_nodes + fwaves - 1) / fwaves, per_cu * (uint32_t)c->num_cu);
+    }
     c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, bt->active_in ? 0u : 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 3u};
     HIP_TRY(c, hipEventRecord(c->ev_start, stream));
     HIP_TRY(c, launch_formfix(a, plan, stream));

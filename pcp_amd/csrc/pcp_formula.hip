@@ -27,7 +27,6 @@ namespace pcp {
 namespace {
 
 enum { F_FAIL = 0, F_OOB = 1, F_CHANGED = 2, F_STEPS2 = 4, F_STEPS3 = 6, F_NARROW = 8, F_WAVES = 9, F_WORDS = 10 };
-constexpr int kMaxDepth = 8;
 
 struct FormCarve {
   size_t dom, chg, live, misc, total;
@@ -104,101 +103,56 @@ __device__ void rec_propagate(const Rec& rec, const LdsDom& dm) {
   (void)eval_record(rec, dm);
 }
 
-struct FormCtx {
-  const FNode* nodes;
-  const Rec* recs;
-  LdsDom dm;
-  uint32_t steps2, steps3;
-};
-
-template <int DEPTH>
-__device__ uint32_t f_subsumed(const FormCtx& c, uint32_t at) {
-  const FNode nd = c.nodes[at];
-  if (nd.type == PCP_F_LEAF) return rec_subsumed(c.recs[nd.first], c.dm);
-  if constexpr (DEPTH > 1) {
-    if (nd.type == PCP_F_AND) {  // conjunction.rs:78-94
-      bool all_entailed = true;
-      for (uint32_t k = 0; k < nd.n_children; ++k) {
-        const uint32_t s = f_subsumed<DEPTH - 1>(c, nd.first + k);
-        if (s == 0u) return 0u;
-        if (s == 2u) all_entailed = false;
-      }
-      return all_entailed ? 1u : 2u;
-    }
-    bool all_disentailed = true;  // disjunction.rs:78-94
-    for (uint32_t k = 0; k < nd.n_children; ++k) {
-      const uint32_t s = f_subsumed<DEPTH - 1>(c, nd.first + k);
-      if (s == 1u) return 1u;
-      if (s == 2u) all_disentailed = false;
-    }
-    return all_disentailed ? 0u : 2u;
-  }
-  return 2u;  // (deeper than the host accepts: never reached)
-}
-
-template <int DEPTH>
-__device__ void f_propagate(FormCtx& c, uint32_t at) {
-  const FNode nd = c.nodes[at];
-  if (nd.type == PCP_F_LEAF) {
-    const Rec rec = c.recs[nd.first];
-    const uint32_t kind = rec.xk >> 28;
-    if (kind >= PCP_LT3 && kind <= PCP_MUL3) ++c.steps3; else ++c.steps2;
-    rec_propagate(rec, c.dm);
-    return;
-  }
-  if constexpr (DEPTH > 1) {
-    if (nd.type == PCP_F_AND) {  // conjunction.rs:97-104: the children in order (a failure ends the node anyway)
-      for (uint32_t k = 0; k < nd.n_children; ++k) f_propagate<DEPTH - 1>(c, nd.first + k);
-      return;
-    }
-    // disjunction.rs:97-117
-    uint32_t num_disentailed = 0, unknown_formula = 0;
-    for (uint32_t k = 0; k < nd.n_children; ++k) {
-      const uint32_t s = f_subsumed<DEPTH - 1>(c, nd.first + k);
-      if (s == 1u) return;
-      if (s == 0u) ++num_disentailed; else unknown_formula = k;
-    }
-    if (num_disentailed + 1 == nd.n_children) f_propagate<DEPTH - 1>(c, nd.first + unknown_formula);
-    else if (num_disentailed == nd.n_children) c.dm.set_fail();
-  }
-}
-
 }  // namespace
 
-__global__ void __launch_bounds__(256) formfix_kernel(const FormArgs a_in) {
-  FormArgs a = a_in;
-  a.stats += blockIdx.x & (kStatSlots - 1);
-  if (a.sp_ptr) {  // host-stepped device-side DFS (pcp_dfs_device): the node on top of the stack, as in fixpoint_kernel
-    const uint32_t sp = *a.sp_ptr;
-    if (sp == 0 || *a.stop_ptr) return;
-    const size_t off = (size_t)(sp - 1) * a.m.n_vars;
-    a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
-  }
+// One WAVEFRONT per node (round 4; it was a 256-thread workgroup per node with one lane per unit and the tree walked by recursion unrolled
+// eight levels deep: 178 VGPRs, 256 bytes of scratch per lane).  A unit's tree is laid out breadth-first — every child behind its parent,
+// the children of a node consecutive (pcp_model_push_formula checks it) — so both walks are LOOPS over the unit's nodes:
+//   bottom-up  (last node to first): is_subsumed() of every node from its children's, kept as two bit masks (true / false) in registers;
+//   top-down   (first to last): propagate() — an `active` bit mask starts at the root; an active Conjunction activates all its children
+//              (conjunction.rs:97-104), an active Disjunction none if a child is entailed, its single not-disentailed child if there is exactly
+//              one, and fails the node if there is none (disjunction.rs:97-117); an active leaf runs its filter.
+// The Disjunction decides on the statuses the bottom-up walk found a moment earlier, where the reference asks its children while it runs: a
+// decision on an older domain is the conservative one (is_subsumed() only ever moves from Unknown to True or False as domains shrink), the
+// round after repeats it on the newer one, and the last round — the one that narrows nothing — sees final domains throughout.
+// A unit whose root is entailed is unlinked (store.rs:200-207) before it is propagated: its propagate() is a no-op (disjunction.rs:103).
+// Units of more than 64 nodes are flat Conjunctions of leaves (Distinct next to formulas): a loop over the members.
+__global__ void __launch_bounds__(256) formfix_kernel(const FormArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t tid = threadIdx.x, nth = blockDim.x, lane = tid & 63;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, U = a.n_units, Wu = (U + 31) >> 5;
   const FormCarve cv = form_carve(S, U);
-  int2* const dom = reinterpret_cast<int2*>(smem + cv.dom);
-  uint32_t* const chg = reinterpret_cast<uint32_t*>(smem + cv.chg);
-  uint32_t* const live = reinterpret_cast<uint32_t*>(smem + cv.live);
-  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem + cv.misc);
-  const uint32_t node = blockIdx.x;
-  const size_t row = (size_t)node * V;
+  unsigned char* const mine = smem + (size_t)wv * cv.total;
+  int2* const dom = reinterpret_cast<int2*>(mine + cv.dom);
+  uint32_t* const chg = reinterpret_cast<uint32_t*>(mine + cv.chg);
+  uint32_t* const live = reinterpret_cast<uint32_t*>(mine + cv.live);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(mine + cv.misc);
   const uint32_t words64 = (U + 63) >> 6;
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
+  pcp_stats* const stats = a.stats + (blockIdx.x & (kStatSlots - 1));
+  unsigned long long acc_s2 = 0, acc_s3 = 0, acc_narrow = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;
 
-  if (tid < (uint32_t)F_WORDS) misc[tid] = 0;
-  for (uint32_t w = tid; w < Wv; w += nth) chg[w] = 0;
-  // Store::active (one bit per unit): the caller's row, or every unit (implicit-active nodes)
-  for (uint32_t w = tid; w < Wu; w += nth) {
-    uint32_t bits = 0xFFFFFFFFu;
-    if (a.active_in) { const uint64_t q = a.active_in[(size_t)node * words64 + (w >> 1)]; bits = (uint32_t)(q >> (32 * (w & 1))); }
-    if (w == Wu - 1 && (U & 31u)) bits &= (1u << (U & 31u)) - 1u;
-    live[w] = bits;
+  uint32_t n_nodes = a.n_nodes, st_base = 0;
+  size_t row_base = 0;
+  if (a.sp_ptr) {  // host-stepped device-side DFS (pcp_dfs_device): ONE node, the one on top of the stack
+    const uint32_t sp = *a.sp_ptr;
+    if (sp == 0 || *a.stop_ptr) return;
+    row_base = (size_t)(sp - 1) * V; st_base = sp - 1; n_nodes = 1;
   }
-  __syncthreads();
-  {
+  for (uint32_t node = blockIdx.x * nwv + wv; node < n_nodes; node += gridDim.x * nwv) {
+    const size_t row = row_base + (size_t)node * V;
+    if (lane < (uint32_t)F_WORDS) misc[lane] = 0;
+    for (uint32_t w = lane; w < Wv; w += 64) chg[w] = 0;
+    // Store::active (one bit per unit): the caller's row, or every unit (implicit-active nodes)
+    for (uint32_t w = lane; w < Wu; w += 64) {
+      uint32_t bits = 0xFFFFFFFFu;
+      if (a.active_in) { const uint64_t q = a.active_in[(size_t)node * words64 + (w >> 1)]; bits = (uint32_t)(q >> (32 * (w & 1))); }
+      if (w == Wu - 1 && (U & 31u)) bits &= (1u << (U & 31u)) - 1u;
+      live[w] = bits;
+    }
     bool bad = false, wide = false;
-    for (uint32_t v = tid; v < S; v += nth) {
+    for (uint32_t v = lane; v < S; v += 64) {
       int l = 0, u = 0;
       if (v < V) {
         l = a.lb_in[row + v]; u = a.ub_in[row + v];
@@ -209,82 +163,114 @@ __global__ void __launch_bounds__(256) formfix_kernel(const FormArgs a_in) {
       }
       dom[v] = make_int2(-l, u);
     }
-    if (bad) atomicOr(&misc[F_FAIL], 1u);
-    if (wide) atomicOr(&misc[F_OOB], 1u);
-  }
-  __syncthreads();
-  if (misc[F_OOB]) {  // a bound beyond +-(2^29 - 1): refused, not wrapped (pcp_hip.h)
-    if (tid == 0) { a.status[node] = kStatusRetry; atomicMax(a.violation, 1u); }
-    return;
-  }
-
-  Ctr ctr;
-  FormCtx fc{a.nodes, a.m.recs, LdsDom{dom, 1u, chg, &misc[F_FAIL], 1u, &ctr, a.m.sums}, 0u, 0u};
-  uint32_t rounds = 0;
-  bool failed_now = misc[F_FAIL] != 0;  // (nobody writes the flag between a round's first barrier and the next round)
-  while (!failed_now) {
-    ++rounds;
-    for (uint32_t u = tid; u < U; u += nth) {
-      if (!((live[u >> 5] >> (u & 31u)) & 1u)) continue;
-      const uint32_t root = a.unit_root[u];
-      f_propagate<kMaxDepth>(fc, root);                       // propagate_one (store.rs:166-175) ...
-      if (f_subsumed<kMaxDepth>(fc, root) == 1u)              // ... is_subsumed() == True: unlink_prop (store.rs:200-207)
-        atomicAnd(&live[u >> 5], ~(1u << (u & 31u)));
+    if (__ballot(wide)) {  // a bound beyond +-(2^29 - 1): refused, not wrapped (pcp_hip.h)
+      if (lane == 0) { a.status[st_base + node] = kStatusRetry; atomicMax(a.violation, 1u); }
+      continue;
     }
-    __syncthreads();
-    bool any = false;
-    for (uint32_t w = tid; w < Wv; w += nth) { any |= chg[w] != 0; }
-    if (any) misc[F_CHANGED] = rounds;  // (benign race: every writer stores the same value)
-    __syncthreads();
-    const bool again = misc[F_CHANGED] == rounds;
-    failed_now = misc[F_FAIL] != 0;
-    for (uint32_t w = tid; w < Wv; w += nth) chg[w] = 0;
-    __syncthreads();
-    if (!again) break;
-  }
+    if (__ballot(bad) && lane == 0) misc[F_FAIL] = 1u;
+    wave_sync();
 
-  // ---- write back -----------------------------------------------------------------------------------------------------------------
-  {
-    bool bad = false;
-    for (uint32_t v = tid; v < V; v += nth) {
+    Ctr ctr;
+    const LdsDom dm{dom, 1u, chg, &misc[F_FAIL], 1u, &ctr, a.m.sums};
+    uint32_t steps2 = 0, steps3 = 0, rounds = 0;
+    auto leaf_propagate = [&](const Rec& rec) {
+      const uint32_t kind = rec.xk >> 28;
+      if (kind >= PCP_LT3 && kind <= PCP_MUL3) ++steps3; else ++steps2;
+      rec_propagate(rec, dm);
+    };
+    bool failed = __builtin_amdgcn_readfirstlane(misc[F_FAIL]) != 0;
+    while (!failed) {
+      ++rounds;
+      const uint32_t before = ctr.narrow;
+      for (uint32_t u = lane; u < U; u += 64) {
+        if (!((live[u >> 5] >> (u & 31u)) & 1u)) continue;
+        const uint32_t root = a.unit_root[u], n = a.unit_root[u + 1] - root;
+        const FNode rn = a.nodes[root];
+        bool entailed;
+        if (n > 64u || rn.type == PCP_F_LEAF) {
+          // a single propagator, or a flat Conjunction of leaves too wide for the masks: the members in order (conjunction.rs:97-104)
+          const uint32_t m0 = rn.type == PCP_F_LEAF ? root : rn.first, m1 = rn.type == PCP_F_LEAF ? root + 1 : rn.first + rn.n_children;
+          entailed = true;
+          for (uint32_t k = m0; k < m1; ++k) {
+            const Rec rec = a.m.recs[a.nodes[k].first];
+            leaf_propagate(rec);
+            entailed = entailed && rec_subsumed(rec, dm) == 1u;
+          }
+        } else {
+          // bottom-up: is_subsumed() of every node of the tree (bit i = node root + i)
+          unsigned long long t_true = 0, t_false = 0;
+          for (uint32_t i = n; i-- > 0;) {
+            const FNode nd = a.nodes[root + i];
+            uint32_t s_;
+            if (nd.type == PCP_F_LEAF) {
+              s_ = rec_subsumed(a.m.recs[nd.first], dm);
+            } else {
+              const unsigned long long cm = (nd.n_children >= 64 ? ~0ull : ((1ull << nd.n_children) - 1ull)) << (nd.first - root);
+              if (nd.type == PCP_F_AND) s_ = (t_false & cm) ? 0u : ((t_true & cm) == cm ? 1u : 2u);   // conjunction.rs:78-94
+              else s_ = (t_true & cm) ? 1u : ((t_false & cm) == cm ? 0u : 2u);                          // disjunction.rs:78-94
+            }
+            if (s_ == 1u) t_true |= 1ull << i; else if (s_ == 0u) t_false |= 1ull << i;
+          }
+          entailed = (t_true & 1ull) != 0;
+          if (!entailed) {
+            // top-down: propagate()
+            unsigned long long active = 1ull;
+            for (uint32_t i = 0; i < n; ++i) {
+              if (!((active >> i) & 1ull)) continue;
+              const FNode nd = a.nodes[root + i];
+              if (nd.type == PCP_F_LEAF) { leaf_propagate(a.m.recs[nd.first]); continue; }
+              const unsigned long long cm = (nd.n_children >= 64 ? ~0ull : ((1ull << nd.n_children) - 1ull)) << (nd.first - root);
+              if (nd.type == PCP_F_AND) { active |= cm; continue; }
+              if (t_true & cm) continue;                                 // an entailed child: the Disjunction holds (disjunction.rs:103)
+              const unsigned long long open = cm & ~t_false;             // the children that are not disentailed
+              if (open == 0ull) dm.set_fail();                           // all disentailed (disjunction.rs:112-114)
+              else if ((open & (open - 1ull)) == 0ull) active |= open;   // exactly one left: unit propagation (disjunction.rs:108-111)
+            }
+          }
+        }
+        if (entailed) atomicAnd(&live[u >> 5], ~(1u << (u & 31u)));      // unlink_prop (store.rs:200-207)
+      }
+      wave_sync();
+      failed = __builtin_amdgcn_readfirstlane(misc[F_FAIL]) != 0;
+      if (!__ballot(ctr.narrow != before)) break;
+    }
+
+    // ---- write back -----------------------------------------------------------------------------------------------------------------
+    bool emptied = false;
+    for (uint32_t v = lane; v < V; v += 64) {
       const int2 d = dom[v];
-      bad |= -d.x > d.y;
+      emptied |= -d.x > d.y;
       a.lb_out[row + v] = -d.x; a.ub_out[row + v] = d.y;
     }
-    if (bad) atomicOr(&misc[F_FAIL], 1u);
-  }
-  for (int o = 32; o > 0; o >>= 1) { ctr.narrow += __shfl_down(ctr.narrow, o); fc.steps2 += __shfl_down(fc.steps2, o); fc.steps3 += __shfl_down(fc.steps3, o); }
-  if (lane == 0) {
-    if (ctr.narrow) atomicAdd(&misc[F_NARROW], ctr.narrow);
-    if (fc.steps2) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[F_STEPS2]), (unsigned long long)fc.steps2);
-    if (fc.steps3) atomicAdd(reinterpret_cast<unsigned long long*>(&misc[F_STEPS3]), (unsigned long long)fc.steps3);
-  }
-  __syncthreads();
-  if (a.active_out)
-    for (uint32_t w = tid; w < words64; w += nth) {
-      const uint64_t lo = live[2 * w], hi = (2 * w + 1 < Wu) ? live[2 * w + 1] : 0u;
-      a.active_out[(size_t)node * words64 + w] = lo | (hi << 32);
-    }
-  if (tid == 0) {
+    failed = failed || __ballot(emptied) != 0;
     bool any_live = false;
-    for (uint32_t w = 0; w < Wu; ++w) any_live |= live[w] != 0;
-    const bool failed = misc[F_FAIL] != 0;
+    for (uint32_t w = lane; w < Wu; w += 64) any_live |= live[w] != 0;
+    if (a.active_out)
+      for (uint32_t w = lane; w < words64; w += 64) {
+        const uint64_t lo = live[2 * w], hi = (2 * w + 1 < Wu) ? live[2 * w + 1] : 0u;
+        a.active_out[(size_t)node * words64 + w] = lo | (hi << 32);
+      }
+    const bool unknown = __ballot(any_live) != 0;
     // Consistency::consistency (store.rs:250-256): False if a propagate failed, True if no subscription remains, else Unknown
-    a.status[node] = failed ? (uint8_t)PCP_FALSE : (any_live ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
-    const unsigned long long s2 = *reinterpret_cast<unsigned long long*>(&misc[F_STEPS2]), s3 = *reinterpret_cast<unsigned long long*>(&misc[F_STEPS3]);
-    if (s2) atomicAdd((unsigned long long*)&a.stats->steps, s2);
-    if (s3) atomicAdd((unsigned long long*)&a.stats->steps3, s3);
-    if (s2 + s3) { atomicAdd((unsigned long long*)&a.stats->evaluated, s2 + s3); atomicAdd((unsigned long long*)&a.stats->full_evals, s2 + s3); }
-    if (misc[F_NARROW]) atomicAdd((unsigned long long*)&a.stats->narrowings, (unsigned long long)misc[F_NARROW]);
-    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)rounds);
-    atomicAdd((unsigned long long*)&a.stats->nodes, 1ull);
-    if (failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, 1ull);
+    if (lane == 0) a.status[st_base + node] = failed ? (uint8_t)PCP_FALSE : (unknown ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
+    for (int o = 32; o > 0; o >>= 1) { steps2 += __shfl_down(steps2, o); steps3 += __shfl_down(steps3, o); ctr.narrow += __shfl_down(ctr.narrow, o); }
+    acc_s2 += steps2; acc_s3 += steps3; acc_narrow += ctr.narrow; acc_waves += rounds ? rounds : 1; acc_nodes += 1; acc_failed += failed ? 1 : 0;
+    wave_sync();
+  }
+  if (lane == 0) {
+    if (acc_s2) atomicAdd((unsigned long long*)&stats->steps, acc_s2);
+    if (acc_s3) atomicAdd((unsigned long long*)&stats->steps3, acc_s3);
+    if (acc_s2 + acc_s3) { atomicAdd((unsigned long long*)&stats->evaluated, acc_s2 + acc_s3); atomicAdd((unsigned long long*)&stats->full_evals, acc_s2 + acc_s3); }
+    if (acc_narrow) atomicAdd((unsigned long long*)&stats->narrowings, acc_narrow);
+    if (acc_waves) atomicAdd((unsigned long long*)&stats->waves, acc_waves);
+    if (acc_nodes) atomicAdd((unsigned long long*)&stats->nodes, acc_nodes);
+    if (acc_failed) atomicAdd((unsigned long long*)&stats->failed_nodes, acc_failed);
   }
 }
 
-size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units) {
+size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units, uint32_t waves) {
   const FormCarve c = form_carve(n_slots, n_units);
-  return c.total <= 160 * 1024 ? c.total : 0;
+  return c.total * waves <= 160 * 1024 ? c.total * waves : 0;
 }
 
 hipError_t launch_formfix(const FormArgs& a, const LaunchPlan& p, hipStream_t stream) {

@@ -87,7 +87,7 @@ using FNode = pcp_fnode;  // leaf: first = record index; inner node: first = ind
 struct FormArgs {
   ModelDev m;                // needs recs, const_val, sums, n_vars, n_slots
   const FNode* nodes;        // the trees of all units
-  const uint32_t* unit_root; // [n_units] root node of each unit
+  const uint32_t* unit_root; // [n_units + 1] root node of each unit, then the number of nodes (a unit's nodes are unit_root[u] .. unit_root[u + 1])
   uint32_t n_units;
   uint32_t n_nodes;
   uint32_t* violation;
@@ -102,7 +102,7 @@ struct FormArgs {
   uint8_t* status;
   pcp_stats* stats;
 };
-size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units);
+size_t lds_bytes_formula(uint32_t n_slots, uint32_t n_units, uint32_t waves);  // one slice per wavefront (= per node in flight)
 hipError_t launch_formfix(const FormArgs& a, const LaunchPlan& p, hipStream_t stream);
 
 // Small stores — a few dozen variables, up to a few thousand filters — over explicit `active` rows or implicit nodes: one wavefront per node
