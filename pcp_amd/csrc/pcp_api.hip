@@ -53,6 +53,11 @@ struct pcp_ctx {
   uint32_t* d_adjp4 = nullptr; size_t cap_adjp4 = 0; bool have_adjp4 = false;  // 4-byte adjacency payloads (pcp_neq.hip)
   uint32_t* d_seed_always = nullptr; size_t cap_seed_always = 0; bool have_seed_always = false;  // variables with a Constant neighbour (pcp_neq.hip)
   bool neq_model = false;            // every record is an XNeqY with at least one variable operand, payload adjacency, slots < 65536
+  // all-different units (pcp_small.hip): a Conjunction / Distinct unit whose members are x != y (no offsets, no constants) over EVERY pair of a
+  // variable set of at most 64 variables — what Distinct::new builds (propagators/distinct.rs:63-83).  ad_tab = [n, then per unit: unit id,
+  // count, first index into ad_vars]; ad_unit_mask bit u = unit u is one.
+  uint32_t* d_ad_tab = nullptr; uint32_t* d_ad_vars = nullptr; uint32_t* d_ad_mask = nullptr; size_t cap_ad_tab = 0, cap_ad_vars = 0, cap_ad_mask = 0;
+  uint32_t n_alldiff = 0;
   uint32_t* d_rec_unit = nullptr;    // grouped models only: unit of each record
   uint32_t* d_unit_first = nullptr;  // grouped models only: first record of each unit (+ sentinel)
   size_t cap_rec_unit = 0, cap_unit_first = 0;
@@ -112,6 +117,7 @@ struct pcp_ctx {
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
+  int64_t opt_small_alldiff = 1;    // 1 = pcp_small.hip filters an all-different unit through its value mask, 0 = pair by pair
   int64_t opt_small_path = 1;       // 1 = small stores (<= 128 slots, <= 2048 records) run one wavefront per node (pcp_small.hip)
   int64_t opt_big_dense_k = 2;      // pcp_big.hip: dense iff k * list entries >= records
   int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
@@ -437,6 +443,50 @@ int32_t finalize_model(pcp_ctx* c) {
     HIP_TRY(c, hipMemcpy(c->d_rec_unit, c->unit_of_prop.data(), P * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_unit_first, first.data(), first.size() * 4, hipMemcpyHostToDevice));
   }
+  c->n_alldiff = 0;
+  if (c->has_groups && !c->has_formulas) {
+    // all-different units: every pair of a set of m <= 64 variables exactly once, as x != y without offsets
+    std::vector<uint32_t> tab{0u}, vars, mask((c->n_units + 31) / 32, 0u);
+    size_t r = 0;
+    while (r < P) {
+      const uint32_t u = c->unit_of_prop[r];
+      size_t e = r;
+      while (e < P && c->unit_of_prop[e] == u) ++e;
+      if (e - r >= 3 && c->props[r].group_kind != 0) {
+        std::vector<uint32_t> vs;
+        std::vector<std::pair<uint32_t, uint32_t>> pairs;
+        bool ok = true;
+        for (size_t k = r; k < e && ok; ++k) {
+          const uint32_t x = recs[k].xk & kSlotMask, y = recs[k].y;
+          ok = (recs[k].xk >> 28) == PCP_NEQ && recs[k].d == 0 && x < c->n_vars && y < c->n_vars && x != y;
+          if (ok) { vs.push_back(x); vs.push_back(y); pairs.emplace_back(std::min(x, y), std::max(x, y)); }
+        }
+        if (ok) {
+          std::sort(vs.begin(), vs.end()); vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
+          std::sort(pairs.begin(), pairs.end());
+          const size_t m = vs.size();
+          // (pcp_small.hip keeps the tables of up to 8 such units over up to 256 variables in LDS: kSmallAdUnits, kSmallAdVars)
+          ok = m <= 64 && tab[0] < 8u && vars.size() + m <= 256 && pairs.size() == m * (m - 1) / 2 && std::adjacent_find(pairs.begin(), pairs.end()) == pairs.end();
+          if (ok) {
+            tab.push_back(u); tab.push_back((uint32_t)m); tab.push_back((uint32_t)vars.size());
+            vars.insert(vars.end(), vs.begin(), vs.end());
+            mask[u >> 5] |= 1u << (u & 31u);
+            ++tab[0];
+          }
+        }
+      }
+      r = e;
+    }
+    if (tab[0]) {
+      if ((rc = ensure(c, c->d_ad_tab, c->cap_ad_tab, tab.size()))) return rc;
+      if ((rc = ensure(c, c->d_ad_vars, c->cap_ad_vars, vars.size()))) return rc;
+      if ((rc = ensure(c, c->d_ad_mask, c->cap_ad_mask, mask.size()))) return rc;
+      HIP_TRY(c, hipMemcpy(c->d_ad_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_ad_vars, vars.data(), vars.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_ad_mask, mask.data(), mask.size() * 4, hipMemcpyHostToDevice));
+      c->n_alldiff = tab[0];
+    }
+  }
   if (c->has_formulas) {
     // every unit as a tree for pcp_formula.hip: a standalone propagator = one leaf, a Conjunction / Distinct group = an AND over
     // its members, a formula = its own tree with the leaves renumbered to record indices
@@ -670,7 +720,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_ad_tab, c->d_ad_vars, c->d_ad_mask, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -854,6 +904,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "big_path must be 0 or 1");
     c->opt_big_path = value;
+  } else if (k == "small_alldiff") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_alldiff must be 0 or 1");
+    c->opt_small_alldiff = value;
   } else if (k == "small_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_path must be 0 or 1");
     c->opt_small_path = value;
@@ -961,6 +1014,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       a.m.recs = c->d_recs; a.m.const_val = c->d_const; a.m.n_recs = P; a.m.n_vars = c->n_vars; a.m.n_slots = S; a.m.has_ternary = c->has_ternary;
       a.m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
       a.rec_unit = c->has_groups ? c->d_rec_unit : nullptr; a.n_units = c->n_units; a.n_nodes = n_nodes;
+      if (c->n_alldiff && c->opt_small_alldiff) { a.ad_tab = c->d_ad_tab; a.ad_vars = c->d_ad_vars; a.ad_mask = c->d_ad_mask; }
       a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
       a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
       a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;

@@ -112,6 +112,9 @@ struct SmallArgs {
   const uint32_t* rec_unit;   // [n_recs] unit of each record, or null: every record is its own unit
   uint32_t n_units;
   uint32_t n_nodes;
+  const uint32_t* ad_tab;     // all-different units, or null: [n, then (unit, count <= 64, first index into ad_vars) each]
+  const uint32_t* ad_vars;    //   their variables
+  const uint32_t* ad_mask;    //   bit u = unit u is one of them
   uint32_t* violation;
   unsigned long long* dbg;    // [kStatSlots][PCP_DBG_COUNT]
   const uint32_t* sp_ptr;     // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)

@@ -12,7 +12,14 @@
 // are ds_min), the records come from an LDS copy the workgroup shares, a round is every live record once, lane-strided, and rounds are
 // separated by a wavefront barrier only; sixteen wavefronts per CU run sixteen nodes at sixteen different points of their fixpoints.  A round's
 // last pass — the one that narrows nothing — has evaluated every live record on the final domains, so its is_subsumed() results ARE the units'
-// entailment: a unit all of whose members are entailed is unlinked.  Integer bound work: no MFMA.
+// entailment: a unit all of whose members are entailed is unlinked.
+// ALL-DIFFERENT units (Distinct::new, propagators/distinct.rs:63-83: x != y over every pair of a variable set; the host recognises them)
+// are filtered as a group, lane = variable: the assigned variables' values go into a 128-bit mask above the unit's smallest lower bound
+// (an LDS atomicOr: a bit that was already set is two variables with one value — the node fails, as the pair's filter would make it);
+// every other variable moves its bounds past the values in the mask.  Pair by pair the reference removes a value only at a bound and only
+// against an assigned partner (x_neq_y.rs:82-93), one value per wake-up: the mask does the same removals, all at once — same fixpoint
+// ("jump windows").  990 pair filters of config 4's Distinct become one step of 45 lanes.  A unit whose values span more than
+// 128 falls back to its pairs for that round.  Integer bound work: no MFMA.
 #include <algorithm>
 
 #include "pcp_device.hpp"
@@ -22,7 +29,18 @@ namespace pcp {
 
 namespace {
 
-enum { S_FAIL = 0, S_OOB = 1, S_WORDS = 4 };
+enum { S_FAIL = 0, S_OOB = 1, S_TAKEN = 4 /* .. 7 */, S_WORDS = 8 };
+constexpr uint32_t kSmallAdUnits = 8;    // all-different units filtered as groups (more of them: the later ones run pair by pair)
+constexpr uint32_t kSmallAdVars = 256;   // their variables, all together
+constexpr uint32_t kSmallAdWords = 1 + 3 * kSmallAdUnits + kSmallAdVars;
+
+// the workgroup's shared part of LDS: the records, their unit ids (u16), the all-different tables
+__host__ __device__ inline size_t small_shared_off(uint32_t P, int part) {
+  auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_unit = up((size_t)P * sizeof(Rec)), o_ad = o_unit + up((size_t)P * 2), o_end = o_ad + up((size_t)kSmallAdWords * 4);
+  return part == 0 ? o_unit : part == 1 ? o_ad : o_end;
+}
+__host__ __device__ inline size_t small_shared_bytes(uint32_t P) { return small_shared_off(P, 2); }
 
 __host__ __device__ inline size_t small_wave_bytes(uint32_t S, uint32_t U) {
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
@@ -38,14 +56,26 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, P = a.m.n_recs, U = a.n_units, Wu = (U + 31) >> 5, Wv = (S + 31) >> 5, words64 = (U + 63) >> 6;
   auto up = [](size_t x) { return (x + 15) & ~(size_t)15; };
   // the workgroup's copy of the records, then one slice per wavefront: cells, a (dummy) changed mask, the live units, the entailed units, flags
+  // (everything a round reads comes from LDS: with the unit ids and the all-different tables in global memory a lane's round was a chain
+  // of dependent L2 round trips, one per record — 0.26 ms for config 4 where the filters themselves take a fifth of that)
   Rec* const recs = reinterpret_cast<Rec*>(smem);
-  unsigned char* const mine = smem + up((size_t)P * sizeof(Rec)) + (size_t)wv * small_wave_bytes(S, U);
+  uint16_t* const runit = reinterpret_cast<uint16_t*>(smem + up((size_t)P * sizeof(Rec)));
+  uint32_t* const adt = reinterpret_cast<uint32_t*>(smem + small_shared_off(P, 1));
+  unsigned char* const mine = smem + small_shared_bytes(P) + (size_t)wv * small_wave_bytes(S, U);
   int2* const dom = reinterpret_cast<int2*>(mine);
   uint32_t* const chg = reinterpret_cast<uint32_t*>(mine + up((size_t)S * 8));
   uint32_t* const live = chg + (up((size_t)Wv * 4) >> 2);
   uint32_t* const ent = live + (up((size_t)Wu * 4) >> 2);
   uint32_t* const misc = ent + (up((size_t)Wu * 4) >> 2);
-  for (uint32_t r = tid; r < P; r += blockDim.x) recs[r] = a.m.recs[r];
+  for (uint32_t r = tid; r < P; r += blockDim.x) { recs[r] = a.m.recs[r]; runit[r] = (uint16_t)(a.rec_unit ? a.rec_unit[r] : r); }
+  // the all-different tables: [n, (unit, count, first) * n] then the variables, kSmallAdWords words in all (the host checks that they fit)
+  const uint32_t n_ad = a.ad_tab ? min(a.ad_tab[0], kSmallAdUnits) : 0u;
+  if (n_ad) {
+    const uint32_t n_vars_ad = a.ad_tab[3 * n_ad] + a.ad_tab[3 * n_ad - 1];  // first + count of the last unit
+    for (uint32_t i = tid; i < 1 + 3 * n_ad; i += blockDim.x) adt[i] = a.ad_tab[i];
+    for (uint32_t i = tid; i < n_vars_ad; i += blockDim.x) adt[1 + 3 * kSmallAdUnits + i] = a.ad_vars[i];
+  }
+  const uint32_t* const adv = adt + 1 + 3 * kSmallAdUnits;
   __syncthreads();
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
   pcp_stats* const stats = a.stats + (blockIdx.x & (kStatSlots - 1));
@@ -99,9 +129,65 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
       for (uint32_t w = lane; w < Wu; w += 64) ent[w] = live[w];  // a live unit counts as entailed until one of its members says otherwise
       wave_sync();
       const uint32_t before = ctr.narrow;
+      unsigned long long grouped = 0;  // (wave-uniform) the all-different units filtered as a group this round: bit k = entry k of ad_tab
+      for (uint32_t k = 0; k < n_ad; ++k) {
+        const uint32_t au = adt[1 + 3 * k], cnt = adt[2 + 3 * k], v0 = adt[3 + 3 * k];
+        if (!((live[au >> 5] >> (au & 31u)) & 1u)) continue;
+        const bool on = lane < cnt;
+        const uint32_t v = on ? adv[v0 + lane] : 0u;
+        int2 d = make_int2(0, 0);
+        if (on) { const int2 c_ = dom[v]; d = make_int2(-c_.x, c_.y); }
+        int lo = on ? d.x : 0x7fffffff, hi = on ? d.y : (int)0x80000000;
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+        if ((long long)hi - (long long)lo >= 128) continue;  // (wave-uniform) too wide for the mask: this unit's pairs run below
+        grouped |= 1ull << k;
+        if (lane < 4) misc[S_TAKEN + lane] = 0;
+        wave_sync();
+        s2 += on ? cnt - 1 : 0u;  // (a variable's step here stands for its cnt - 1 pair filters: counted as such, halves added up below)
+        const bool single = on && d.x == d.y;
+        if (single) {
+          const uint32_t b = (uint32_t)(d.x - lo);
+          if (atomicOr(&misc[S_TAKEN + (b >> 5)], 1u << (b & 31u)) & (1u << (b & 31u))) dm.set_fail();  // two variables, one value
+        }
+        wave_sync();
+        if (on && !single) {
+          const uint32_t t0 = misc[S_TAKEN], t1 = misc[S_TAKEN + 1], t2 = misc[S_TAKEN + 2], t3 = misc[S_TAKEN + 3];
+          auto taken = [&](int val) { const uint32_t b = (uint32_t)(val - lo); const uint32_t w_ = b < 32 ? t0 : b < 64 ? t1 : b < 96 ? t2 : t3; return ((w_ >> (b & 31u)) & 1u) != 0; };
+          int nl = d.x, nu = d.y;
+          while (nl <= nu && taken(nl)) ++nl;
+          while (nu >= nl && taken(nu)) --nu;
+          if (nl > d.x) dm.raise_lb(v, nl);
+          if (nu < d.y && nu >= nl) dm.lower_ub(v, nu);
+          if (nl > nu) dm.set_fail();
+        }
+        wave_sync();
+        // the unit's is_subsumed(): True iff every pair is disjoint (conjunction.rs:78-94 over x_neq_y.rs:71-73).  More values claimed than
+        // the hull has room for is an overlap somewhere (the usual case, one wave sum); otherwise every lane looks at every other interval.
+        {
+          int l2 = 0, u2 = -1;
+          if (on) { const int2 c2 = dom[v]; l2 = -c2.x; u2 = c2.y; }
+          uint32_t claimed = on && u2 >= l2 ? (uint32_t)(u2 - l2 + 1) : 0u;
+          for (int o = 32; o > 0; o >>= 1) claimed += __shfl_xor(claimed, o);
+          bool overlap = claimed > (uint32_t)(hi - lo + 1);
+          if (!overlap) {
+            bool ov = false;
+            for (uint32_t j = 0; j < cnt; ++j) {
+              const int lj = __builtin_amdgcn_readlane(l2, (int)j), uj = __builtin_amdgcn_readlane(u2, (int)j);
+              ov |= on && j != lane && !(u2 < lj || uj < l2);
+            }
+            overlap = __ballot(ov) != 0;
+          }
+          if (overlap && lane == 0) atomicAnd(&ent[au >> 5], ~(1u << (au & 31u)));
+        }
+      }
       for (uint32_t r = lane; r < P; r += 64) {
-        const uint32_t u = a.rec_unit ? a.rec_unit[r] : r;
+        const uint32_t u = runit[r];
         if (!((live[u >> 5] >> (u & 31u)) & 1u)) continue;
+        if (grouped) {  // a member of an all-different unit that was filtered as a group this round?
+          bool skip = false;
+          for (uint32_t k = 0; k < n_ad; ++k) skip |= ((grouped >> k) & 1ull) && adt[1 + 3 * k] == u;
+          if (skip) continue;
+        }
         const Rec rec = recs[r];
         if ((rec.xk >> 28) >= PCP_LT3) ++s3; else ++s2;
         if (!eval_record(rec, dm)) atomicAnd(&ent[u >> 5], ~(1u << (u & 31u)));   // propagate_one + is_subsumed (store.rs:166-175)
@@ -150,7 +236,7 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
 }
 
 size_t lds_bytes_small(uint32_t n_slots, uint32_t n_units, uint32_t n_recs, uint32_t waves) {
-  const size_t b = (((size_t)n_recs * sizeof(Rec) + 15) & ~(size_t)15) + (size_t)waves * small_wave_bytes(n_slots, n_units);
+  const size_t b = small_shared_bytes(n_recs) + (size_t)waves * small_wave_bytes(n_slots, n_units);
   return b <= 160 * 1024 ? b : 0;
 }
 

@@ -475,6 +475,48 @@ def test_nqueens_1000_root_and_dive(ctx):
         assert got[4]["steps"] >= N * om.n_units
 
 
+def test_all_different_units_on_the_small_kernel(ctx):
+    """Distinct::new units (distinct.rs:63-83) filtered as a group by pcp_small.hip — value mask, duplicate detection, entailment — against
+    the oracle's pairwise XNeqY: random boxes with many assigned variables (chains of forced values, duplicates), domains wider than the
+    128-value mask (that round falls back to the pairs), two units sharing variables, a unit that ends up entailed."""
+    rng = np.random.default_rng(77)
+    for case in range(6):
+        V = [9, 14, 20, 33, 12, 40][case]
+        dom = [(0, 12), (-5, 20), (0, 40), (1, 60), (0, 300), (0, 70)][case]
+        vs, cs = M.VStore(), M.CStore()
+        xs = [vs.alloc(dom) for _ in range(V)]
+        cs.alloc(M.Distinct(xs[: V - 2]))
+        if case in (1, 3):
+            cs.alloc(M.Distinct(xs[2:]))          # a second unit overlapping the first
+        for i in range(V - 1):
+            if case != 5 and rng.random() < 0.4:
+                cs.alloc(M.XLessY(xs[i], M.Addition(xs[i + 1], int(rng.integers(0, 4)))))
+        props = cs.lower(V)
+        lb0, ub0 = vs.bounds()
+        N = 300
+        L = np.tile(lb0, (N, 1)); U = np.tile(ub0, (N, 1))
+        for k in range(N):
+            p_assign = rng.uniform(0.1, 0.95)
+            for v in range(V):
+                r = rng.random()
+                if r < p_assign:
+                    L[k, v] = U[k, v] = int(rng.integers(dom[0], min(dom[1], dom[0] + V + 3) + 1))   # values collide often
+                elif r < p_assign + 0.2:
+                    a_ = int(rng.integers(dom[0], dom[1] + 1)); b_ = int(rng.integers(a_, dom[1] + 1))
+                    L[k, v], U[k, v] = a_, b_
+        if case == 5:  # pairwise disjoint singletons: the unit is entailed
+            for k in range(0, N, 3):
+                perm = rng.permutation(dom[1] - dom[0] + 1)[:V] + dom[0]
+                L[k] = U[k] = perm
+        L, U = L.astype(np.int32), U.astype(np.int32)
+        act = random_active(500 + case, N, len(cs), p_off=0.1)
+        ref, got = both(ctx, V, props, L, U, act, f"all-different case {case}")
+        assert ctx.n_units == len(cs)
+        assert (ref[3] == 0).any()
+        if case == 5:
+            assert (ref[3] == 1).any()  # (every third node is a permutation: the unit, the only one, is entailed — True)
+
+
 def test_golomb_distinct_sum_network(ctx):
     """BASELINE config 4: EQ3 sum network + ONE Distinct unit (a Conjunction group of 990 XNeqY) + LT chain, V=55;
     the search frontier after 12 BinarySplit levels, propagated in one launch (batch and team paths)."""
@@ -504,7 +546,13 @@ def test_golomb_distinct_sum_network(ctx):
     assert L4.shape[0] >= 2048
     ref4 = om.consistency(L4, U4, A4)
     got4 = ctx.propagate(L4, U4, A4)
+    assert ctx.last_plan()["path"] == 4  # the bench leg's kernel: one wavefront per node, the Distinct of 990 pairs as ONE all-different step
     assert_parity(ref4[:4], got4[:4], f"golomb frontier of {L4.shape[0]} nodes")
+    ctx.set_option("small_alldiff", 0)   # the same kernel with the Distinct pair by pair
+    got4p = ctx.propagate(L4, U4, A4)
+    ctx.set_option("small_alldiff", 1)
+    assert ctx.last_plan()["path"] == 4
+    assert_parity(ref4[:4], got4p[:4], f"golomb frontier of {L4.shape[0]} nodes, pairwise Distinct")
     got4i = ctx.propagate_implicit(L4, U4)
     assert_parity(om.consistency(L4, U4, None)[:4], got4i[:4], f"golomb frontier of {L4.shape[0]} nodes [implicit]")
 
