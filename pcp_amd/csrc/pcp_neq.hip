@@ -396,15 +396,17 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
           if constexpr (PACKED) p0[i * B] = __builtin_amdgcn_perm((uint32_t)u[i], (uint32_t)(-l[i]), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
           else p0[i * B] = make_int2(-l[i], u[i]);
         }
-        const uint32_t f_oob = ((mn < -lim) | (mx > lim)) ? 2u : 0u;  // refused, not wrapped (pcp_hip.h)
-        if (dmin <= 0 || a.seed_always) {
+        // everything else is ONE rarely taken branch: a bound out of range (the node is refused, not wrapped: pcp_hip.h), an empty domain
+        // (the node is failed), a singleton (an assigned variable: marked for the sweep round) or a model with Constant neighbours
+        if (((mn < -lim) | (mx > lim) | (dmin <= 0)) || a.seed_always) {
           uint32_t nib = 0;
 #pragma unroll
           for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
           if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
           if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+          return (((mn < -lim) | (mx > lim)) ? 2u : 0u) | (dmin < 0 ? 1u : 0u);
         }
-        return f_oob | (dmin < 0 ? 1u : 0u);        // empty input domain: the node is failed
+        return 0u;
       }
       uint32_t nib = 0;
       bool bad = false, oob = false;
@@ -424,7 +426,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
       return (bad ? 1u : 0u) | (oob ? 2u : 0u);
     };
-    auto note = [&](uint32_t f, uint32_t b) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; };
+    auto note = [&](uint32_t f, uint32_t b) { if (f) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; } };
     const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
     if (vec) {
       // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight

@@ -59,7 +59,7 @@ def nodes_with_assignments(seed, n_vars, n_nodes, dom, p_assign=0.3, p_narrow=0.
 
 def run_both_paths(ctx, om, L, U, what, in_place=True):
     ref = om.consistency(L, U, None)
-    ctx.set_option("neq_path", 1)
+    ctx.set_option("neq_path", 1); ctx.set_option("small_path", 0)  # (a handful of nodes of a small store would take pcp_small.hip)
     got = ctx.propagate_implicit(L, U, in_place=in_place)
     pl = ctx.last_plan()
     assert pl["path"] == 1 and pl["implicit_active"] == 1, pl
