@@ -209,10 +209,61 @@ def run_search_mode(args, torch, dist, world, rank, dev):
         }), flush=True)
 
 
+def c5_legs(args, torch, dist, world, rank, dev, n):
+    """--gpus N > 1, appended to the headline run (every rank calls it): BASELINE config 5 on a fixed node budget, twice —
+    the sharded open-node WORKLIST (distributed.parallel_search_device: all_gather of the stack sizes + pairwise send/recv of node
+    records over RCCL every few rounds) and the interval FOREST with its cross-rank refill.  Returns flat keys (rank 0 prints them):
+    c5_nps nodes/s of the worklist engine, c5_xchg_share = the slowest rank's share of wall time inside the exchange step,
+    c5_moved node records that changed GPU, c5_moved_mb; c5f_nps / c5f_moved the forest's."""
+    import pcp_amd.engine as E
+    from pcp_amd import model as M
+    from pcp_amd import distributed as D
+    from pcp_amd.search_device import DeviceSearch
+    from pcp_amd.search_forest import forest_search
+    ctx = E.Context(dev.index)
+    ctx.set_model(n, M.nqueens_props(n))
+    ctx.set_hull(1, n)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    batch, budget = args.search_batch, args.c5_budget
+    out = {}
+
+    def timed(fn):
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(); dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return r, float(t.item())
+
+    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, budget + 4 * batch), implicit=True)
+    D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=min(budget, 8 * batch * world), rounds_per_exchange=args.rounds_per_exchange, base=1)
+    info = {}
+    (nodes, sols, fails, steps, moved), dt = timed(lambda: D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=budget,
+                                                                                  rounds_per_exchange=args.rounds_per_exchange, info=info, base=1))
+    x = torch.tensor([info.get("exchange_s", 0.0)], dtype=torch.float64, device=dev)
+    dist.all_reduce(x, op=dist.ReduceOp.MAX)
+    out.update(c5_nps=float(f"{nodes / dt:.4g}"), c5_xchg_share=round(float(x.item()) / dt, 4), c5_moved=int(moved),
+               c5_moved_mb=round(moved * info.get("record_bytes", 8 * n) / 1e6, 2), c5_nodes=int(nodes), c5_ms=round(dt * 1e3, 2), c5_exchanges=int(info.get("exchanges", 0)))
+    del ds
+    torch.cuda.empty_cache()
+    trees = args.trees if args.trees else 4096
+    spl = args.steps_per_launch if args.steps_per_launch else 1024
+    forest_search(ctx, lb0, ub0, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world, dist=dist)
+    finfo = {}
+    fr, dtf = timed(lambda: forest_search(ctx, lb0, ub0, node_limit=8 * budget, n_trees=trees, steps_per_launch=spl, rank=rank, world=world, dist=dist, info=finfo))
+    tot = torch.tensor([fr["nodes"], finfo.get("moved_rows", 0), fr["error"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    fn, fm, fe = (int(v) for v in tot.tolist())
+    out.update(c5f_nps=float(f"{fn / dtf:.4g}"), c5f_moved=fm, c5f_nodes=fn, c5f_ms=round(dtf * 1e3, 2), c5f_err=fe)
+    return out
+
+
 def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode=True):
     """--mode search (--engine forest, and always with --domains set): every rank expands the root to the same frontier (no communication), takes the open nodes
     r, r + world, ... and searches each as a tree in one CU's LDS with an undo trail (pcp_amd.search_forest); one all_reduce of
-    the counters at the end.  Subtrees are not re-balanced (N-queens-1000: no subtree ends within the budget)."""
+    the counters at the end.  Interval forest with N > 1: the node budget is global and a rank whose trees ran dry is refilled from the
+    others between launches (search_forest.refill_across_ranks; N-queens-1000: no subtree ends within the budget, so nothing moves)."""
     from pcp_amd.search_forest import forest_search, forest_search_set
     n = args.n
     trees = args.trees if args.trees else (512 if set_mode else 4096)
@@ -222,7 +273,8 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
     def search(limit, steps):
         if set_mode:
             return forest_search_set(ctx, lb0, ub0, 1, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world, info=info)
-        return forest_search(ctx, lb0, ub0, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world)
+        return forest_search(ctx, lb0, ub0, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world,
+                             dist=dist if world > 1 else None, info=info)
 
     search(4 * trees * world, 4)  # warm-up
     torch.cuda.synchronize()
@@ -260,6 +312,8 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
                 "steps_reference_equivalent_per_s": steps / dt, "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails,
                 "trees": ntrees, "steps_per_launch": spl, "launches_rank0": fr["launches"], "error": err, "engine": "forest",
                 "trail_entries_max_rank0": info.get("trail_max"), "levels_max_rank0": info.get("levels_max"), "domains": "set" if set_mode else "interval",
+                "stack_rows_per_tree_rank0": info.get("capacity"), "stack_grown_rank0": info.get("grown"), "moved_rows_rank0": info.get("moved_rows"),
+                "exchange_seconds_rank0": info.get("exchange_s"),
                 "parallelism": f"subtrees sharded over {world} GPU(s)",
             },
         }), flush=True)
@@ -293,6 +347,9 @@ def main():
     ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
     ap.add_argument("--search-batch", type=int, default=4096)
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
+    ap.add_argument("--c5-single", action="store_true", help="run the config-5 legs of --gpus N > 1 on one GPU too (one-rank process group)")
+    ap.add_argument("--c5-budget", type=int, default=262144,
+                    help="--gpus N > 1: nodes of the short config-5 leg appended to the headline run (worklist engine; the forest leg runs 8x as many); 0 = skip")
     ap.add_argument("--engine", choices=["forest", "worklist"], default="forest",
                     help="--mode search: forest = one in-kernel DFS per open node of a frontier, no exchange (default; the only engine for --domains set); "
                          "worklist = batched rounds with the open-node stacks balanced GPU-to-GPU over RCCL")
@@ -406,6 +463,16 @@ def main():
     steps_all, eval_all, full_all = (float(x) for x in t_cnt.tolist())
 
     status = t_status.cpu().numpy()
+    c5 = {}
+    if args.c5_budget > 0 and (world > 1 or args.c5_single):
+        if not dist.is_initialized():  # --c5-single: the same legs through a one-rank RCCL group (a 1-GPU box can check everything but the transfers)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29543")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if world > 1:  # (one GPU keeps pool[0] for the parity check below)
+            pool.clear()
+            torch.cuda.empty_cache()
+        c5 = c5_legs(args, torch, dist, world, rank, dev, n)
     if rank == 0:
         k_ms = float(np.median(kernel_ms))
         compulsory = args.nodes * node_bytes(V, words, not implicit) + 8 * V * min(args.nodes, per_step["narrowings"])
@@ -438,7 +505,7 @@ def main():
                 "active_rows": args.active,
                 "plan": plan,
                 "domain_cells": "i32 bounds in/out; 16-bit packed (-lb, ub) LDS cells under the declared hull [1,n]",
-                "fresh_inputs": max(0, min(args.steps, len(pool) - args.warmup)),
+                "fresh_inputs": max(0, min(args.steps, n_pool - args.warmup)),
                 "filter_steps_per_step_per_gpu": per_step["steps"] + per_step["steps3"],
                 "evaluated_per_step_per_gpu": per_step["evaluated"],
                 "full_evals_per_step_per_gpu": per_step["full_evals"],
@@ -509,6 +576,7 @@ def main():
         put_ms("expl_ms", "C2-frontier-explicit-active-rows"); put_k("expl_frac", "C2-frontier-explicit-active-rows", "hbm_frac", 3)
         put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
         put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
+        flat.update(c5)  # --gpus N > 1: the config-5 legs that exercise RCCL
         out["config"] = {**flat, **out["config"]}
         if legs:
             full = json.dumps({"legs": legs})
@@ -521,7 +589,7 @@ def main():
                 pass
         _flush_c_stdio()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()
 

@@ -332,12 +332,16 @@ class Context:
                 "first_solution": sol.cpu().numpy() if cn[1] else None}
 
     def dfs_forest(self, root_lb, root_ub, stop_on_solution: bool = False, node_limit_per_tree: int = 0, steps_per_launch: int = 256, capacity: int = 2048,
-                   max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False, rebalance: bool = True, info: dict | None = None):
+                   max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False, rebalance: bool = True, info: dict | None = None, dist=None, max_capacity: int = 0):
         """pcp_dfs_forest_device: the reference's search loop (interval mode, all-XNeqY models) on many subtrees at once, one workgroup per
         tree, each exactly a pcp_dfs_device instance.  root_lb / root_ub: [n_trees, n_vars] int32 (numpy or CUDA tensors): the roots, not yet
         propagated.  Launches of steps_per_launch nodes per tree are repeated until every stack is empty, a tree stopped (solution with
         stop_on_solution / error / its node limit), node_budget nodes were explored by all trees together (checked between launches) or
-        max_launches is reached.  Returns dict(nodes, solutions, failed, error, open, launches, per_tree=[n_trees, 5], first_solutions)."""
+        max_launches is reached.  With ``dist`` (a torch.distributed group / module, one rank per GPU) the launches run in lockstep on every
+        rank, node_budget and the end of the search are GLOBAL (one small all_reduce per launch), and a rank whose trees ran dry takes open
+        nodes from the other ranks (search_forest.refill_across_ranks).  ``capacity`` rows per tree are allocated up front and doubled, up to
+        ``max_capacity``, whenever a tree fills its stack (error 1 is only reported beyond that).  Returns dict(nodes, solutions, failed, error, open, launches,
+        per_tree=[n_trees, 5], first_solutions) — this rank's counters."""
         import torch
         dev = torch.device("cuda", self.device)
         V = self.n_vars
@@ -352,29 +356,26 @@ class Context:
         status = torch.zeros((T, capacity), dtype=torch.uint8, device=dev)
         counters = torch.zeros((T, 5), dtype=torch.int64, device=dev)
         sol = torch.zeros((T, V), dtype=torch.int32, device=dev) if want_solution else None
-        st = DfsState(lb.data_ptr(), ub.data_ptr(), capacity, sp.data_ptr(), stop.data_ptr(), status.data_ptr(), counters.data_ptr(), sol.data_ptr() if want_solution else None)
+        from .search_forest import ForestStacks, run_forest_loop
         stream = torch.cuda.current_stream(dev).cuda_stream
-        launches = steals = 0
-        while launches < max_launches:
-            self._check(self._L.pcp_dfs_forest_device(self._h, C.byref(st), T, int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit_per_tree), C.c_void_p(stream)))
-            launches += 1
-            live = (sp > 0) & (stop == 0)
-            summary = torch.stack([live.sum(), counters[:, 0].sum(), counters[:, 1].sum(), counters[:, 3].max()]).cpu().tolist()  # (the launch's only synchronisation)
-            if summary[0] == 0 or summary[3] or (stop_on_solution and summary[2]) or (node_budget and summary[1] >= node_budget):
-                break
-            if rebalance and summary[0] < T and not node_limit_per_tree:
-                # Finished trees take work from the others: the BOTTOM row of a tree's stack is its oldest open node (the subtree nearest
-                # its root); it moves to the finished tree's row 0 and the donor's stack shifts down by one row.  Counters stay per
-                # tree, so their sum is the search's.  (With a per-tree node limit a tree that reached it must stay stopped.)
-                spc = sp.cpu().numpy()
-                idle = [int(i) for i in np.nonzero(spc == 0)[0]]
-                donors = [int(i) for i in np.argsort(-spc) if spc[i] >= 2][:len(idle)]
-                for d, r in zip(donors, idle):
-                    k = int(spc[d])
-                    lb[r, 0] = lb[d, 0]; ub[r, 0] = ub[d, 0]
-                    lb[d, 0:k - 1] = lb[d, 1:k].clone(); ub[d, 0:k - 1] = ub[d, 1:k].clone()
-                    sp[d] = k - 1; sp[r] = 1
-                    steals += 1
+        box = {}
+
+        def point(fs):  # (re)build the pcp_dfs_state over the forest's current buffers
+            box["st"] = DfsState(fs.lb.data_ptr(), fs.ub.data_ptr(), fs.capacity, sp.data_ptr(), stop.data_ptr(), fs.status.data_ptr(), counters.data_ptr(),
+                                 sol.data_ptr() if want_solution else None)
+
+        fs = ForestStacks(lb, ub, status, sp, stop, counters, max_capacity=max(max_capacity, capacity), on_grow=point)
+        del lb, ub, status
+        point(fs)
+
+        def launch():
+            self._check(self._L.pcp_dfs_forest_device(self._h, C.byref(box["st"]), T, int(steps_per_launch), int(bool(stop_on_solution)), int(node_limit_per_tree), C.c_void_p(stream)))
+
+        loop = run_forest_loop(launch, fs, stop_on_solution=stop_on_solution, node_budget=node_budget,
+                               rebalance=rebalance and not node_limit_per_tree, max_launches=max_launches, dist=dist)
+        launches, steals = loop["launches"], loop["steals"]
+        if info is not None:
+            info.update(loop)
         cn = counters.cpu().numpy()
         return {"nodes": int(cn[:, 0].sum()), "solutions": int(cn[:, 1].sum()), "failed": int(cn[:, 2].sum()), "error": int(cn[:, 3].max()),
                 "open": int(sp.sum().item()), "launches": launches, "per_tree": cn, "trees": T, "steals": steals,

@@ -90,3 +90,20 @@ def test_finished_trees_take_the_oldest_open_node_of_the_others(ctx, n, trees, s
     plain = ctx.dfs_forest(rl, ru, steps_per_launch=steps, capacity=256, rebalance=False)
     assert (plain["nodes"], plain["solutions"], plain["failed"]) == rest and plain["steals"] == 0
     assert r["launches"] < plain["launches"]
+
+
+@pytest.mark.parametrize("n,trees,steps", [(10, 4, 50), (12, 16, 200)])
+def test_stacks_grow_on_demand(ctx, n, trees, steps):
+    """Stacks that start far too small (2 rows per tree) are doubled whenever a tree fills its rows (ForestStacks.grow): the forest
+    still visits exactly the oracle's tree; a ceiling that is too low is reported as error 1, never hidden."""
+    from pcp_amd.search_forest import seed_roots_interval
+    props, lb0, ub0 = nqueens(ctx, n)
+    want = oracle_tree(n, props, lb0, ub0)
+    rl, ru, st = seed_roots_interval(ctx, lb0, ub0, trees)
+    rest = (want[0] - st.num_nodes, want[1] - st.num_solution, want[2] - st.num_failed_node)
+    info = {}
+    r = ctx.dfs_forest(rl, ru, steps_per_launch=steps, capacity=2, max_capacity=256, info=info)
+    assert r["error"] == 0 and r["open"] == 0 and (r["nodes"], r["solutions"], r["failed"]) == rest
+    assert info["grown"] >= 1 and 2 < info["capacity"] <= 256
+    low = ctx.dfs_forest(rl, ru, steps_per_launch=steps, capacity=2, max_capacity=2, rebalance=False)
+    assert low["error"] == 1 and low["open"] > 0

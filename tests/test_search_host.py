@@ -270,3 +270,141 @@ def test_forest_budget_shares_add_up():
         shares = [share_of_budget(limit, seeded, r, world) for r in range(world)]
         assert sum(shares) == max(limit - seeded, 0)
         assert max(shares) - min(shares) <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The interval forest's host loop (pcp_amd.search_forest.run_forest_loop) with a stand-in for pcp_dfs_forest_device that does what the
+# kernel does to the stacks (pop, propagate — here with the oracle —, count, push the left child above the right one, error 1 when a
+# stack is full): refill within a rank, refill across ranks over gloo, and stacks that grow on demand.
+# ---------------------------------------------------------------------------------------------------------------
+class _StandInForest:
+    def __init__(self, n, trees, capacity, roots, max_capacity):
+        import torch
+        from pcp_amd.search_forest import ForestStacks
+        self.n, self.T = n, trees
+        self.ctx = OracleCtx(n, M.nqueens_props(n))
+        lb = torch.zeros((trees, capacity, n), dtype=torch.int32)
+        ub = torch.zeros((trees, capacity, n), dtype=torch.int32)
+        sp = torch.zeros(trees, dtype=torch.int32)
+        for t, (l, u) in enumerate(roots):
+            lb[t, 0] = torch.from_numpy(l); ub[t, 0] = torch.from_numpy(u); sp[t] = 1
+        self.fs = ForestStacks(lb, ub, torch.zeros((trees, capacity), dtype=torch.uint8), sp, torch.zeros(trees, dtype=torch.int32),
+                               torch.zeros((trees, 5), dtype=torch.int64), max_capacity=max_capacity)
+        self.visited = []  # (lb, ub) of every node this rank counted, as tuples
+        self.solutions = []
+
+    def launch(self, steps):
+        from pcp_amd import search as S
+        fs = self.fs
+        for t in range(self.T):
+            for _ in range(steps):
+                sp = int(fs.sp[t])
+                if sp == 0 or int(fs.stop[t]):
+                    break
+                l, u = fs.lb[t, sp - 1].numpy().copy(), fs.ub[t, sp - 1].numpy().copy()
+                pl, pu, _, st, _ = self.ctx.propagate(l[None], u[None])
+                key = (tuple(int(x) for x in l), tuple(int(x) for x in u))
+                if st[0] == 0:
+                    fs.counters[t, 0] += 1; fs.counters[t, 2] += 1; fs.sp[t] = sp - 1
+                    self.visited.append(key)
+                elif st[0] == 1:
+                    fs.counters[t, 0] += 1; fs.counters[t, 1] += 1; fs.sp[t] = sp - 1
+                    self.visited.append(key)
+                    self.solutions.append(tuple(int(x) for x in pl[0]))
+                elif sp >= fs.capacity:
+                    fs.counters[t, 3] = 1; fs.stop[t] = 1  # stack full: the node stays, uncounted
+                else:
+                    fs.counters[t, 0] += 1
+                    self.visited.append(key)
+                    cl, cu, _ = S.branch(pl, pu, None)
+                    import torch
+                    fs.lb[t, sp - 1] = torch.from_numpy(cl[1]); fs.ub[t, sp - 1] = torch.from_numpy(cu[1])  # the right child takes the parent's row
+                    fs.lb[t, sp] = torch.from_numpy(cl[0]); fs.ub[t, sp] = torch.from_numpy(cu[0])          # the left child goes on top
+                    fs.sp[t] = sp + 1
+
+
+def _reference_tree(n):
+    """Every node of the n-queens search tree as the (lb, ub) it is entered with, by the plain recursive definition."""
+    from pcp_amd import search as S
+    ctx = OracleCtx(n, M.nqueens_props(n))
+    nodes, sols, stack = [], [], [(np.ones(n, np.int32), np.full(n, n, np.int32))]
+    while stack:
+        l, u = stack.pop()
+        nodes.append((tuple(int(x) for x in l), tuple(int(x) for x in u)))
+        pl, pu, _, st, _ = ctx.propagate(l[None], u[None])
+        if st[0] == 1:
+            sols.append(tuple(int(x) for x in pl[0]))
+        elif st[0] == 2:
+            cl, cu, _ = S.branch(pl, pu, None)
+            stack.append((cl[1], cu[1])); stack.append((cl[0], cu[0]))
+    return nodes, sols
+
+
+def test_forest_loop_grows_stacks_and_refills_locally():
+    """One rank, 4 trees, the whole tree below ONE root: the three empty trees are fed by the first one, the 2-row stacks are doubled
+    on demand, and the forest visits exactly the reference's nodes."""
+    from pcp_amd.search_forest import run_forest_loop
+    n = 7
+    ref_nodes, ref_sols = _reference_tree(n)
+    f = _StandInForest(n, 4, 2, [(np.ones(n, np.int32), np.full(n, n, np.int32))], max_capacity=64)
+    r = run_forest_loop(lambda: f.launch(3), f.fs)
+    assert sorted(f.visited) == sorted(ref_nodes) and len(set(f.visited)) == len(f.visited)
+    assert sorted(f.solutions) == sorted(ref_sols)
+    assert int(f.fs.counters[:, 0].sum()) == len(ref_nodes) and int(f.fs.counters[:, 3].max()) == 0
+    assert r["steals"] > 0 and r["grown"] > 0 and 2 < r["capacity"] <= 64
+    assert (f.fs.counters[:, 0] > 0).all()  # every tree did real work
+    # a ceiling that is too low is reported, not hidden
+    g = _StandInForest(n, 1, 2, [(np.ones(n, np.int32), np.full(n, n, np.int32))], max_capacity=2)
+    run_forest_loop(lambda: g.launch(3), g.fs)
+    assert int(g.fs.counters[0, 3]) == 1
+
+
+def _forest_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    from pcp_amd.search_forest import run_forest_loop
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # ALL the work starts on rank 0 (one root); the other ranks' trees are empty: they can only work on what the refill brings
+        roots = [(np.ones(n, np.int32), np.full(n, n, np.int32))] if rank == 0 else []
+        f = _StandInForest(n, 3, 4, roots, max_capacity=64)
+        r = run_forest_loop(lambda: f.launch(2), f.fs, dist=dist)
+        q.put((rank, f.visited, f.solutions, int(f.fs.counters[:, 0].sum()), r["moved_rows"], r["launches"], int(f.fs.counters[:, 3].max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_four_rank_forest_refill_gloo():
+    """world_size 4 over gloo: the forest with cross-rank refill explores EXACTLY the reference's tree (every node once, on some rank),
+    rows really move between ranks, every rank works, and all ranks run the same number of launches."""
+    import torch.multiprocessing as mp
+    n, world = 8, 4
+    ref_nodes, ref_sols = _reference_tree(n)
+    assert len(ref_nodes) == 779 and len(ref_sols) == 92
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_forest_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    visited = [v for r in res for v in r[1]]
+    assert len(visited) == 779 and sorted(visited) == sorted(ref_nodes)
+    assert sorted(s for r in res for s in r[2]) == sorted(ref_sols)
+    assert sum(r[3] for r in res) == 779 and all(r[3] > 0 for r in res)
+    assert res[0][4] > 0 and sum(r[4] for r in res) >= 3  # rank 0 gave rows away; at least one per starved rank
+    assert len({r[5] for r in res}) == 1 and all(r[6] == 0 for r in res)
+
+
+def test_plan_refill():
+    from pcp_amd.search_forest import plan_refill
+    assert plan_refill([0, 3, 0, 2], [4, 0, 2, 0]) == [(0, 1, 3), (0, 3, 1), (2, 3, 1)]
+    assert plan_refill([0, 0], [5, 5]) == []
+    assert plan_refill([2, 2], [0, 0]) == []
+    assert plan_refill([1, 0], [3, 3]) == [(1, 0, 1)]  # a rank with idle trees does not give
+    mv = plan_refill([0, 7, 0], [2, 0, 1])
+    assert sum(k for _, _, k in mv) == 3 and all(k >= 1 for _, _, k in mv)
