@@ -190,7 +190,7 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     dt = float(t_dt.item())
     if rank == 0:
         _flush_c_stdio()
-        print(json.dumps({
+        emit_json({
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: sharded open-node worklist)",
             "value": info.get("evaluated", 0) / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
@@ -206,7 +206,7 @@ def run_search_mode(args, torch, dist, world, rank, dev):
                 "record_bytes": 8 * n + (8 * n * ((n + 63) // 64) if set_mode else 0), "domains": args.domains,
                 "parallelism": f"worklist sharded over {world} GPU(s)",
             },
-        }), flush=True)
+        })
 
 
 def c5_legs(args, torch, dist, world, rank, dev, n):
@@ -297,7 +297,7 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
     nodes, sols, fails, evaluated, steps, ntrees, err = (int(x) for x in tot.tolist())
     if rank == 0:
         _flush_c_stdio()
-        print(json.dumps({
+        emit_json({
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000 (config 5: parallel subtree search" + (" over FDSpace)" if set_mode else ")"),
             "value": evaluated / dt, "unit": "filter-steps/s", "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": dt * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64" if set_mode else "i32", "data": "synthetic",
@@ -316,7 +316,21 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
                 "exchange_seconds_rank0": info.get("exchange_s"),
                 "parallelism": f"subtrees sharded over {world} GPU(s)",
             },
-        }), flush=True)
+        })
+
+
+_JSON_FD = None
+
+
+def emit_json(obj) -> None:
+    """Write the result line to the process's original stdout (see main)."""
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    _flush_c_stdio()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
 
 
 def _flush_c_stdio():
@@ -362,6 +376,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # The ONE JSON line is the only thing that reaches the real stdout: RCCL prints a version banner on fd 1 when a process group comes
+    # up, so fd 1 is pointed at stderr for the rest of the run and the line is written to the saved descriptor.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -588,7 +608,7 @@ def main():
             except OSError:
                 pass
         _flush_c_stdio()
-        print(json.dumps(out), flush=True)
+        emit_json(out)
     if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()

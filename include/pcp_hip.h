@@ -243,6 +243,10 @@ int32_t pcp_branch_device_set(pcp_ctx* ctx, uint32_t n_nodes, const uint64_t* bi
  *                      2 hull violation; 3 an Unknown node without a variable to branch on — the reference panics, first_smallest_var.rs:36), internal },
  *                      accumulated (the caller zeroes them)
  *   first_solution   : [n_vars] device or NULL: the first solution found
+ *   node_limit       : != 0 = StopNode(limit) nested as the reference nests it, Monitor<Statistics, StopNode<..>> (stop_node.rs:90-97): the node that
+ *                      brings `nodes` to the limit is counted as a node and NEITHER as a solution nor as a failure (its status reaches the monitor as
+ *                      EndOfSearch, stop_node.rs:57-62), and `stop` is raised.  The same rule in pcp_dfs_forest_device (per tree) and
+ *                      pcp_dfs_forest_device_set (on total_nodes).
  * Interval mode only. */
 typedef struct {
   int32_t* lb;

@@ -2607,10 +2607,13 @@ __global__ void __launch_bounds__(256) dfs_step_kernel(uint32_t V, int32_t* __re
   }
   if (tid == 0) {
     const unsigned long long n = ++counters[0];
-    if (st == PCP_TRUE) {
+    // StopNode hands EndOfSearch to the monitor for the node that reaches the limit (stop_node.rs:57-62, nesting of stop_node.rs:90-97):
+    // it is a node, but neither a solution nor a failure
+    const bool last = node_limit && n >= node_limit;
+    if (st == PCP_TRUE && !last) {
       if (counters[1]++ == 0 && first_solution) counters[4] = 1;  // flag for the copy below
       if (stop_on_solution) *stop = 1u;
-    } else if (st == PCP_FALSE) {
+    } else if (st == PCP_FALSE && !last) {
       ++counters[2];
     } else if (st > PCP_UNKNOWN) {
       counters[3] = 2; *stop = 1u;  // a node the engine refused (PCP_STATUS_HULL)

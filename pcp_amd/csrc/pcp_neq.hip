@@ -1028,17 +1028,23 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const bool failed = (misc[N_FAIL] & 1u) != 0, refused = (misc[N_OOB] & 1u) != 0, open = (misc[N_UNK] & 1u) != 0;
     dfs_resume_var = 0xFFFFFFFFu;
     uint32_t new_sp = dfs_sp - 1;
+    // StopNode (stop_node.rs:57-62) replaces the status of the node that reaches the limit by EndOfSearch BEFORE the monitor sees it
+    // (Monitor<Statistics, StopNode<..>>, stop_node.rs:90-97): that node is counted as a node, never as a solution or a failure.
+    const bool last = a.dfs.node_limit && c_nodes + 1 >= a.dfs.node_limit;
     if (refused) {
       c_err = 2; dfs_stop = 1;  // a node the engine refused (PCP_STATUS_HULL)
       ++c_nodes;
     } else if (failed) {
-      ++c_nodes; ++c_fail;
+      ++c_nodes;
+      if (!last) ++c_fail;
     } else if (!open) {  // True: a solution (monitor.rs:19-68); the first one is kept
       ++c_nodes;
-      if (c_sols == 0 && a.dfs.first_solution)
-        for (uint32_t v = tid; v < V; v += nth) a.dfs.first_solution[v] = cell_bounds<PACKED>(dom[rowof(v)]).x;
-      ++c_sols;
-      if (a.dfs.stop_on_solution) dfs_stop = 1;
+      if (!last) {
+        if (c_sols == 0 && a.dfs.first_solution)
+          for (uint32_t v = tid; v < V; v += nth) a.dfs.first_solution[v] = cell_bounds<PACKED>(dom[rowof(v)]).x;
+        ++c_sols;
+        if (a.dfs.stop_on_solution) dfs_stop = 1;
+      }
     } else {
       // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (brancher.rs:52-71): the first variable of minimal size > 1
       unsigned long long key = ~0ull;

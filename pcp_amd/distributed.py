@@ -289,24 +289,26 @@ def balance_stacks(stack, dist, info: Optional[dict] = None) -> int:
     return delta
 
 
-def seed_frontier(search, lb0, ub0, dist, target: int, all_solutions: bool = True, base: int = 0) -> None:
+def seed_frontier(search, lb0, ub0, dist, target: int, all_solutions: bool = True, base: int = 0, node_limit: int = 0) -> int:
     """"the frontier is first expanded breadth-first to >= 8*64 open nodes, then sharded".  Every rank runs the SAME
     expansion of the root (no communication: it is a few rounds of at most `batch` nodes) and keeps the open nodes r, r + world,
     r + 2 world, ...; the nodes of the expansion are counted once, on rank 0.  No GPU waits for the first exchange."""
     world, rank = dist.get_world_size(), dist.get_rank()
     search.reset(lb0, ub0, base) if getattr(search, "bits", None) is not None else search.reset(lb0, ub0)
-    while 0 < search.size < target:
-        if search.advance(all_solutions=all_solutions, max_rounds=1, keep_solutions=0):
+    # (the expansion is part of the search: it stops at the node limit like everything else — StopNode, stop_node.rs:57-62)
+    while 0 < search.size < target and not (node_limit and search.stats.num_nodes >= node_limit):
+        if search.advance(all_solutions=all_solutions, max_rounds=1, keep_solutions=0, node_limit=node_limit):
             break
+    seeded = int(search.stats.num_nodes)  # (the same number on every rank)
     if world == 1:
-        return
+        return seeded
     found = (not all_solutions) and search.stats.num_solution > 0
     if rank != 0:  # the expansion's nodes, failures and solutions are rank 0's to report
         search.stats = type(search.stats)()
         search.ctx.stats_reset(search._stream())
-    if found:
+    if found or (node_limit and seeded >= node_limit):
         search.segs = []
-        return
+        return seeded
     search.compact()
     n = search.size
     import torch
@@ -314,6 +316,7 @@ def seed_frontier(search, lb0, ub0, dist, target: int, all_solutions: bool = Tru
     for t in search._rows():
         t[:idx.numel()] = t[idx]
     search.segs = [[0, int(idx.numel())]] if idx.numel() else []
+    return seeded
 
 
 def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, node_limit: int = 0, rounds_per_exchange: int = 4, info: Optional[dict] = None,
@@ -326,7 +329,7 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
     import torch
     dev = search.lb.device
     world = dist.get_world_size()
-    seed_frontier(search, lb0, ub0, dist, min(seed_nodes, search.batch * world) if world > 1 else 0, all_solutions=all_solutions, base=base)
+    seed_frontier(search, lb0, ub0, dist, min(seed_nodes, search.batch * world) if world > 1 else 0, all_solutions=all_solutions, base=base, node_limit=node_limit)
     moved = 0
     exchange_s, exchanges = 0.0, 0
     xinfo = {}

@@ -382,7 +382,7 @@ class Context:
                 "first_solutions": sol.cpu().numpy() if want_solution else None}
 
     def dfs_forest_set(self, root_bits, stop_on_solution: bool = False, node_limit: int = 0, steps_per_launch: int = 256,
-                       level_capacity: int = 4096, trail_capacity: int = 1 << 20, max_launches: int = 1 << 30, want_solution: bool = True,
+                       level_capacity: int = 0, trail_capacity: int = 0, max_launches: int = 1 << 30, want_solution: bool = True,
                        info: dict | None = None, rebalance: bool = True):
         """pcp_dfs_forest_device_set: the reference's search loop over FDSpace on the device, one tree per workgroup, the current
         node in LDS, an undo trail in HBM.  root_bits: [n_trees, n_vars, set_words] uint64 (numpy or a CUDA int64 tensor): the roots,
@@ -392,6 +392,11 @@ class Context:
         import torch
         dev = torch.device("cuda", self.device)
         V, sw = self.n_vars, self.set_words
+        # 0 = the model's own bound: a trail entry takes at least one value out of a set and is popped before the value can return, so a
+        # tree never holds more entries (or open levels) than the root has values
+        bound = V * sw * 64 + 16
+        trail_capacity = int(trail_capacity) or bound
+        level_capacity = int(level_capacity) or min(bound, 1 << 14)
         if isinstance(root_bits, np.ndarray):
             bits = torch.from_numpy(np.ascontiguousarray(root_bits).view(np.int64)).to(dev)
         else:

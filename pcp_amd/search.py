@@ -130,6 +130,11 @@ def dfs(ctx, lb0: np.ndarray, ub0: np.ndarray, all_solutions: bool = False, node
             st.launches += 1
             st.filter_steps += s["steps"] + s["steps3"]
         st.num_nodes += L.shape[0]
+        if node_limit and st.num_nodes >= node_limit:
+            # StopNode hands EndOfSearch to the monitor for the node that reaches the limit (stop_node.rs:57-62 under Monitor,
+            # stop_node.rs:90-97): it is counted as a node, never as a solution or a failure
+            status = status.copy()
+            status[-1] = UNKNOWN
         st.num_failed_node += int((status == FALSE).sum())
         done = False
         for r in np.nonzero(status == TRUE)[0]:
@@ -216,16 +221,18 @@ def dfs_set(ctx, lb0: np.ndarray, ub0: np.ndarray, base: int, all_solutions: boo
             st.launches += 1
             st.filter_steps += s["steps"] + s["steps3"]
         st.num_nodes += Bt.shape[0]
+        at_limit = bool(node_limit and st.num_nodes >= node_limit)
+        if at_limit:  # the node that reaches the limit is a node, never a solution or a failure (StopNode under Monitor, stop_node.rs:57-62, 90-97)
+            status = status.copy()
+            status[-1] = UNKNOWN
         st.num_failed_node += int((status == FALSE).sum())
-        if node_limit and st.num_nodes >= node_limit:
-            break
         done = False
         for r in np.nonzero(status == TRUE)[0]:
             st.num_solution += 1
             st.solutions.append(lb[r].copy())
             if not all_solutions:
                 done = True
-        if done:
+        if done or at_limit:
             break
         unk = np.nonzero(status == UNKNOWN)[0]
         if len(unk):

@@ -14,7 +14,7 @@ from typing import List
 
 import numpy as np
 
-from .model import TRUE
+from .model import FALSE, TRUE
 
 
 @dataclass
@@ -171,6 +171,12 @@ class DeviceSearch:
             rounds += 1
             st.rounds += 1
             st.num_nodes += n
+            if node_limit and st.num_nodes >= node_limit:
+                # the node that reaches the limit (the last one in pop order: the lowest row of the round) is counted as a node, never as a
+                # solution or a failure: StopNode hands EndOfSearch to the monitor (stop_node.rs:57-62 under Monitor, stop_node.rs:90-97)
+                s_last = int(status[0].item())
+                n_true -= int(s_last == TRUE)
+                n_false -= int(s_last == FALSE)
             st.num_solution += n_true
             st.num_failed_node += n_false
             if n_true and len(st.solutions) < keep_solutions:

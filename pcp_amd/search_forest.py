@@ -35,9 +35,17 @@ def seed_roots(ctx, lb0, ub0, base: int, want: int):
     return roots, st
 
 
+def trail_bound(ctx) -> int:
+    """The most entries a tree's undo trail can hold: one per value of the root's sets (see forest_search_set)."""
+    return int(ctx.n_vars) * int(ctx.set_words) * 64 + 16
+
+
 def forest_search_set(ctx, lb0, ub0, base: int = 0, node_limit: int = 0, n_trees: int = 512, steps_per_launch: int = 2048, rank: int = 0, world: int = 1,
-                      trail_capacity: int = 1 << 21, level_capacity: int = 1 << 14, info: dict | None = None) -> dict:
+                      trail_capacity: int = 0, level_capacity: int = 0, info: dict | None = None) -> dict:
     """All solutions of the space below (lb0, ub0) — or the first `node_limit` nodes of this rank's share of it.
+    trail_capacity / level_capacity 0 = derived from the model (trail_bound): every trail entry takes at least one value out of one
+    set and is popped before that value can come back, so a tree's trail never holds more entries than the root has values —
+    n_vars * set_words * 64 at most.  (N-queens-1000: 1 024 000 entries = 16 MB per tree; a 100-variable model: 100 KB.)
     Returns dict(nodes, solutions, failed, error, seeded_nodes, trees, launches); with world > 1 the expansion's counters are
     reported by rank 0 only, so that a sum over the ranks counts every node once."""
     roots, st = seed_roots(ctx, lb0, ub0, base, n_trees * world)
@@ -52,7 +60,9 @@ def forest_search_set(ctx, lb0, ub0, base: int = 0, node_limit: int = 0, n_trees
             return out
     if mine.shape[0] == 0:
         return out
-    r = ctx.dfs_forest_set(mine, node_limit=budget, steps_per_launch=steps_per_launch, trail_capacity=trail_capacity, level_capacity=level_capacity,
+    bound = trail_bound(ctx)
+    r = ctx.dfs_forest_set(mine, node_limit=budget, steps_per_launch=steps_per_launch, trail_capacity=trail_capacity or bound,
+                           level_capacity=level_capacity or min(bound, 1 << 14),
                            want_solution=False, info=info)
     out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]
     out["error"] = r["error"]; out["launches"] = r["launches"]
@@ -277,7 +287,9 @@ def forest_search(ctx, lb0, ub0, node_limit: int = 0, n_trees: int = 768, steps_
     if per_tree and not multi:
         ceiling = min(ceiling, per_tree + 64)
     if not capacity:
-        capacity = min(128, ceiling)
+        # a known small bound (a per-tree share of a budget, at most 8 GiB for the forest) is allocated at once; otherwise start at 128 rows
+        row_bytes = int(ml.shape[0]) * int(ml.shape[1]) * 8
+        capacity = ceiling if (per_tree and not multi and ceiling * row_bytes <= (8 << 30)) else min(128, ceiling)
     r = ctx.dfs_forest(ml, mu, node_limit_per_tree=0 if multi else per_tree, steps_per_launch=steps_per_launch, capacity=capacity, max_capacity=max(ceiling, capacity),
                        node_budget=max(node_limit - st.num_nodes, 1) if multi else budget, dist=dist if multi else None, info=info)
     out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]

@@ -755,6 +755,34 @@ def test_device_side_dfs(ctx, n):
     assert ctx.propagate(lb0[None], ub0[None])[3][0] in (0, 1, 2)  # the context still serves ordinary calls
 
 
+@pytest.mark.parametrize("opts", [{}, {"neq_dfs": 0}, {"neq_dfs": 0, "small_path": 0}])
+def test_node_limit_lands_on_leaves_and_inner_nodes(ctx, opts):
+    """StopNode under Monitor (stop_node.rs:57-62, 90-97): the node that reaches the limit is a node and nothing else.  n-queens 6, EVERY limit
+    up to the size of the tree (the limit falls on failures, solutions and inner nodes), for the in-kernel search loop of pcp_neq.hip, the
+    stepping kernel of the generic path, the batched device search and the set forest: all four agree with the oracle."""
+    from pcp_amd.search_device import DeviceSearch
+    n = 6
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    for k, v in {"force_path": 0, "nodes_per_block": 0, "block_threads": 1024, "team": 0, "list_cap": 2048, "global_dom": 0, "packed": 1, "word_level": 1,
+                 "neq_dfs": 1, "small_path": 1, **opts}.items():
+        ctx.set_option(k, v)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    om = orc.OracleModel(n, props)
+    total = om.search(lb0, ub0, all_solutions=True)[0]["num_nodes"]
+    try:
+        for limit in range(1, total + 1):
+            ss = om.search(lb0, ub0, all_solutions=True, node_limit=limit)[0]
+            want = (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
+            r = ctx.dfs_device(lb0, ub0, 100000, capacity=64, stop_on_solution=False, node_limit=limit, chunk=7)
+            assert (r["nodes"], r["solutions"], r["failed"]) == want and r["error"] == 0, (limit, r, want)
+            if not opts and limit % 5 == 0:
+                st = DeviceSearch(ctx, batch=1, capacity=256).run(lb0, ub0, all_solutions=True, node_limit=limit)
+                assert (st.num_nodes, st.num_solution, st.num_failed_node) == want, limit
+    finally:
+        ctx.set_option("neq_dfs", 1); ctx.set_option("small_path", 1)
+
+
 def test_parallel_search_device_single_rank(ctx):
     """parallel_search_device with world_size 1 (the driver's GPU box has one GPU): the exchange steps run (all_gather,
     all_reduce) and the totals are the reference's tree."""

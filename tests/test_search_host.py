@@ -145,7 +145,7 @@ def test_two_rank_worklist_gloo(batch):
     assert len(res[0][5]) > 0 and len(res[1][5]) > 0  # both ranks did real work
 
 
-def _device_worker(rank, world, port, n, batch, implicit, q):
+def _device_worker(rank, world, port, n, batch, implicit, q, node_limit=0):
     """parallel_search_device end to end over gloo: DeviceSearch on CPU tensors with the oracle-backed stand-in context."""
     import torch
     import torch.distributed as dist
@@ -158,10 +158,30 @@ def _device_worker(rank, world, port, n, batch, implicit, q):
         ctx = OracleDeviceCtx(n, M.nqueens_props(n))
         ds = DeviceSearch(ctx, batch=batch, capacity=4096, device=torch.device("cpu"), implicit=implicit)
         info = {}
-        tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, info=info)
+        tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, info=info,
+                                       node_limit=node_limit)
         q.put((rank, tot, ds.stats.num_nodes, info["exchanges"], info["moved_bytes"], info["record_bytes"], info["exchange_s"]))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limit", [3, 10])
+def test_two_rank_small_node_limit_stops_the_expansion_gloo(limit):
+    """A node limit below the size of the replicated expansion (seed_frontier): the expansion stops AT the limit (StopNode, stop_node.rs:57-62),
+    no rank explores anything after it, and the total is exactly the limit."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_device_worker, args=(r, 2, port, 8, 16, True, q, limit)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][1][0] == limit and res[0][1][4] == 0
+    assert res[0][2] == limit and res[1][2] == 0  # the expansion's nodes are rank 0's to report
 
 
 @pytest.mark.parametrize("implicit", [True, False])
@@ -408,3 +428,22 @@ def test_plan_refill():
     assert plan_refill([1, 0], [3, 3]) == [(1, 0, 1)]  # a rank with idle trees does not give
     mv = plan_refill([0, 7, 0], [2, 0, 1])
     assert sum(k for _, _, k in mv) == 3 and all(k >= 1 for _, _, k in mv)
+
+
+@pytest.mark.parametrize("n", [5, 6])
+def test_node_limit_on_every_node_of_the_tree(n):
+    """StopNode under Monitor (stop_node.rs:57-62, 90-97): whatever node the limit falls on — a failure, a solution or an inner node —
+    that node is counted as a node and as nothing else.  The host DFS against the oracle's for EVERY limit up to the size of the tree."""
+    props = M.nqueens_props(n)
+    ctx = OracleCtx(n, props)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    om = orc.OracleModel(n, props)
+    total = om.search(lb0, ub0, all_solutions=True)[0]["num_nodes"]
+    kinds = set()
+    for limit in range(1, total + 1):
+        ss = om.search(lb0, ub0, all_solutions=True, node_limit=limit)[0]
+        st = S.dfs(ctx, lb0, ub0, all_solutions=True, node_limit=limit)
+        assert (st.num_nodes, st.num_solution, st.num_failed_node) == (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"]), limit
+        nxt = om.search(lb0, ub0, all_solutions=True, node_limit=limit + 1)[0]
+        kinds.add((nxt["num_solution"] - ss["num_solution"], nxt["num_failed_node"] - ss["num_failed_node"]))
+    assert {(1, 0), (0, 1), (0, 0)} <= kinds  # the limit fell on solutions, failures and inner nodes
