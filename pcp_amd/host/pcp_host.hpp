@@ -11,6 +11,11 @@
 //   x_geq_y_plus_z x_leq_y_plus_z — propagators/cmp/*.rs, propagators/cmp/mod.rs:34-86
 //   Distinct / join_distinct      — propagators/distinct.rs:26-126
 //   AllEqual                      — propagators/all_equal.rs:47-64
+//   Sum                           — term/sum.rs:56-92
+//   Boolean / BooleanNeg / Conjunction / Disjunction / not_ / implication / equivalence
+//                                 — logic/boolean.rs:111-140, boolean_neg.rs:71-96, conjunction.rs:70-119, disjunction.rs:68-141,
+//                                   logic/ops.rs:17-19, logic/mod.rs:30-45   (formula units: pcp_model_push_formula)
+//   Cumulative::join              — propagators/cumulative.rs:59-114
 //   GpuCStore::alloc / consistency / label / restore — propagation/store.rs:223-230, 247-257, 306-324
 //   Space::consistency            — search/space.rs:41-43
 //   one_solution / all_solutions with FirstSmallestVar, MiddleVal, BinarySplit, StopNode
@@ -22,6 +27,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -49,9 +55,10 @@ struct Interval {
 };
 
 // ---- views -------------------------------------------------------------------------------------------------
-struct Operand {  // a flattened view: Identity / Addition chain over a variable, or a Constant
-  uint32_t var;   // variable index or PCP_CONST
+struct Operand {  // a flattened view: Identity / Addition chain over a variable, a Constant, or a Sum
+  uint32_t var;   // variable index, PCP_CONST, or PCP_SUM (the members below)
   int32_t off;    // Addition offset, or the constant's value
+  std::vector<uint32_t> members;  // var == PCP_SUM: the variables of the Sum
 };
 struct View {
   virtual ~View() = default;
@@ -62,7 +69,7 @@ struct Identity final : View {
   size_t idx;
   explicit Identity(size_t i) : idx(i) {}
   size_t index() const { return idx; }
-  Operand flat() const override { return {(uint32_t)idx, 0}; }
+  Operand flat() const override { return {(uint32_t)idx, 0, {}}; }
 };
 struct Addition final : View {  // term/addition.rs: read = x + v, update(d) = x.update(d - v)
   Var x;
@@ -73,9 +80,26 @@ struct Addition final : View {  // term/addition.rs: read = x + v, update(d) = x
 struct Constant final : View {
   int32_t value;
   explicit Constant(int32_t c) : value(c) {}
-  Operand flat() const override { return {PCP_CONST, value}; }
+  Operand flat() const override { return {PCP_CONST, value, {}}; }
+};
+struct Sum final : View {  // term/sum.rs:56-92: read = the interval sum of the members; an update through it never narrows a member
+  std::vector<Var> vars;
+  explicit Sum(std::vector<Var> v) : vars(std::move(v)) {}
+  Operand flat() const override {
+    if (vars.empty()) throw Panic("At least one variable in sum.");
+    Operand o{PCP_SUM, 0, {}};
+    for (const Var& v : vars) {
+      Operand m = v->flat();
+      if (m.var == PCP_SUM) throw Panic("a Sum of Sums has no lowering");
+      o.off += m.off;  // constant members and Addition offsets fold into one offset
+      if (m.var != PCP_CONST) o.members.push_back(m.var);
+    }
+    if (o.members.empty()) o.var = PCP_CONST;
+    return o;
+  }
 };
 inline Var identity(size_t i) { return std::make_shared<Identity>(i); }
+inline Var sum(std::vector<Var> vars) { return std::make_shared<Sum>(std::move(vars)); }
 inline Var addition(Var x, int32_t v) { return std::make_shared<Addition>(std::move(x), v); }
 inline Var constant(int32_t c) { return std::make_shared<Constant>(c); }
 
@@ -112,24 +136,43 @@ class VStore {
 };
 
 // ---- propagators ----------------------------------------------------------------------------------------------
-struct Propagator {  // one unit of the constraint store: one elementary filter or a Conjunction/Distinct of them
+struct Propagator {  // one unit of the constraint store (one Box<dyn PropagatorConcept>, one bit of `active`)
+  // type == PCP_F_LEAF: one elementary filter, or the members of a flat Conjunction / Distinct of them (group_kind 1 / 2)
   std::vector<pcp_prop> rows;
+  std::vector<std::vector<uint32_t>> sums;  // the Sum views of this unit: a row names one as PCP_SUM | index in this list
+  // type == PCP_F_AND / PCP_F_OR: logic::Conjunction / Disjunction over arbitrary formulas (a formula unit: pcp_model_push_formula)
+  uint8_t type = PCP_F_LEAF;
+  std::vector<Propagator> fs;
+  bool is_tree() const { return type != PCP_F_LEAF; }
 };
-inline pcp_prop make_row(pcp_kind k, std::initializer_list<Var> ops) {
+inline Propagator make_unit(pcp_kind k, std::initializer_list<Var> ops) {
+  Propagator u;
   pcp_prop p{};
   p.kind = (uint8_t)k;
   for (int i = 0; i < 3; ++i) { p.var[i] = PCP_NOVAR; p.off[i] = 0; }
   int i = 0;
-  for (const Var& v : ops) { Operand o = v->flat(); p.var[i] = o.var; p.off[i] = o.off; ++i; }
-  return p;
+  for (const Var& v : ops) {
+    Operand o = v->flat();
+    if (o.var == PCP_SUM) { p.var[i] = PCP_SUM | (uint32_t)u.sums.size(); u.sums.push_back(std::move(o.members)); }
+    else p.var[i] = o.var;
+    p.off[i] = o.off;
+    ++i;
+  }
+  u.rows.push_back(p);
+  return u;
 }
-inline Propagator XNeqY(Var x, Var y) { return {{make_row(PCP_NEQ, {x, y})}}; }
-inline Propagator XEqY(Var x, Var y) { return {{make_row(PCP_EQ, {x, y})}}; }
-inline Propagator XLessY(Var x, Var y) { return {{make_row(PCP_LT, {x, y})}}; }
-inline Propagator XLessYPlusZ(Var x, Var y, Var z) { return {{make_row(PCP_LT3, {x, y, z})}}; }
-inline Propagator XGreaterYPlusZ(Var x, Var y, Var z) { return {{make_row(PCP_GT3, {x, y, z})}}; }
-inline Propagator XEqYPlusZ(Var x, Var y, Var z) { return {{make_row(PCP_EQ3, {x, y, z})}}; }
-inline Propagator XEqYMulZ(Var x, Var y, Var z) { return {{make_row(PCP_MUL3, {x, y, z})}}; }
+inline pcp_prop make_row(pcp_kind k, std::initializer_list<Var> ops) {  // (views without Sums)
+  Propagator u = make_unit(k, ops);
+  if (!u.sums.empty()) throw Panic("Sum views are not allowed here");
+  return u.rows[0];
+}
+inline Propagator XNeqY(Var x, Var y) { return make_unit(PCP_NEQ, {x, y}); }
+inline Propagator XEqY(Var x, Var y) { return make_unit(PCP_EQ, {x, y}); }
+inline Propagator XLessY(Var x, Var y) { return make_unit(PCP_LT, {x, y}); }
+inline Propagator XLessYPlusZ(Var x, Var y, Var z) { return make_unit(PCP_LT3, {x, y, z}); }
+inline Propagator XGreaterYPlusZ(Var x, Var y, Var z) { return make_unit(PCP_GT3, {x, y, z}); }
+inline Propagator XEqYPlusZ(Var x, Var y, Var z) { return make_unit(PCP_EQ3, {x, y, z}); }
+inline Propagator XEqYMulZ(Var x, Var y, Var z) { return make_unit(PCP_MUL3, {x, y, z}); }
 // propagators/cmp/mod.rs:34-86
 inline Propagator x_greater_y(Var x, Var y) { return XLessY(y, x); }
 inline Propagator x_geq_y(Var x, Var y) { return x_greater_y(addition(x, 1), y); }
@@ -167,6 +210,67 @@ inline Propagator Distinct(const std::vector<Var>& vars) {  // propagators/disti
   }
   return p;
 }
+
+// ---- the reified layer (logic/) ------------------------------------------------------------------------------------
+inline Propagator Boolean(Var b) { return make_unit(PCP_BOOL, {b}); }        // logic/boolean.rs:111-140: the formula "b = 1" over a 0/1 view
+inline Propagator BooleanNeg(Var b) { return make_unit(PCP_NBOOL, {b}); }    // logic/boolean_neg.rs:71-96: "b = 0"
+namespace detail {
+// a child formula as tree nodes: a flat Conjunction of elementary members (rows) becomes an AND node over one leaf per member
+inline Propagator as_tree_child(const Propagator& f) {
+  if (f.is_tree() || f.rows.size() <= 1) return f;
+  Propagator t;
+  t.type = PCP_F_AND;
+  for (const pcp_prop& r : f.rows) {
+    Propagator leaf;
+    pcp_prop q = r;
+    q.group_kind = 0;
+    for (int k = 0; k < 3; ++k)
+      if (q.var[k] != PCP_CONST && q.var[k] != PCP_NOVAR && (q.var[k] & PCP_SUM) == PCP_SUM) {
+        leaf.sums.push_back(f.sums[q.var[k] & ~PCP_SUM]);
+        q.var[k] = PCP_SUM | (uint32_t)(leaf.sums.size() - 1);
+      }
+    leaf.rows.push_back(q);
+    t.fs.push_back(std::move(leaf));
+  }
+  return t;
+}
+inline Propagator node(uint8_t type, std::vector<Propagator> fs) {
+  if (fs.empty()) throw Panic("a Conjunction / Disjunction needs at least one child");
+  Propagator t;
+  t.type = type;
+  for (Propagator& f : fs) t.fs.push_back(as_tree_child(f));
+  return t;
+}
+inline bool is_sum(uint32_t var) { return var != PCP_CONST && var != PCP_NOVAR && (var & PCP_SUM) == PCP_SUM; }
+}  // namespace detail
+// logic::Conjunction (logic/conjunction.rs:77-119) and logic::Disjunction (logic/disjunction.rs:78-141) over arbitrary formulas: ONE unit
+inline Propagator Conjunction(std::vector<Propagator> fs) { return detail::node(PCP_F_AND, std::move(fs)); }
+inline Propagator Disjunction(std::vector<Propagator> fs) { return detail::node(PCP_F_OR, std::move(fs)); }
+// NotFormula::not (logic/ops.rs:17-19), applied when the formula is built, as the reference does
+inline Propagator not_(const Propagator& f) {
+  if (f.is_tree()) {  // De Morgan: conjunction.rs:70-74, disjunction.rs:68-75
+    std::vector<Propagator> nf;
+    for (const Propagator& g : f.fs) nf.push_back(not_(g));
+    return f.type == PCP_F_AND ? Disjunction(std::move(nf)) : Conjunction(std::move(nf));
+  }
+  if (f.rows.size() != 1) return not_(detail::as_tree_child(f));
+  Propagator n = f;
+  pcp_prop& r = n.rows[0];
+  auto swap_ops = [&](int a, int b) { std::swap(r.var[a], r.var[b]); std::swap(r.off[a], r.off[b]); };
+  switch (r.kind) {
+    case PCP_NEQ: r.kind = PCP_EQ; break;                             // x_neq_y.rs:61-63
+    case PCP_EQ: r.kind = PCP_NEQ; break;                             // x_eq_y.rs:62-64
+    case PCP_LT: r.off[0] += 1; swap_ops(0, 1); break;                // x_less_y.rs:62-64: x >= y  =  y < x + 1
+    case PCP_LT3: r.kind = PCP_GT3; r.off[0] += 1; break;             // x_less_y_plus_z.rs:66-72: x >= y + z  =  x + 1 > y + z
+    case PCP_GT3: r.kind = PCP_LT3; r.off[0] -= 1; break;             // x_greater_y_plus_z.rs:66-72: x <= y + z  =  x - 1 < y + z
+    case PCP_BOOL: r.kind = PCP_NBOOL; break;                         // boolean.rs:74-76
+    case PCP_NBOOL: r.kind = PCP_BOOL; break;                         // boolean_neg.rs:66-68
+    default: throw Panic("not implemented");                          // XEqYPlusZ / XEqYMulZ: unimplemented!() (x_eq_y_plus_z.rs:74-76)
+  }
+  return n;
+}
+inline Propagator implication(const Propagator& f, const Propagator& g) { return Disjunction({f, not_(g)}); }                    // logic/mod.rs:30-36
+inline Propagator equivalence(const Propagator& f, const Propagator& g) { return Conjunction({implication(f, g), implication(g, f)}); }  // logic/mod.rs:38-45
 
 // ---- constraint store on the GPU --------------------------------------------------------------------------------
 // IntCStore-shaped (concept.rs:120-138): alloc, consistency, label/restore.  Branch constraints of the search —
@@ -239,7 +343,7 @@ class GpuCStore {
     if (v) b[i >> 6] |= 1ull << (i & 63); else b[i >> 6] &= ~(1ull << (i & 63));
   }
   static bool is_unary(const Propagator& p) {
-    if (p.rows.size() != 1) return false;
+    if (p.is_tree() || p.rows.size() != 1 || !p.sums.empty()) return false;
     const pcp_prop& r = p.rows[0];
     if (r.kind != PCP_LT && r.kind != PCP_EQ) return false;
     return (r.var[0] == PCP_CONST) != (r.var[1] == PCP_CONST);
@@ -273,12 +377,49 @@ class GpuCStore {
       check(pcp_model_truncate(ctx_, (uint32_t)common));
     }
     dev_units_.resize(common);
+    // runs of plain units go up in one pcp_model_push_props; a formula unit is one pcp_model_push_formula.  The Sum views of a unit are
+    // registered first (pcp_model_push_sum) and its rows re-pointed from their unit-local numbers to the terms the engine returned.
     std::vector<pcp_prop> rows;
+    auto flush = [&]() {
+      if (!rows.empty()) check(pcp_model_push_props(ctx_, (uint32_t)rows.size(), rows.data()));
+      rows.clear();
+    };
+    auto with_terms = [&](pcp_prop r, const std::vector<std::vector<uint32_t>>& sums) {
+      for (int k = 0; k < 3; ++k)
+        if (detail::is_sum(r.var[k])) {
+          const std::vector<uint32_t>& m = sums[r.var[k] & ~PCP_SUM];
+          uint32_t term = 0;
+          check(pcp_model_push_sum(ctx_, (uint32_t)m.size(), m.data(), &term));
+          r.var[k] = PCP_SUM | term;
+        }
+      return r;
+    };
     for (size_t k = common; k < want.size(); ++k) {
-      for (const pcp_prop& r : units_[want[k]].rows) rows.push_back(r);
+      const Propagator& u = units_[want[k]];
+      if (!u.is_tree()) {
+        for (const pcp_prop& r : u.rows) rows.push_back(with_terms(r, u.sums));
+      } else {
+        flush();
+        // breadth-first layout: nodes[0] is the root, the children of an inner node are consecutive
+        std::vector<pcp_fnode> nodes(1);
+        std::vector<pcp_prop> leaves;
+        std::vector<std::pair<const Propagator*, size_t>> queue{{&u, 0}};
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+          const Propagator* g = queue[qi].first;
+          const size_t at = queue[qi].second;
+          if (g->is_tree()) {
+            nodes[at] = pcp_fnode{g->type, 0, (uint16_t)g->fs.size(), (uint32_t)nodes.size()};
+            for (const Propagator& c : g->fs) { nodes.push_back(pcp_fnode{}); queue.push_back({&c, nodes.size() - 1}); }
+          } else {
+            nodes[at] = pcp_fnode{PCP_F_LEAF, 0, 0, (uint32_t)leaves.size()};
+            leaves.push_back(with_terms(g->rows[0], g->sums));
+          }
+        }
+        check(pcp_model_push_formula(ctx_, (uint32_t)nodes.size(), nodes.data(), (uint32_t)leaves.size(), leaves.data()));
+      }
       dev_units_.push_back(want[k]);
     }
-    if (!rows.empty()) check(pcp_model_push_props(ctx_, (uint32_t)rows.size(), rows.data()));
+    flush();
   }
   void check(int32_t rc) {
     if (rc == PCP_ERR_CONTRACT) throw Panic(pcp_last_error(ctx_));
@@ -298,6 +439,49 @@ inline void join_distinct(VStore&, GpuCStore& cstore, const std::vector<Var>& va
   for (size_t i = 0; i + 1 < vars.size(); ++i)
     for (size_t j = i + 1; j < vars.size(); ++j) cstore.alloc(XNeqY(vars[i], vars[j]));
 }
+
+// propagators/cumulative.rs:59-114 — the decomposition of Schutt et al.: for each task j, the resources of the tasks that overlap j's start must
+// fit the capacity.  join() allocates, per ordered pair (j, i != j): a Boolean b_i, the unit b_i <=> (s_i <= s_j /\ s_j < s_i + d_i), an
+// intermediate r = b_i * r_i (XEqYMulZ), then c >= r_j + Sum(r).  Variable and propagator allocation order as in the reference.
+class Cumulative {
+ public:
+  Cumulative(std::vector<Var> starts, std::vector<Var> durations, std::vector<Var> resources, Var capacity)
+      : starts_(std::move(starts)), durations_(std::move(durations)), resources_(std::move(resources)), capacity_(std::move(capacity)) {
+    if (starts_.size() != durations_.size() || starts_.size() != resources_.size()) throw Panic("Cumulative: starts, durations and resources differ in length");
+  }
+  void join(VStore& vstore, GpuCStore& cstore) {
+    const size_t tasks = starts_.size();
+    if (tasks == 1) {
+      cstore.alloc(x_geq_y(capacity_, resources_[0]));  // c >= r[j]   (cumulative.rs:67-70)
+      return;
+    }
+    for (size_t j = 0; j < tasks; ++j) {
+      std::vector<Var> resource_vars;
+      intermediate_.emplace_back();
+      for (size_t i = 0; i < tasks; ++i) {
+        if (i == j) continue;
+        Propagator conj = Conjunction({x_leq_y(starts_[i], starts_[j]),                       // s[i] <= s[j]
+                                       XLessYPlusZ(starts_[j], starts_[i], durations_[i])});  // s[j] < s[i] + d[i]
+        Var bi = vstore.alloc(Interval(0, 1));  // Boolean::new (boolean.rs:38-43)
+        cstore.alloc(equivalence(Boolean(bi), conj));
+        const Operand ro = resources_[i]->flat();
+        if (ro.var == PCP_SUM) throw Panic("Cumulative: a resource must be a variable view or a constant");
+        const int32_t ri_ub = ro.var == PCP_CONST ? ro.off : vstore[ro.var].upper() + ro.off;
+        Var r = vstore.alloc(Interval(0, ri_ub));
+        intermediate_.back().push_back(r->flat().var);
+        cstore.alloc(XEqYMulZ(r, bi, resources_[i]));  // r = bi * r[i]
+        resource_vars.push_back(r);
+      }
+      cstore.alloc(x_geq_y_plus_z(capacity_, resources_[j], sum(resource_vars)));  // c >= r[j] + sum
+    }
+  }
+  const std::vector<std::vector<uint32_t>>& intermediate() const { return intermediate_; }
+
+ private:
+  std::vector<Var> starts_, durations_, resources_;
+  Var capacity_;
+  std::vector<std::vector<uint32_t>> intermediate_;
+};
 
 // ---- space and search ----------------------------------------------------------------------------------------------
 struct Space {

@@ -270,3 +270,66 @@ def test_formula_at_the_depth_limit(ctx):
     L, U = random_boxes(4243, vs, 300)
     ref, _ = gpu_vs_oracle(ctx, vs, cs, L, U, "depth-8 formulas")
     assert (ref[3] == 0).any() and (ref[3] != 0).any()
+
+
+def _run_host_example(name, args):
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(g.ROOT, "pcp_amd", "host", "examples", name)
+    return json.loads(subprocess.run([exe, *[str(a) for a in args]], check=True, capture_output=True, text=True).stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_cpp_host_twin_replays_the_cumulative_tests(case):
+    """The 14 cumulative vectors through the C++ host twin (pcp_amd/host/pcp_host.hpp: Cumulative::join over Boolean / Conjunction /
+    Disjunction / implication / equivalence / XEqYMulZ / Sum, lowered by the header itself to pcp_model_push_formula): the golden status,
+    and the oracle's fixpoint bit for bit on the same store built by the Python mirror (same allocation order, so the same variable indices)."""
+    args = [int(case["constant"]), len(case["starts"])]
+    for key in ("starts", "durations", "resources"):
+        for d in case[key]:
+            args += list(d)
+    args += list(case["capacity"])
+    out = _run_host_example("cumulative", args)
+    vs, cs = cumulative_store(case)
+    assert out["vars"] == len(vs) and out["units"] == len(cs)
+    assert out["status"] == case["after"]
+    om = orc.OracleModel(len(vs))
+    M.push_model(om, cs, len(vs))
+    lb, ub = vs.bounds()
+    r = om.consistency(lb[None], ub[None], None)
+    assert int(r[3][0]) == out["status"]
+    if out["status"] != M.FALSE:
+        assert out["lb"] == [int(v) for v in r[0][0]] and out["ub"] == [int(v) for v in r[1][0]]
+
+
+@pytest.mark.gpu
+def test_cpp_host_twin_logic_layer():
+    """implication / equivalence / not_ of the C++ host twin against the same formulas built by the Python mirror and run by the oracle;
+    the second step of each pair allocs one more propagator on the narrowed store, as a search would."""
+    out = _run_host_example("cumulative", ["logic-test"])
+
+    def oracle_steps(doms, units_steps):
+        vs, cs = M.VStore(), M.CStore()
+        vars_ = [vs.alloc(d) for d in doms]
+        lb, ub = vs.bounds()
+        res = []
+        for mk in units_steps:
+            cs.alloc(mk(*vars_))
+            om = orc.OracleModel(len(vs))
+            M.push_model(om, cs, len(vs))
+            r = om.consistency(lb[None], ub[None], None)
+            res.append((int(r[3][0]), [int(v) for v in r[0][0]], [int(v) for v in r[1][0]]))
+            lb, ub = r[0][0].copy(), r[1][0].copy()
+        return res
+    want = oracle_steps([(0, 9), (0, 9), (0, 1)], [lambda x, y, b: M.equivalence(M.Boolean(b), M.XLessY(x, y)),
+                                                   lambda x, y, b: M.XEqY(b, M.Constant(1))])
+    want += oracle_steps([(5, 9), (0, 7)], [lambda x, y: M.implication(M.XLessY(x, y), M.XLessY(M.Addition(x, 3), y)),
+                                            lambda x, y: M.not_(M.x_geq_y(x, y))])
+    assert len(out) == 4
+    for got, (st, lb, ub) in zip(out, want):
+        assert got["status"] == st, (got, st)
+        if st != M.FALSE:
+            assert got["lb"] == lb and got["ub"] == ub, (got, lb, ub)
+    assert out[1]["status"] != M.FALSE and out[1]["ub"][0] == 8 and out[1]["lb"][1] == 1  # b = 1 propagated x < y
