@@ -1,9 +1,10 @@
-//! Raw bindings of `include/pcp_hip.h` (ABI v4): one line per exported symbol, `#[repr(C)]` mirrors of its structs.
+//! Raw bindings of `include/pcp_hip.h` (ABI v6): one line per exported symbol, `#[repr(C)]` mirrors of its structs — plus the four HIP
+//! runtime calls the device-resident store needs (hipMalloc / hipFree / hipMemcpy; `build.rs` links amdhip64).  UNCOMPILED here.
 //! Every entry point cites the libpcp item it replaces in the header; the safe layer is `pcp-gpu-cstore`.
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PCP_ABI_VERSION: u32 = 5;
+pub const PCP_ABI_VERSION: u32 = 6;
 pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
 pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
 pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
@@ -26,6 +27,8 @@ pub const PCP_LT3: u8 = 3;
 pub const PCP_GT3: u8 = 4;
 pub const PCP_EQ3: u8 = 5;
 pub const PCP_MUL3: u8 = 6;
+pub const PCP_BOOL: u8 = 7; //  logic::Boolean, "X = 1" over a 0/1 view (one operand)
+pub const PCP_NBOOL: u8 = 8; // logic::BooleanNeg, "X = 0"
 // pcp_status == trilean::SKleene
 pub const PCP_FALSE: u8 = 0;
 pub const PCP_TRUE: u8 = 1;
@@ -94,7 +97,8 @@ pub struct pcp_plan {
     pub block: u32,
     pub lds_bytes: u32,
     pub list_cap: u32,
-    pub path: u32, // 0 generic sweep kernels, 1 assignment-driven all-XNeqY kernel
+    pub path: u32, // 0 generic sweep kernels (pcp_kernels.hip), 1 assignment-driven all-XNeqY kernel (pcp_neq.hip), 2 10-bit-cell kernel for
+                   // large binary stores (pcp_big.hip), 3 formula kernel (pcp_formula.hip), 4 one wavefront per node for small stores (pcp_small.hip)
 }
 
 /// The device-resident DFS of `pcp_dfs_device`: a LIFO stack of implicit-active nodes and its 8 bytes of state.
@@ -131,6 +135,14 @@ pub struct pcp_forest_state {
     pub solution_flag: *mut u32,
 }
 
+/// `pcp_debug_counters` slots (ABI v6): which code paths ran since the last `pcp_stats_reset`.
+pub const PCP_DBG_BIG_DENSE: usize = 0;
+pub const PCP_DBG_BIG_SPARSE: usize = 1;
+pub const PCP_DBG_NEQ_TILES: usize = 2;
+pub const PCP_DBG_NEQ_OVERLAP: usize = 3;
+pub const PCP_DBG_SMALL_NODES: usize = 4;
+pub const PCP_DBG_COUNT: usize = 16;
+
 pub enum pcp_ctx {}
 
 extern "C" {
@@ -165,7 +177,17 @@ extern "C" {
                           hip_stream: *mut c_void) -> i32; // OneSolution/AllSolution<Propagation<Brancher<..>>> under StopNode, n_steps nodes
     pub fn pcp_stats_reset(ctx: *mut pcp_ctx, hip_stream: *mut c_void) -> i32;
     pub fn pcp_stats_read(ctx: *mut pcp_ctx, out: *mut pcp_stats, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_debug_counters(ctx: *mut pcp_ctx, out: *mut u64, n: u32, hip_stream: *mut c_void) -> i32; // out[PCP_DBG_*]
     pub fn pcp_last_kernel_ms(ctx: *mut pcp_ctx, ms: *mut f32) -> i32;
     pub fn pcp_last_plan(ctx: *const pcp_ctx, out: *mut pcp_plan) -> i32;
     pub fn pcp_set_option(ctx: *mut pcp_ctx, key: *const c_char, value: i64) -> i32;
+}
+
+// ---- the HIP runtime, as far as pcp-gpu-cstore::resident needs it (hip_runtime_api.h) ---------------------------------------------
+pub const HIP_MEMCPY_HOST_TO_DEVICE: i32 = 1; // hipMemcpyHostToDevice
+pub const HIP_MEMCPY_DEVICE_TO_HOST: i32 = 2; // hipMemcpyDeviceToHost
+extern "C" {
+    pub fn hipMalloc(ptr: *mut *mut c_void, size: usize) -> i32;
+    pub fn hipFree(ptr: *mut c_void) -> i32;
+    pub fn hipMemcpy(dst: *mut c_void, src: *const c_void, size: usize, kind: i32) -> i32; // synchronises the null stream
 }

@@ -283,7 +283,6 @@ class GpuCStore {
     int32_t rc = pcp_ctx_create(hip_device, &ctx_);
     if (rc != PCP_OK) throw std::runtime_error(std::string("pcp_ctx_create: ") + pcp_strerror(rc) + " (there is no CPU path)");
   }
-  ~GpuCStore() { pcp_ctx_destroy(ctx_); }
   GpuCStore(const GpuCStore&) = delete;
   GpuCStore& operator=(const GpuCStore&) = delete;
 
@@ -325,18 +324,26 @@ class GpuCStore {
     std::vector<uint64_t> act((dev_units_.size() + 63) / 64, 0);
     for (size_t k = 0; k < dev_units_.size(); ++k)
       if (get_bit(active_, dev_units_[k])) act[k >> 6] |= 1ull << (k & 63);
-    uint8_t status = 0;
-    int32_t rc = pcp_propagate(ctx_, 1, vs.lbs().data(), vs.ubs().data(), nullptr, act.empty() ? nullptr : act.data(), &status, &last_stats_);
-    if (rc == PCP_ERR_CONTRACT) throw Panic(pcp_last_error(ctx_));
-    if (rc != PCP_OK) throw std::runtime_error(std::string("pcp_propagate: ") + pcp_last_error(ctx_));
+    const uint8_t status = run_node(vs, act);
     if (status != PCP_FALSE)
       for (size_t k = 0; k < dev_units_.size(); ++k) set_bit(active_, dev_units_[k], (act[k >> 6] >> (k & 63)) & 1);
     return (SKleene)status;
   }
   const pcp_stats& last_stats() const { return last_stats_; }
   pcp_ctx* ctx() { return ctx_; }
+  virtual ~GpuCStore() { pcp_ctx_destroy(ctx_); }
 
- private:
+ protected:
+  // One node through the engine: the vstore's bounds and the device units' `active` words in, the fixpoint out (both in place).
+  // This form hands host buffers to pcp_propagate (two PCIe copies of the whole node per call); pcp_host_resident.hpp overrides it
+  // with rows that stay in HBM.
+  virtual uint8_t run_node(VStore& vs, std::vector<uint64_t>& act) {
+    uint8_t status = 0;
+    int32_t rc = pcp_propagate(ctx_, 1, vs.lbs().data(), vs.ubs().data(), nullptr, act.empty() ? nullptr : act.data(), &status, &last_stats_);
+    if (rc == PCP_ERR_CONTRACT) throw Panic(pcp_last_error(ctx_));
+    if (rc != PCP_OK) throw std::runtime_error(std::string("pcp_propagate: ") + pcp_last_error(ctx_));
+    return status;
+  }
   static bool get_bit(const std::vector<uint64_t>& b, size_t i) { return (i >> 6) < b.size() && ((b[i >> 6] >> (i & 63)) & 1); }
   static void set_bit(std::vector<uint64_t>& b, size_t i, bool v) {
     if ((i >> 6) >= b.size()) b.resize((i >> 6) + 1, 0);
@@ -484,12 +491,14 @@ class Cumulative {
 };
 
 // ---- space and search ----------------------------------------------------------------------------------------------
-struct Space {
+template <class CStoreT>
+struct BasicSpace {  // Space<VStore, CStore, R> (search/space.rs:23-43) over any store with GpuCStore's interface
   VStore vstore;
-  GpuCStore cstore;
-  explicit Space(int hip_device = 0) : cstore(hip_device) {}
+  CStoreT cstore;
+  explicit BasicSpace(int hip_device = 0) : cstore(hip_device) {}
   SKleene consistency() { return cstore.consistency(vstore); }  // search/space.rs:41-43
 };
+using Space = BasicSpace<GpuCStore>;
 
 enum class Status { Satisfiable, Unsatisfiable, EndOfSearch };
 struct Statistics { uint64_t num_solution = 0, num_failed_node = 0, num_nodes = 0; };  // search/statistics.rs:19-24
@@ -508,8 +517,8 @@ inline int32_t middle_val(Interval d) { return (int32_t)(((int64_t)d.lower() + d
 
 // OneSolution<Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>>, VectorStack> (search/mod.rs:45-52),
 // optionally under AllSolution and StopNode(node_limit).  on_solution is called with the space at every solution.
-inline Status search(Space& space, bool all_solutions, uint64_t node_limit, Statistics& st,
-                     const std::function<void(const Space&)>& on_solution = nullptr) {
+template <class SpaceT, class OnSolution>
+inline Status search(SpaceT& space, bool all_solutions, uint64_t node_limit, Statistics& st, OnSolution&& on_solution) {
   struct Branch { std::vector<int32_t> lb, ub; GpuCStore::Label clabel; size_t var; int32_t val; bool left; };
   std::vector<Branch> stack;  // VectorStack: LIFO
   bool first = true, found = false;
@@ -531,7 +540,7 @@ inline Status search(Space& space, bool all_solutions, uint64_t node_limit, Stat
     if (k == SKleene::True) {
       ++st.num_solution;
       found = true;
-      if (on_solution) on_solution(space);
+      on_solution(space);
       if (!all_solutions) return Status::Satisfiable;
     } else if (k == SKleene::False) {
       ++st.num_failed_node;
@@ -545,6 +554,10 @@ inline Status search(Space& space, bool all_solutions, uint64_t node_limit, Stat
   }
   if (all_solutions) return Status::EndOfSearch;
   return found ? Status::Satisfiable : Status::Unsatisfiable;
+}
+template <class SpaceT>
+inline Status search(SpaceT& space, bool all_solutions, uint64_t node_limit, Statistics& st) {
+  return search(space, all_solutions, node_limit, st, [](const SpaceT&) {});
 }
 
 }  // namespace pcp_host

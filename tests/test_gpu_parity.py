@@ -833,6 +833,29 @@ def test_cpp_host_mirror_nqueens():
     assert out == {"first": [[0, 8], [1, 9]], "second": [[1, 9], [0, 8]]}
 
 
+def test_cpp_host_resident_store():
+    """ResidentGpuCStore (pcp_amd/host/pcp_host_resident.hpp, the compiled twin of integration/pcp-gpu-cstore/src/resident.rs): the node's rows
+    stay in HBM between consistency() calls (pcp_propagate_device), only the changed index range goes up.  Node for node the same search as the
+    host-buffer store and the oracle — and far fewer bytes over PCIe than whole nodes."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    exe = os.path.join(g.ROOT, "pcp_amd", "host", "examples", "nqueens")
+    for n, args in [(8, []), (10, []), (8, ["all"]), (6, ["all", "10"]), (1, []), (3, [])]:
+        plain = json.loads(subprocess.run([exe, str(n), *args], check=True, capture_output=True, text=True).stdout)
+        res = json.loads(subprocess.run([exe, "resident", str(n), *args], check=True, capture_output=True, text=True).stdout)
+        for k in ("status", "solutions", "nodes", "failed", "first"):
+            assert plain[k] == res[k], (n, args, k, plain, res)
+        assert res["pcie_whole_node"] > 0 and plain["pcie_whole_node"] == 0
+        if res["nodes"] > 4:
+            assert res["pcie_in"] + res["pcie_out"] < res["pcie_whole_node"]
+            assert res["pcie_in"] * 4 < res["pcie_whole_node"] // 2  # the way in is a small part of a whole node per call
+    n = 8
+    ss, _, _, _ = orc.OracleModel(n, M.nqueens_props(n)).search(np.ones(n, np.int32), np.full(n, n, np.int32), all_solutions=True)
+    res = json.loads(subprocess.run([exe, "resident", str(n), "all"], check=True, capture_output=True, text=True).stdout)
+    assert (res["nodes"], res["solutions"], res["failed"]) == (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
+
+
 def test_contract_errors(ctx):
     ctx.set_model(2, M.lower_units([M.XLessY(M.Identity(0), M.Identity(1))], 2))
     with pytest.raises(E.PcpError) as e:
