@@ -7,32 +7,38 @@
 //! (search/branching/branch.rs:51-55).  This store keeps the node's rows (lb, ub, `active` words, status byte) in device memory together
 //! with a host mirror of what they hold:
 //!   in : only the index range whose bounds differ from the mirror goes host-to-device;
-//!   run: `pcp_propagate_device` on the resident rows, in place;
-//!   out: the status byte; the rows only when the node did not fail (a failed node's rows are unspecified — the mirror is dropped), and only
-//!        the variables the fixpoint narrowed go through `MonotonicUpdate::update` (variable/store.rs:151-166), so the trail records them.
+//!   run: `pcp_propagate_device` from the current pair of rows into a second pair (out of place);
+//!   out: the status byte; the rows only when the node did not fail, and then the output pair becomes the current one (a failed node's
+//!        output rows are unspecified: the input rows and the mirror survive it); only the variables the fixpoint narrowed go through
+//!        `MonotonicUpdate::update` (variable/store.rs:151-166), so the trail records them.
 //! Everything else — Alloc, Empty, Clone, Freeze/Snapshot, Collection, DisplayStateful — is `GpuCStore`'s (lib.rs), reached through `inner`.
 use super::*;
 use std::os::raw::c_void;
 
 struct Rows {
-    lb: *mut i32,
-    ub: *mut i32,
-    act: *mut u64,
+    lb: [*mut i32; 2],  // two pairs of rows: [cur] holds the node, the other takes the output
+    ub: [*mut i32; 2],
+    act: [*mut u64; 2],
     status: *mut u8,
+    cur: usize,
     n: usize,
     words_cap: usize,
 }
 impl Rows {
-    fn none() -> Rows { Rows { lb: ptr::null_mut(), ub: ptr::null_mut(), act: ptr::null_mut(), status: ptr::null_mut(), n: usize::MAX, words_cap: 0 } }
+    fn none() -> Rows {
+        Rows { lb: [ptr::null_mut(); 2], ub: [ptr::null_mut(); 2], act: [ptr::null_mut(); 2], status: ptr::null_mut(), cur: 0, n: usize::MAX, words_cap: 0 }
+    }
     fn hip(e: i32) { assert!(e == 0, "HIP error {}", e); }
     fn alloc(n: usize, words: usize) -> Rows {
         let mut r = Rows::none();
         r.n = n;
         r.words_cap = words.max(16);
         unsafe {
-            Self::hip(hipMalloc(&mut r.lb as *mut *mut i32 as *mut *mut c_void, n.max(1) * 4));
-            Self::hip(hipMalloc(&mut r.ub as *mut *mut i32 as *mut *mut c_void, n.max(1) * 4));
-            Self::hip(hipMalloc(&mut r.act as *mut *mut u64 as *mut *mut c_void, r.words_cap * 8));
+            for k in 0..2 {
+                Self::hip(hipMalloc(&mut r.lb[k] as *mut *mut i32 as *mut *mut c_void, n.max(1) * 4));
+                Self::hip(hipMalloc(&mut r.ub[k] as *mut *mut i32 as *mut *mut c_void, n.max(1) * 4));
+                Self::hip(hipMalloc(&mut r.act[k] as *mut *mut u64 as *mut *mut c_void, r.words_cap * 8));
+            }
             Self::hip(hipMalloc(&mut r.status as *mut *mut u8 as *mut *mut c_void, 8));
         }
         r
@@ -41,7 +47,8 @@ impl Rows {
 impl Drop for Rows {
     fn drop(&mut self) {
         unsafe {
-            for p in [self.lb as *mut c_void, self.ub as *mut c_void, self.act as *mut c_void, self.status as *mut c_void] {
+            for p in [self.lb[0] as *mut c_void, self.lb[1] as *mut c_void, self.ub[0] as *mut c_void, self.ub[1] as *mut c_void,
+                      self.act[0] as *mut c_void, self.act[1] as *mut c_void, self.status as *mut c_void] {
                 if !p.is_null() { hipFree(p); }
             }
         }
@@ -51,7 +58,7 @@ impl Drop for Rows {
 pub struct ResidentCStore<VStore> {
     inner: GpuCStore<VStore>,
     rows: Rows,
-    mirror: Option<(Vec<i32>, Vec<i32>)>, // what the device rows hold; None = nothing usable is resident
+    mirror: Option<(Vec<i32>, Vec<i32>, Vec<u64>)>, // what the device's current rows hold (lb, ub, active words); None = nothing resident
     pub bytes_in: u64,
     pub bytes_out: u64,
 }
@@ -89,28 +96,32 @@ where
             self.rows = Rows::alloc(n, words);
             self.mirror = None;
         }
-        // in: the range of variables whose bounds differ from what the device rows hold
+        let (cur, other) = (self.rows.cur, self.rows.cur ^ 1);
+        // in: the range of variables whose bounds differ from what the device's current rows hold; the `active` words when they differ
         let (mut lo, mut hi) = (0usize, n);
-        if let Some((ml, mu)) = &self.mirror {
+        let mut act_differs = words > 0;
+        if let Some((ml, mu, ma)) = &self.mirror {
             while lo < n && lb[lo] == ml[lo] && ub[lo] == mu[lo] { lo += 1; }
             while hi > lo && lb[hi - 1] == ml[hi - 1] && ub[hi - 1] == mu[hi - 1] { hi -= 1; }
+            act_differs = words > 0 && *ma != active;
         }
         unsafe {
             if hi > lo {
-                Rows::hip(hipMemcpy(self.rows.lb.add(lo) as *mut c_void, lb.as_ptr().add(lo) as *const c_void, (hi - lo) * 4, HIP_MEMCPY_HOST_TO_DEVICE));
-                Rows::hip(hipMemcpy(self.rows.ub.add(lo) as *mut c_void, ub.as_ptr().add(lo) as *const c_void, (hi - lo) * 4, HIP_MEMCPY_HOST_TO_DEVICE));
+                Rows::hip(hipMemcpy(self.rows.lb[cur].add(lo) as *mut c_void, lb.as_ptr().add(lo) as *const c_void, (hi - lo) * 4, HIP_MEMCPY_HOST_TO_DEVICE));
+                Rows::hip(hipMemcpy(self.rows.ub[cur].add(lo) as *mut c_void, ub.as_ptr().add(lo) as *const c_void, (hi - lo) * 4, HIP_MEMCPY_HOST_TO_DEVICE));
                 self.bytes_in += 8 * (hi - lo) as u64;
             }
-            if words > 0 {
-                Rows::hip(hipMemcpy(self.rows.act as *mut c_void, active.as_ptr() as *const c_void, words * 8, HIP_MEMCPY_HOST_TO_DEVICE));
+            if act_differs {
+                Rows::hip(hipMemcpy(self.rows.act[cur] as *mut c_void, active.as_ptr() as *const c_void, words * 8, HIP_MEMCPY_HOST_TO_DEVICE));
                 self.bytes_in += 8 * words as u64;
             }
         }
-        // run: in place on the resident rows (null stream)
+        self.mirror = Some((lb.clone(), ub.clone(), active.clone())); // the current rows now hold exactly this node
+        // run: out of place into the other pair of rows (null stream)
         let batch = pcp_device_batch {
-            lb_in: self.rows.lb, ub_in: self.rows.ub, lb_out: self.rows.lb, ub_out: self.rows.ub,
-            active_in: if words > 0 { self.rows.act } else { ptr::null() },
-            active_out: if words > 0 { self.rows.act } else { ptr::null_mut() },
+            lb_in: self.rows.lb[cur], ub_in: self.rows.ub[cur], lb_out: self.rows.lb[other], ub_out: self.rows.ub[other],
+            active_in: if words > 0 { self.rows.act[cur] } else { ptr::null() },
+            active_out: if words > 0 { self.rows.act[other] } else { ptr::null_mut() },
             status: self.rows.status, bits_in: ptr::null(), bits_out: ptr::null_mut(),
         };
         let rc = unsafe { pcp_propagate_device(g.dev.ctx, 1, &batch, ptr::null_mut()) };
@@ -121,18 +132,18 @@ where
         self.bytes_out += 1;
         assert!(status != PCP_STATUS_HULL, "a bound left the hull of the root's domains");
         if status == PCP_FALSE {
-            self.mirror = None; // the rows of a failed node are unspecified
-            return SKleene::False;
+            return SKleene::False; // nothing to fetch; the current rows still hold this node as it came in
         }
         let (mut nl, mut nu) = (vec![0i32; n], vec![0i32; n]);
         unsafe {
-            Rows::hip(hipMemcpy(nl.as_mut_ptr() as *mut c_void, self.rows.lb as *const c_void, n * 4, HIP_MEMCPY_DEVICE_TO_HOST));
-            Rows::hip(hipMemcpy(nu.as_mut_ptr() as *mut c_void, self.rows.ub as *const c_void, n * 4, HIP_MEMCPY_DEVICE_TO_HOST));
+            Rows::hip(hipMemcpy(nl.as_mut_ptr() as *mut c_void, self.rows.lb[other] as *const c_void, n * 4, HIP_MEMCPY_DEVICE_TO_HOST));
+            Rows::hip(hipMemcpy(nu.as_mut_ptr() as *mut c_void, self.rows.ub[other] as *const c_void, n * 4, HIP_MEMCPY_DEVICE_TO_HOST));
             if words > 0 {
-                Rows::hip(hipMemcpy(active.as_mut_ptr() as *mut c_void, self.rows.act as *const c_void, words * 8, HIP_MEMCPY_DEVICE_TO_HOST));
+                Rows::hip(hipMemcpy(active.as_mut_ptr() as *mut c_void, self.rows.act[other] as *const c_void, words * 8, HIP_MEMCPY_DEVICE_TO_HOST));
             }
         }
         self.bytes_out += 8 * n as u64 + 8 * words as u64;
+        self.rows.cur = other; // the output pair is the node now
         // post-conditions of Store::consistency: narrowed domains through MonotonicUpdate::update (the trail records the old values,
         // variable/memory/trail_memory.rs:100-104), the event delta left drained, entailed units out of `active`
         for i in 0..n {
@@ -145,7 +156,7 @@ where
         for (k, &(u, _)) in g.dev_units.iter().enumerate() {
             if (active[k >> 6] >> (k & 63)) & 1 == 0 { g.cpu.deactivate(u); }
         }
-        self.mirror = Some((nl, nu));
+        self.mirror = Some((nl, nu, active));
         match status { PCP_TRUE => SKleene::True, _ => SKleene::Unknown }
     }
 }
@@ -175,7 +186,7 @@ impl<VStore> Freeze for ResidentCStore<VStore> where CStoreFD<VStore>: Freeze {
 pub struct FrozenResidentCStore<VStore> where CStoreFD<VStore>: Freeze {
     inner: FrozenGpuCStore<VStore>,
     rows: Rows,
-    mirror: Option<(Vec<i32>, Vec<i32>)>,
+    mirror: Option<(Vec<i32>, Vec<i32>, Vec<u64>)>,
     bytes_in: u64,
     bytes_out: u64,
 }
