@@ -136,7 +136,24 @@ uint32_t pcp_abi_version(void);
  *                    search/mod.rs:41-43): every domain is a SET, carried as `set_words` u64 words per variable; value v is
  *                    bit (v - lo) where [lo, hi] is the hull declared with pcp_model_set_hull — REQUIRED in set mode, with
  *                    hi - lo < 64 * set_words.  XNeqY removes interior values, XEqY intersects sets, `active`/True follow
- *                    set disjointness.  XEqYMulZ is interval-mode only (PCP_ERR_UNSUPPORTED). */
+ *                    set disjointness.
+ *   WHAT SET MODE REFUSES (PCP_ERR_UNSUPPORTED from pcp_model_push_props / _push_sum / _push_formula), and why:
+ *     - XEqYMulZ over sets: the reference computes y.read() * z.read() with IntervalSet's Mul (x_eq_y_mul_z.rs:68-115), which lives in the
+ *       third-party crate intervallum (not vendored in the reference tree, version pinned only by Cargo.lock); no test of the reference
+ *       exercises it over IntervalSet, so neither the oracle nor this engine has anything to pin a set-valued product against.  The
+ *       Interval<i32> product (bounds only) IS pinned (5 vectors, x_eq_y_mul_z.rs tests) and is what interval mode runs.
+ *     - Sum views over sets (term/sum.rs:56-92): Sum::read adds IntervalSets member by member — the same unpinned third-party algebra
+ *       (IntervalSet + IntervalSet); the reference's only Sum users (cumulative.rs) are tested over Interval stores.
+ *     - the reified layer over sets (Boolean / BooleanNeg / formula units): Disjunction::propagate and is_subsumed are domain-agnostic, but
+ *       every reference test of logic/ runs over VStoreFD (Interval); formula leaves would reuse the set-mode leaf filters (XNeqY / XEqY /
+ *       XLessY / LT3 / GT3 / EQ3 are offered over sets as plain units), the kernel that combines them (pcp_formula.hip) reads 8-byte
+ *       interval cells only.  Refused rather than approximated: bounds-only leaves under a set-valued store would disagree with the
+ *       reference on interior values.
+ *   ENUMERATE (search/branching/enumerate.rs:33-60: children `x = v` and `x != v`) needs no engine support in set mode — both children are
+ *   exact set operations the caller applies to `bits` before propagating (keep bit v / clear bit v), as pcp_branch_device_set does for
+ *   BinarySplit.  In interval mode `x != v` with v inside (lb, ub) is not a domain operation: it stays a per-node propagator, i.e. a unit
+ *   pushed with pcp_model_push_props before the node's call and removed with pcp_model_truncate after it (what the host twins do for
+ *   every branch constraint); batches of nodes with DIFFERENT per-node units are not offered. */
 int32_t pcp_model_reset(pcp_ctx* ctx, uint32_t n_vars, uint32_t set_words);
 /* ≡ Store::alloc, append-only (propagation/store.rs:223-230). */
 int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
