@@ -851,22 +851,10 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         # the reified layer: Cumulative (propagators/cumulative.rs:59-114) = Booleans, equivalences over conjunctions, XEqYMulZ, Sum views —
         # formula units, formfix_kernel (plan.path 3).  Nodes: the start windows narrowed at random (a scheduler's open nodes); everything else is derived by the propagation.
         reset_opts()
-        T4, H4, N4 = 8, 15, 4096
-        vs4, cs4 = M.VStore(), M.CStore()
-        rng4 = np.random.default_rng(0xF4)
-        starts = [vs4.alloc((0, H4)) for _ in range(T4)]
-        durs = [M.Constant(int(d)) for d in rng4.integers(1, 6, size=T4)]
-        ress = [M.Constant(int(r)) for r in rng4.integers(1, 4, size=T4)]
-        cap4 = vs4.alloc((5, 5))
-        M.Cumulative(starts, durs, ress, cap4).join(vs4, cs4)
+        T4, N4 = 8, 4096
+        vs4, cs4, Lf, Uf = W.cumulative_nodes(N4, tasks=T4, horizon=15, seed=0xF4)
         V4f = len(vs4)
         M.push_model(ctx, cs4, V4f)
-        lb0f, ub0f = vs4.bounds()
-        Lf = np.tile(lb0f, (N4, 1)); Uf = np.tile(ub0f, (N4, 1))
-        pick = rng4.random((N4, V4f)) < 0.7
-        pick[:, T4:] = False  # only the start windows: the Booleans and intermediates are what the propagation derives
-        a_ = rng4.integers(lb0f, ub0f + 1, size=(N4, V4f)); b_ = rng4.integers(lb0f, ub0f + 1, size=(N4, V4f))
-        Lf = np.where(pick, np.minimum(a_, b_), Lf).astype(np.int32); Uf = np.where(pick, np.maximum(a_, b_), Uf).astype(np.int32)
         leg = Leg(ctx, torch, "F4-cumulative-reified-layer", torch.from_numpy(Lf).to(dev), torch.from_numpy(Uf).to(dev), None, N4 * node_bytes(V4f, ctx.words, False),
                   f"{N4} nodes with random start windows over Cumulative with {T4} tasks (V={V4f}, {ctx.n_units} units: formula trees of equivalences, XEqYMulZ, sums over Sum views), implicit nodes")
         res = leg.run(launches=5, warmup=1)

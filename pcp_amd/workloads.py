@@ -174,3 +174,25 @@ def golomb_frontier(ctx, nodes: int = 4096, m: int = 10, length: int = 80, max_r
     lb0, ub0 = vs.bounds()
     L, U, A, _ = S.bfs_frontier(ctx, lb0, ub0, nodes, max_rounds=max_rounds)
     return props, L, U, A
+
+
+def cumulative_nodes(n_nodes: int = 4096, tasks: int = 8, horizon: int = 15, seed: int = 0xF4):
+    """The reified layer as a batch (bench.py's F4 leg): Cumulative (propagators/cumulative.rs:59-114) over `tasks` tasks with constant durations
+    and resources — Booleans, equivalences over conjunctions, XEqYMulZ, Sum views: formula units — and `n_nodes` nodes whose START windows are
+    narrowed at random (a scheduler's open nodes); everything else is derived by the propagation.  Returns (vstore, cstore, lb, ub)."""
+    from . import model as M
+    vs, cs = M.VStore(), M.CStore()
+    rng = np.random.default_rng(seed)
+    starts = [vs.alloc((0, horizon)) for _ in range(tasks)]
+    durs = [M.Constant(int(d)) for d in rng.integers(1, 6, size=tasks)]
+    ress = [M.Constant(int(r)) for r in rng.integers(1, 4, size=tasks)]
+    cap = vs.alloc((5, 5))
+    M.Cumulative(starts, durs, ress, cap).join(vs, cs)
+    V = len(vs)
+    lb0, ub0 = vs.bounds()
+    L = np.tile(lb0, (n_nodes, 1)); U = np.tile(ub0, (n_nodes, 1))
+    pick = rng.random((n_nodes, V)) < 0.7
+    pick[:, tasks:] = False  # only the start windows: the Booleans and intermediates are what the propagation derives
+    a_ = rng.integers(lb0, ub0 + 1, size=(n_nodes, V)); b_ = rng.integers(lb0, ub0 + 1, size=(n_nodes, V))
+    L = np.where(pick, np.minimum(a_, b_), L).astype(np.int32); U = np.where(pick, np.maximum(a_, b_), U).astype(np.int32)
+    return vs, cs, L, U

@@ -2,7 +2,7 @@
 batches are built by thousands of one-node launches, which made the PMC passes of round 2 abort):
    python tools/replay_leg.py save deep500 deep3000     # build the batches once, un-profiled, into /tmp on the GPU box
    python tools/replay_leg.py run deep500 [launches]    # load and launch: in place on fresh copies, HIP-event time per launch
-   python tools/replay_leg.py run c3 | c4 | frontier | search | setforest   # these build their input with a handful of launches"""
+   python tools/replay_leg.py run c3 | c4 | f4 | mix | explicit | frontier | search | setforest   # these build their input with a handful of launches"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -64,6 +64,18 @@ else:
     elif nm == "c4":
         p4, L4, U4, A4 = W.golomb_frontier(ctx, 4096)
         lb, ub, act = torch.from_numpy(L4).to(dev), torch.from_numpy(U4).to(dev), torch.from_numpy(A4.view(np.int64)).to(dev)
+    elif nm == "f4":
+        vs4, cs4, Lf, Uf = W.cumulative_nodes(4096)
+        M.push_model(ctx, cs4, len(vs4))
+        lb, ub = torch.from_numpy(Lf).to(dev), torch.from_numpy(Uf).to(dev)
+    elif nm == "mix":
+        nq()
+        lb, ub, _ = W.nqueens_dfs_samples(ctx, n, 16384, 12)
+        nq()
+    elif nm == "explicit":
+        nq()
+        L, U, A = W.nqueens_frontier(ctx, n, 4096, share=0, shares=8, implicit=False)
+        lb, ub, act = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev), torch.from_numpy(A.view(np.int64)).to(dev)
     elif nm == "search":
         from pcp_amd.search_device import DeviceSearch
         nq()
