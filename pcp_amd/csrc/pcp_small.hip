@@ -151,8 +151,12 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
         }
         wave_sync();
         if (on && !single) {
-          const uint32_t t0 = misc[S_TAKEN], t1 = misc[S_TAKEN + 1], t2 = misc[S_TAKEN + 2], t3 = misc[S_TAKEN + 3];
-          auto taken = [&](int val) { const uint32_t b = (uint32_t)(val - lo); const uint32_t w_ = b < 32 ? t0 : b < 64 ? t1 : b < 96 ? t2 : t3; return ((w_ >> (b & 31u)) & 1u) != 0; };
+          // the 128 value bits as two 64-bit registers.  (Made opaque: left to itself the compiler turns "pick one of four loaded words"
+          // into "pick one of four ADDRESSES, then load", through an array of pointers in scratch memory — 72 bytes per lane.)
+          unsigned long long tlo = (unsigned long long)misc[S_TAKEN] | ((unsigned long long)misc[S_TAKEN + 1] << 32);
+          unsigned long long thi = (unsigned long long)misc[S_TAKEN + 2] | ((unsigned long long)misc[S_TAKEN + 3] << 32);
+          asm volatile("" : "+v"(tlo), "+v"(thi));
+          auto taken = [&](int val) { const uint32_t b = (uint32_t)(val - lo); return (((b < 64 ? tlo : thi) >> (b & 63u)) & 1ull) != 0; };
           int nl = d.x, nu = d.y;
           while (nl <= nu && taken(nl)) ++nl;
           while (nu >= nl && taken(nu)) --nu;

@@ -20,5 +20,9 @@ timeout 500 bash tools/profile_leg.sh $T c4 smallfix > gpurun_out/$T/prof_c4.log
 timeout 500 bash tools/profile_leg.sh $T f4 formfix > gpurun_out/$T/prof_f4.log 2>&1
 timeout 500 bash tools/profile_leg.sh $T explicit fixpoint > gpurun_out/$T/prof_explicit.log 2>&1
 timeout 500 bash tools/profile_leg.sh $T setforest "setdfs" > gpurun_out/$T/prof_setforest.log 2>&1
+# leftovers of a profile pass that hit its timeout (rocpd databases are hundreds of MB: gpurun copies back at most 64 MiB)
+find gpurun_out/$T -type d \( -name "trace_*" -o -name "pmc_*" -o -name trace \) -prune -exec rm -rf {} + 2>/dev/null
+find gpurun_out/$T -type f -size +4M -exec rm -f {} + 2>/dev/null
+du -sh gpurun_out/$T
 grep -h "passed\|failed" gpurun_out/$T/gputests.log 2>/dev/null | tail -2
 tail -c 600 gpurun_out/$T/bench.json
