@@ -287,9 +287,15 @@ def forest_search(ctx, lb0, ub0, node_limit: int = 0, n_trees: int = 768, steps_
     if per_tree and not multi:
         ceiling = min(ceiling, per_tree + 64)
     if not capacity:
-        # a known small bound (a per-tree share of a budget, at most 8 GiB for the forest) is allocated at once; otherwise start at 128 rows
+        # a KNOWN bound (one rank: a tree never holds more rows than its share of the node budget) is allocated at once when it is at most
+        # an eighth of the free HBM — growing to it step by step costs three allocations and two copies of a short search; without a
+        # bound (no budget, or several ranks with a global budget and refill) a tree starts at 128 rows and grows on demand
         row_bytes = int(ml.shape[0]) * int(ml.shape[1]) * 8
-        capacity = ceiling if (per_tree and not multi and ceiling * row_bytes <= (8 << 30)) else min(128, ceiling)
+        upfront = 8 << 30
+        if ml.is_cuda:
+            import torch
+            upfront = max(upfront, torch.cuda.mem_get_info(ml.device)[0] // 8)
+        capacity = ceiling if (per_tree and not multi and ceiling * row_bytes <= upfront) else min(128, ceiling)
     r = ctx.dfs_forest(ml, mu, node_limit_per_tree=0 if multi else per_tree, steps_per_launch=steps_per_launch, capacity=capacity, max_capacity=max(ceiling, capacity),
                        node_budget=max(node_limit - st.num_nodes, 1) if multi else budget, dist=dist if multi else None, info=info)
     out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]
