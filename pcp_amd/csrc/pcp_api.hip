@@ -118,6 +118,7 @@ struct pcp_ctx {
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_small_alldiff = 1;    // 1 = pcp_small.hip filters an all-different unit through its value mask, 0 = pair by pair
+  int64_t opt_time_kernels = 1;     // 1 = a pair of HIP events brackets every fixpoint launch (pcp_last_kernel_ms); 0 = nothing but the kernel is enqueued
   int64_t opt_small_path = 1;       // 1 = small stores (<= 128 slots, <= 2048 records) run one wavefront per node (pcp_small.hip)
   int64_t opt_big_dense_k = 2;      // pcp_big.hip: dense iff k * list entries >= records
   int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
@@ -572,13 +573,13 @@ int32_t propagate_set_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     live_in = bt->active_in; live = c->d_live;
   }
   c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, implicit ? 1u : 0u, 1u, n_nodes, 1024u, (uint32_t)lds, cap, 0u};
-  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_setfix(m, n_nodes, c->set_words, c->hull_lo, cap, bt->bits_in, bt->bits_out, bt->lb_out, bt->ub_out, live_in, live, bt->status,
                            c->d_stats, derive, stream));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (c->has_groups && bt->active_out && P)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
-  c->ev_valid = true;
+  c->ev_valid = c->opt_time_kernels != 0;
   return PCP_OK;
 }
 
@@ -643,13 +644,13 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, two_pass ? 1u : 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
   if (two_pass) HIP_TRY(c, hipMemsetAsync(c->d_deep, 0, 4, stream));
-  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   if (two_pass) {
     HIP_TRY(c, launch_neqwave(a, wgrid, wblock, wlds, stream));
     a.node_index = c->d_deep + 4; a.n_index = c->d_deep;
   }
   HIP_TRY(c, launch_neqfix(a, plan, stream));
-  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (bt->active_out && P) {
     // the `active` rows on request: record r is live iff it is not entailed under the final domains
     ModelDev m = a.m;
@@ -664,7 +665,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, bt->active_out, n_nodes, stream));
     }
   }
-  c->ev_valid = !c->dfs_sp;
+  c->ev_valid = !c->dfs_sp && c->opt_time_kernels != 0;
   return PCP_OK;
 }
 
@@ -907,6 +908,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "small_alldiff") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_alldiff must be 0 or 1");
     c->opt_small_alldiff = value;
+  } else if (k == "time_kernels") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "time_kernels must be 0 or 1");
+    c->opt_time_kernels = value;
   } else if (k == "small_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_path must be 0 or 1");
     c->opt_small_path = value;
@@ -996,10 +1000,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       plan.grid = std::min<uint32_t>((n_nodes + fwaves - 1) / fwaves, per_cu * (uint32_t)c->num_cu);
     }
     c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, bt->active_in ? 0u : 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 3u};
-    HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
     HIP_TRY(c, launch_formfix(a, plan, stream));
-    HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
-    c->ev_valid = true;
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+    c->ev_valid = c->opt_time_kernels != 0;
     return PCP_OK;
   }
   // a small store — at most 128 slots, 2048 records, no formulas: one wavefront per node (pcp_small.hip, plan.path 4).  Explicit rows and
@@ -1023,10 +1027,10 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / lds), 2048u / plan.block));
       plan.grid = std::min<uint32_t>((n_nodes + waves - 1) / waves, per_cu * (uint32_t)c->num_cu);
       c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, bt->active_in ? 0u : 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 4u};
-      if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+      if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
       HIP_TRY(c, launch_smallfix(a, plan, stream));
-      if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
-      c->ev_valid = !c->dfs_sp;
+      if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+      c->ev_valid = !c->dfs_sp && c->opt_time_kernels != 0;
       return PCP_OK;
     }
   }
@@ -1108,9 +1112,9 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     LaunchPlan plan;
     plan.grid = n_nodes; plan.block = 1024; plan.lds_bytes = lds_bytes_big(c->n_vars, S);
     c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 2u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, 0u, 2u};
-    HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
     HIP_TRY(c, launch_bigfix(a, plan, stream));
-    HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+    if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
     if (bt->active_out && P) {  // the `active` rows on request: record r is live iff it is not entailed under the final domains
       ModelDev m = a.m;
       m.sums = SumTab{c->d_sum_off, c->d_sum_mem, c->n_vars, c->n_sum_slots, c->d_mul_off};
@@ -1122,7 +1126,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
         HIP_TRY(c, launch_derive_active(m, bt->lb_out, bt->ub_out, bt->active_out, n_nodes, stream));
       }
     }
-    c->ev_valid = true;
+    c->ev_valid = c->opt_time_kernels != 0;
     return PCP_OK;
   }
   // ---- choose the path: B nodes per workgroup (batch) or a team of G workgroups per node ------------------
@@ -1285,7 +1289,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     HIP_TRY(c, hipMemcpyAsync(bt->ub_out, bt->ub_in, (size_t)n_nodes * c->n_vars * 4, hipMemcpyDeviceToDevice, stream));
   }
   c->last_plan = pcp_plan{B, team, Bp ? 1u : 0u, a.word_level, dom10 ? 2u : a.global_dom, a.m.recs8 ? 1u : 0u, implicit ? 1u : 0u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, list_cap_used, 0u};
-  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_fixpoint(a, plan, stream));
   if (Bp && hull_fits16) c->trusted_epoch = a.epoch;  // no retry launch: a tile outside the hull is the caller's contract violation (d_retry[1])
   if (Bp && !hull_fits16) {
@@ -1300,7 +1304,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     plan2.grid = (n_nodes + Bp / 2 - 1) / (Bp / 2);
     HIP_TRY(c, launch_fixpoint(a2, plan2, stream));
   }
-  if (!c->dfs_sp) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (implicit && bt->active_out && P) {
     // the `active` rows on request: record r is live iff it is not entailed under the final domains
     if (c->has_groups) {
@@ -1312,7 +1316,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     }
   } else if (c->has_groups && bt->active_out)
     HIP_TRY(c, launch_contract_units(c->d_unit_first, c->n_units, P, c->d_live, bt->active_out, n_nodes, stream));
-  c->ev_valid = !c->dfs_sp;
+  c->ev_valid = !c->dfs_sp && c->opt_time_kernels != 0;
   return PCP_OK;
 }
 
@@ -1361,10 +1365,10 @@ int32_t pcp_dfs_forest_device_set(pcp_ctx* c, const pcp_forest_state* st, uint32
   a.stop = st->stop; a.first_solution = st->first_solution; a.solution_flag = st->solution_flag; a.stats = c->d_stats;
   if (!n_steps) return PCP_OK;
   c->last_plan = pcp_plan{1u, 1u, 0u, 0u, 0u, 0u, 1u, 1u, st->n_trees, 1024u, (uint32_t)lds, cap, 0u};
-  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_setdfs(a, stream));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
-  c->ev_valid = true;
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  c->ev_valid = c->opt_time_kernels != 0;
   return PCP_OK;
 }
 
@@ -1406,10 +1410,10 @@ static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_tr
   LaunchPlan plan;
   plan.grid = n_trees; plan.block = c->opt_neq_dfs_block ? (uint32_t)c->opt_neq_dfs_block : (n_trees > 1 ? 256u : 512u); plan.lds_bytes = lds;
   c->last_plan = pcp_plan{1u, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, n_trees, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
-  HIP_TRY(c, hipEventRecord(c->ev_start, stream));
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_neqfix(a, plan, stream));
-  HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
-  c->ev_valid = true;
+  if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  c->ev_valid = c->opt_time_kernels != 0;
   return 1;
 }
 
@@ -1549,7 +1553,7 @@ int32_t pcp_last_plan(const pcp_ctx* c, pcp_plan* out) {
 
 int32_t pcp_last_kernel_ms(pcp_ctx* c, float* ms) {
   if (!c || !ms) return PCP_ERR_ARG;
-  if (!c->ev_valid) return fail(c, PCP_ERR_ARG, "no timed launch");
+  if (!c->ev_valid) return fail(c, PCP_ERR_ARG, "no timed launch (option time_kernels = 0, or nothing was launched yet)");
   HIP_TRY(c, hipEventSynchronize(c->ev_stop));
   HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
   return PCP_OK;
