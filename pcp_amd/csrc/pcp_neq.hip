@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         const int mn = min(min(min(l[0], l[1]), min(l[2], l[3])), min(min(u[0], u[1]), min(u[2], u[3])));
         const int mx = max(max(max(l[0], l[1]), max(l[2], l[3])), max(max(u[0], u[1]), max(u[2], u[3])));
         const int dmin = min(min(u[0] - l[0], u[1] - l[1]), min(u[2] - l[2], u[3] - l[3]));
-        Cell* const p0 = dom + rowof(v0) + b;  // (v0 is a multiple of four: the four rows are B cells apart, no padding between them)
+        // (v0 is a multiple of four: the four rows are B cells apart, no padding between them.  With 16-node tiles row(4q) = 68 q: a 24-bit
+        // multiply, full rate — the 32-bit v_mul_lo_u32 the compiler picks for "q * 272 bytes" is quarter rate, sixteen cycles per wavefront)
+        Cell* const p0 = dom + (BT >= 16 ? __umul24(v0 >> 2, 4u * B + 4u) : rowof(v0)) + b;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (PACKED) p0[i * B] = __builtin_amdgcn_perm((uint32_t)u[i], (uint32_t)(-l[i]), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
@@ -448,14 +450,17 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
         int4 L[UF], U[UF];
         uint32_t bq = bs, qq = qs;
+        uint32_t ro = bs * V * 4u;
         if (!gather) {
 #pragma unroll
           for (int j = 0; j < UF; ++j) {
-            const uint32_t off = t0 + j * nth < tasks ? (bq * V + 4u * qq) * 4u : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
+            const uint32_t off = t0 + j * nth < tasks ? ro + 16u * qq : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
             const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
             L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
             U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
-            step(bq, qq);
+            // the row's byte offset moves with the node by additions (a 32-bit multiply per load pair is a quarter-rate instruction)
+            qq += dq; bq += db; ro += db * V * 4u;
+            if (qq >= SQ) { qq -= SQ; ++bq; ro += V * 4u; }
           }
         } else {
 #pragma unroll
