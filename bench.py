@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--node-budget", type=int, default=2_000_000, help="--mode search: nodes of the tree to explore (all ranks together)")
     ap.add_argument("--search-batch", type=int, default=4096)
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
+    ap.add_argument("--c5-timeout", type=float, default=240.0, help="seconds after which the config-5 legs are given up and the headline line is printed without them")
     ap.add_argument("--c5-single", action="store_true", help="run the config-5 legs of --gpus N > 1 on one GPU too (one-rank process group)")
     ap.add_argument("--c5-budget", type=int, default=262144,
                     help="--gpus N > 1: nodes of the short config-5 leg appended to the headline run (worklist engine; the forest leg runs 8x as many); 0 = skip")
@@ -491,16 +492,7 @@ def main():
     steps_all, eval_all, full_all = (float(x) for x in t_cnt.tolist())
 
     status = t_status.cpu().numpy()
-    c5 = {}
-    if args.c5_budget > 0 and (world > 1 or args.c5_single):
-        if not dist.is_initialized():  # --c5-single: the same legs through a one-rank RCCL group (a 1-GPU box can check everything but the transfers)
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29543")
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        if world > 1:  # (one GPU keeps pool[0] for the parity check below)
-            pool.clear()
-            torch.cuda.empty_cache()
-        c5 = c5_legs(args, torch, dist, world, rank, dev, n)
+    out, flat, legs = None, {}, []
     if rank == 0:
         k_med = float(np.median(kernel_ms))  # one event pair around each of the probe launches (a pair costs the queue a few microseconds)
         k_ms = region_ms                     # the roofline's duration: HIP events over the timed region / launches
@@ -607,7 +599,38 @@ def main():
         put_ms("expl_ms", "C2-frontier-explicit-active-rows"); put_k("expl_frac", "C2-frontier-explicit-active-rows", "hbm_frac", 3)
         put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
         put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
-        flat.update(c5)  # --gpus N > 1: the config-5 legs that exercise RCCL
+    # ---- --gpus N > 1: the config-5 legs that exercise RCCL, AFTER the headline record is complete and under a watchdog: if a rank fails or a
+    # collective hangs (this path cannot be run on more than one GPU where it was written), rank 0 still prints the headline line, with
+    # `c5_error` in place of the c5 keys, and every rank leaves.
+    c5 = {}
+    if args.c5_budget > 0 and (world > 1 or args.c5_single):
+        import threading
+
+        def finish(extra):
+            if rank == 0:
+                out["config"] = {**flat, **extra, **out["config"]}
+                emit_json(out)
+            _flush_c_stdio()
+            os._exit(0)
+
+        dog = threading.Timer(args.c5_timeout, lambda: finish({"c5_error": f"no result after {args.c5_timeout:.0f} s (a collective did not return)"}))
+        dog.daemon = True
+        dog.start()
+        try:
+            if not dist.is_initialized():  # --c5-single: the same legs through a one-rank RCCL group (a 1-GPU box can check everything but the transfers)
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29543")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            pool.clear()
+            torch.cuda.empty_cache()
+            c5 = c5_legs(args, torch, dist, world, rank, dev, n)
+        except Exception as e:  # this rank is out of the collectives: it reports (rank 0) and leaves; the others' watchdogs end them
+            dog.cancel()
+            print(f"config-5 legs failed on rank {rank}: {e!r}", file=sys.stderr, flush=True)
+            finish({"c5_error": f"rank {rank}: {type(e).__name__}: {str(e)[:160]}"})
+        dog.cancel()
+    if rank == 0:
+        flat.update(c5)
         out["config"] = {**flat, **out["config"]}
         if legs:
             full = json.dumps({"legs": legs})
