@@ -447,6 +447,51 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
+      if (BT >= 16 && !gather) {
+        // 16-node tiles.  A wavefront's task = FOUR nodes x SIXTEEN consecutive quads (lanes 0-15 node 4g, 16-31 node 4g+1, ...): the loads are
+        // still 256 contiguous bytes per row, and the 64 cells a wavefront writes per store — word 68 q + b, q = 16 consecutive, b = 4 consecutive —
+        // fall on all 32 LDS banks, two lanes each.  (64 consecutive quads of ONE node, the obvious mapping, put word 68 q + b on 8 banks: every
+        // ds_write of the staging loop ran 8-way conflicted — three quarters of the launch's SQ_LDS_BANK_CONFLICT cycles.)
+        const uint32_t QC = (SQ + 15u) >> 4, NG = (nb + 3u) >> 2, wtasks = NG * QC;
+        const uint32_t lane_o = tid_o & 63u, lb4 = lane_o >> 4, lq = lane_o & 15u;
+        const uint32_t wv_s = __builtin_amdgcn_readfirstlane(tid_o >> 6), nwv_s = nth >> 6;
+        const uint32_t dqc = nwv_s % QC, dng = nwv_s / QC;
+        uint32_t ngs = wv_s / QC, qcs = wv_s - ngs * QC;  // (wave-uniform: scalar registers)
+        const uint32_t ro_lane = lb4 * V * 4u + 16u * lq;
+        for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
+          int4 L[UF], U[UF];
+          uint32_t ng = ngs, qc = qcs;
+#pragma unroll
+          for (int j = 0; j < UF; ++j) {
+            const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
+            const bool on = w0 + j * nwv_s < wtasks && q < SQ && b < nb;
+            const uint32_t off = on ? ro_lane + ng * (16u * V) + qc * 256u : 0u;
+            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
+            L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
+            U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
+            qc += dqc; ng += dng;
+            if (qc >= QC) { qc -= QC; ++ng; }
+          }
+          if (!adj_stored) {
+            adj_stored = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+          }
+          ng = ngs; qc = qcs;
+#pragma unroll
+          for (int j = 0; j < UF; ++j) {
+            if (w0 + j * nwv_s >= wtasks) break;  // (uniform)
+            const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
+            if (q < SQ && b < nb) {
+              const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
+              note(put(b, 4 * q, l, u, 4), b);
+            }
+            qc += dqc; ng += dng;
+            if (qc >= QC) { qc -= QC; ++ng; }
+          }
+          ngs = ng; qcs = qc;
+        }
+      } else
       for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
         int4 L[UF], U[UF];
         uint32_t bq = bs, qq = qs;

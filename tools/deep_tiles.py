@@ -17,8 +17,9 @@ for D in (500, 3000):
     N = lb.shape[0]
     status = torch.zeros(N, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    for npb in (16, 8):
+    for npb, blk in ((16, 0), (32, 0), (32, 1024), (8, 512)):
         ctx.set_option("nodes_per_block", npb)
+        ctx.set_option("neq_block", blk)
         ms = []
         for _ in range(4):
             l2, u2 = lb.clone(), ub.clone()
@@ -27,4 +28,4 @@ for D in (500, 3000):
             s = ctx.stats_read(stream)
             ms.append(ctx.last_kernel_ms())
         pl = ctx.last_plan()
-        print(f"dive {D} nodes_per_block {npb}: kernel ms {['%.3f' % m for m in ms]} grid {pl['grid']} lds {pl['lds_bytes']} cap {pl['list_cap']} wl {pl['word_level']} steps/s {s['steps'] / min(ms) * 1e3:.3e}")
+        print(f"dive {D} nodes_per_block {npb} neq_block {blk} block {pl['block']} path {pl['path']}: kernel ms {['%.3f' % m for m in ms]} grid {pl['grid']} lds {pl['lds_bytes']} cap {pl['list_cap']} wl {pl['word_level']} steps/s {s['steps'] / min(ms) * 1e3:.3e}")
