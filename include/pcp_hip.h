@@ -377,7 +377,7 @@ int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
  *   "word_level" 0 = never use the word-group sweep, "solo_cascade" 0 = a wake-up round with one changed variable is an ordinary round
  *   (1, the default: its records are re-run in place and a bound jumps over the values assigned neighbours forbid), "branch_reverse" 1 = pcp_branch_device writes child k of the batch
  *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
- * "time_kernels" 0 = no HIP events around the fixpoint launches: a call enqueues the kernel and nothing else, pcp_last_kernel_ms then has nothing to report (1, the default: two event records per launch, a few microseconds of queue time each), "small_path" 0 = small stores use the generic kernels too (1, the default: path 4; any option that asks for a geometry of the generic kernels — "nodes_per_block", "force_path", "team", "global_dom" — keeps them as well), "big_path" 0 = never use the 10-bit-cell kernel (path 2), "big_round" / "big_dense_k" its wake-up rounds (0 auto, 1 dense, 2 sparse; dense iff k * list entries >= records), "neq_persist" 0 = one workgroup per tile instead of persistent workgroups, "neq_dfs_block" threads per tree of the in-kernel search loop (0 = auto: 512 for one tree, 256 for a forest), "neq_dfs" 0 = pcp_dfs_device launches one step at a time on all-XNeqY models too
+ * "neq_prefetch" 1 = large all-XNeqY batches run the prefetching form of the tile kernel (one workgroup per CU, the next tile's rows requested a tile ahead; 0, the default: measured slower, pcp_neq.hip), "time_kernels" 0 = no HIP events around the fixpoint launches: a call enqueues the kernel and nothing else, pcp_last_kernel_ms then has nothing to report (1, the default: two event records per launch, a few microseconds of queue time each), "small_path" 0 = small stores use the generic kernels too (1, the default: path 4; any option that asks for a geometry of the generic kernels — "nodes_per_block", "force_path", "team", "global_dom" — keeps them as well), "big_path" 0 = never use the 10-bit-cell kernel (path 2), "big_round" / "big_dense_k" its wake-up rounds (0 auto, 1 dense, 2 sparse; dense iff k * list entries >= records), "neq_persist" 0 = one workgroup per tile instead of persistent workgroups, "neq_dfs_block" threads per tree of the in-kernel search loop (0 = auto: 512 for one tree, 256 for a forest), "neq_dfs" 0 = pcp_dfs_device launches one step at a time on all-XNeqY models too
  *   (1, the default: the whole search loop runs in one workgroup, n_steps nodes per launch), "neq_wave" 1 = an all-XNeqY batch of 1024 or more implicit nodes runs two passes on the device — one wavefront per node finishes the nodes with at most "neq_wave_max" (4) assigned variables, tiles take the rest; pcp_plan.compact reports 1 — (0, the default: tiles only; the two-pass launch is bit-exact but measured 4x slower, pcp_neq.hip), "neq_path" 0 = all-XNeqY models use the generic kernels too (1, the default: the assignment-driven kernel when the nodes are implicit), "neq_block" threads
  *   per workgroup of that kernel (0 = auto).
  * Unknown key -> PCP_ERR_ARG. */

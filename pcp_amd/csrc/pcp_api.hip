@@ -109,6 +109,7 @@ struct pcp_ctx {
   int64_t opt_neq_persist = 1;      // 1 = the tile kernel's workgroups are persistent (at most what the chip holds at once; each runs several tiles)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
   int64_t opt_neq_trace = 0;        // profiling only: device pointer of NeqArgs::trace
+  int64_t opt_neq_prefetch = 0;     // 1 = large batches of 16-node tiles run the prefetching form of the all-XNeqY kernel (one workgroup per CU): measured, slower (pcp_neq.hip)
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_wave = 0;         // 1 = batches of >= 1024 implicit nodes of an all-XNeqY model run two passes (one wavefront per shallow node, then tiles for the deep ones), 0 (default: the first pass is 4x slower than the tiles, pcp_neq.hip) = tiles only
   int64_t opt_neq_wave_block = 256;  // threads per block of the wave-per-node pass (64..1024)
@@ -607,7 +608,18 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
   // staging overlaps the other's list walk
   plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
-  if (c->opt_neq_persist) {
+  // many 16-node tiles of 16-bit cells: ONE 512-thread workgroup per CU that requests tile k+1's rows before it computes on tile k
+  // (pcp_neq.hip, PF) instead of two workgroups whose staging and compute overlap only by luck
+  uint32_t lds_wgs = (uint32_t)c->opt_neq_wgs;
+  const bool prefetch = c->opt_neq_prefetch && c->opt_neq_persist && B == 16 && packed && c->have_adjp4 && plan.block == 512 && !c->opt_neq_wave && !c->dfs_sp &&
+                        plan.grid > 2u * (uint32_t)c->num_cu && (V & 3u) == 0;
+  if (prefetch) {
+    lds_wgs = 1;
+    plan.lds_bytes = lds_bytes_neq(S, V, B, packed, 1);
+  }
+  if (prefetch) {
+    plan.grid = std::min<uint32_t>(plan.grid, (uint32_t)c->num_cu);
+  } else if (c->opt_neq_persist) {
     // persistent tiles: no more workgroups than the chip holds at once (LDS and threads per CU); each runs the tiles g, g + grid, ...
     const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / plan.lds_bytes), 2048u / plan.block));
     plan.grid = std::min<uint32_t>(plan.grid, per_cu * (uint32_t)c->num_cu);
@@ -621,7 +633,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u;
   a.violation = c->d_retry + 1; a.dbg = c->d_dbg;
   a.debug = (uint32_t)c->opt_neq_debug; a.trace = reinterpret_cast<unsigned long long*>(c->opt_neq_trace);
-  a.lds_wgs = (uint32_t)c->opt_neq_wgs;
+  a.lds_wgs = lds_wgs; a.prefetch = prefetch ? 1u : 0u;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
@@ -920,6 +932,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_round") {
     if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "big_round must be 0 (auto), 1 (dense rounds only) or 2 (sparse rounds only)");
     c->opt_big_round = value;
+  } else if (k == "neq_prefetch") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_prefetch must be 0 or 1");
+    c->opt_neq_prefetch = value;
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;

@@ -60,7 +60,8 @@ namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
-       N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */ };
+       N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */,
+       N_SC0 = 36, N_SC1 = 37 /* PF: the two alternating sums of the round-end vote (a __syncthreads_count without its fence) */ };
 constexpr uint32_t kMaxRounds = 1u << 22;  // a round that runs narrows something, so a fixpoint has far fewer; the cap only makes a runaway impossible
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
@@ -273,8 +274,17 @@ __device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type*
 // BT = the tile size as a compile-time constant — 16 (the batch default), 1 (the search loop) — or 0: taken from the launch.  With it the
 // cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
 // kernel does not have (it spills scalars into VGPR lanes as it is).
-template <bool PACKED, bool PAY4, bool DFS, int BT>
-__global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
+// PF = one 512-thread workgroup per CU (256 VGPRs per lane instead of 128) that keeps the NEXT tile's rows in flight, in registers, while
+// it computes on the current tile: staging and compute overlap inside a workgroup instead of by luck between two (see the staging code).
+// MEASURED AND NOT USED BY DEFAULT ("neq_prefetch" = 0): bit-exact (tests/test_neq_path.py::test_prefetching_form), 186 VGPRs, no scratch,
+// no vmcnt wait at any barrier — and 66.2 us on the bench frontier where two plain workgroups per CU take 51.4.  Two reasons, both measured:
+// (1) loads return in order on gfx9 (ONE vmcnt counter), so the first payload load of the round-0 walk waits for the sixteen prefetched
+// rows issued before it: the "overlapped" compute starts when the prefetch has landed (66.2 = its staging-only 41.6 + the compute 24.6);
+// (2) eight wavefronts hold 131 KB in flight per CU and a round trip under load is ~10 us: 3.2 TB/s, where the sixteen wavefronts of two
+// workgroups reach 4.4.  What would be needed is a second memory counter (gfx10+ has one for stores only) or a loader wavefront with its
+// own LDS ring, for which 160 KB have no room next to a 64 KB tile and 128 KB of raw rows.
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool PF = false>
+__global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
   if (a.dbg) a.dbg += (size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT;
@@ -294,6 +304,12 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const uint32_t nth = blockDim.x;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = BT ? (uint32_t)BT : a.nodes_per_block;
+  // The workgroup barrier.  __syncthreads() is a fence + s_barrier, and on gfx9 the fence waits for EVERY outstanding memory operation of
+  // the wavefront (one counter for loads and stores): it would drain the prefetched rows at the first barrier of the compute phase.  The
+  // wavefronts of a tile talk through LDS only, so PF waits for its LDS operations alone.
+  auto bar = [&]() {
+    if constexpr (PF) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
+  };
   const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
   const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
   const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
@@ -329,6 +345,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   // (loaded behind the first tile's zeroing barrier, together with its row loads — hipcc drains outstanding loads at a barrier)
   uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
   bool adj_loaded = false, adj_stored = false;
+  int4 PL[8], PU[8];      // PF: the next tile's rows, requested a tile ahead (64 VGPRs that only a workgroup alone on its CU can spare)
+  bool pf_valid = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
@@ -364,9 +382,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     resume = dfs_resume_var != 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
+  if (PF && tid >= (uint32_t)N_SC0 && tid <= (uint32_t)N_SC1) misc[tid] = 0;
   if (tid < nb) misc[N_NID + tid] = (!DFS && a.node_index) ? a.node_index[node0 + tid] : node0 + tid;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
-  __syncthreads();
+  bar();
   PCP_TR(1);
   if (!adj_loaded) {
     adj_loaded = true;
@@ -451,33 +470,30 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         // 16-node tiles.  A wavefront's task = FOUR nodes x SIXTEEN consecutive quads (lanes 0-15 node 4g, 16-31 node 4g+1, ...): the loads are
         // still 256 contiguous bytes per row, and the 64 cells a wavefront writes per store — word 68 q + b, q = 16 consecutive, b = 4 consecutive —
         // fall on all 32 LDS banks, two lanes each.  (64 consecutive quads of ONE node, the obvious mapping, put word 68 q + b on 8 banks: every
-        // ds_write of the staging loop ran 8-way conflicted — three quarters of the launch's SQ_LDS_BANK_CONFLICT cycles.)
-        const uint32_t QC = (SQ + 15u) >> 4, NG = (nb + 3u) >> 2, wtasks = NG * QC;
+        // ds_write of the staging loop ran 8-way conflicted — most of the launch's SQ_LDS_BANK_CONFLICT cycles.)
+        const uint32_t QC = (SQ + 15u) >> 4;
         const uint32_t lane_o = tid_o & 63u, lb4 = lane_o >> 4, lq = lane_o & 15u;
         const uint32_t wv_s = __builtin_amdgcn_readfirstlane(tid_o >> 6), nwv_s = nth >> 6;
         const uint32_t dqc = nwv_s % QC, dng = nwv_s / QC;
-        uint32_t ngs = wv_s / QC, qcs = wv_s - ngs * QC;  // (wave-uniform: scalar registers)
+        const uint32_t ng_first = wv_s / QC, qc_first = wv_s - ng_first * QC;  // (wave-uniform: scalar registers)
         const uint32_t ro_lane = lb4 * V * 4u + 16u * lq;
-        for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
-          int4 L[UF], U[UF];
-          uint32_t ng = ngs, qc = qcs;
+        // UF wave-tasks from (w0; ng, qc) of a tile of tnb nodes behind the descriptors (r_lb, r_ub): the loads / the cells
+        auto loadw = [&](const __amdgpu_buffer_rsrc_t r_lb, const __amdgpu_buffer_rsrc_t r_ub, uint32_t tnb, uint32_t w0, uint32_t ng, uint32_t qc, int4 (&L)[UF], int4 (&U)[UF]) {
+          const uint32_t wt = ((tnb + 3u) >> 2) * QC;
 #pragma unroll
           for (int j = 0; j < UF; ++j) {
             const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
-            const bool on = w0 + j * nwv_s < wtasks && q < SQ && b < nb;
+            const bool on = w0 + j * nwv_s < wt && q < SQ && b < tnb;
             const uint32_t off = on ? ro_lane + ng * (16u * V) + qc * 256u : 0u;
-            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
+            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(r_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(r_ub, (int)off, 0, 0);
             L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
             U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
             qc += dqc; ng += dng;
             if (qc >= QC) { qc -= QC; ++ng; }
           }
-          if (!adj_stored) {
-            adj_stored = true;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
-          }
-          ng = ngs; qc = qcs;
+        };
+        const uint32_t wtasks = ((nb + 3u) >> 2) * QC;
+        auto putw = [&](const int4 (&L)[UF], const int4 (&U)[UF], uint32_t w0, uint32_t& ng, uint32_t& qc) {
 #pragma unroll
           for (int j = 0; j < UF; ++j) {
             if (w0 + j * nwv_s >= wtasks) break;  // (uniform)
@@ -489,7 +505,42 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
             qc += dqc; ng += dng;
             if (qc >= QC) { qc -= QC; ++ng; }
           }
-          ngs = ng; qcs = qc;
+        };
+        auto store_adj = [&]() {
+          if (!adj_stored) {
+            adj_stored = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+          }
+        };
+        uint32_t ngs = ng_first, qcs = qc_first;
+        if constexpr (PF) {
+          // The first UF wave-tasks of this tile (all of them when 4 ceil(V / 64) <= UF x wavefronts: V <= 1024 on 512 threads) were requested
+          // while the LAST tile was being computed on; the rest, if any, is loaded here and now.
+          if (!pf_valid) loadw(rs_lb, rs_ub, nb, wv_s, ngs, qcs, PL, PU);
+          store_adj();
+          putw(PL, PU, wv_s, ngs, qcs);
+          for (uint32_t w0 = wv_s + UF * nwv_s; w0 < wtasks; w0 += UF * nwv_s) {
+            int4 L[UF], U[UF];
+            loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
+            putw(L, U, w0, ngs, qcs);
+          }
+          // ... and the next tile of this workgroup is requested now: its rows travel while this tile's rounds and status scan run
+          const uint32_t tile_n = tile + gridDim.x;
+          pf_valid = tile_n < n_tiles;
+          if (pf_valid) {
+            const uint32_t node0_n = tile_n * B, nb_n = min(B, n_eff - node0_n);
+            const __amdgpu_buffer_rsrc_t rn_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0_n * V), 0, (int)(nb_n * V * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rn_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0_n * V), 0, (int)(nb_n * V * 4u), 0x00020000);
+            loadw(rn_lb, rn_ub, nb_n, wv_s, ng_first, qc_first, PL, PU);
+          }
+        } else {
+          for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
+            int4 L[UF], U[UF];
+            loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
+            store_adj();
+            putw(L, U, w0, ngs, qcs);
+          }
         }
       } else
       for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
@@ -565,7 +616,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
   }
   PCP_TR(2);
-  __syncthreads();
+  bar();
   PCP_TR(3);
   if (ptime) pt1 = __builtin_amdgcn_s_memtime();
   if (misc[N_OOB] && tid == 0) atomicMax(a.violation, 1u);  // sticky: reported by pcp_stats_read
@@ -577,7 +628,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const bool one_piece = a.m.max_deg <= 64u * U4;
   bool cascade = false;  // the round before narrowed in many threads at once (workgroup-uniform)
   for (uint32_t round = 0;; ++round) {
-    if (round >= kMaxRounds) { if (tid == 0) { atomicOr(&misc[N_OOB], nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)); atomicMax(a.violation, 1u); } __syncthreads(); break; }  // (refused, not hung)
+    if (round >= kMaxRounds) { if (tid == 0) { atomicOr(&misc[N_OOB], nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)); atomicMax(a.violation, 1u); } bar(); break; }  // (refused, not hung)
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
     const uint32_t narrow_before = ctr.narrow;
@@ -597,7 +648,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
 #endif
       for (uint32_t b = wv; b < nb; b += nwv)
         if (!((inert >> b) & 1u)) resweep_marks<PACKED>(dom, chg + (size_t)b * Wv, adjo, a.seed_always, V, Wv, B, sh, b, lane);
-      __syncthreads();
+      bar();
     }
 #endif
     // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
@@ -667,7 +718,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       if (rm && lane == 0) atomicOr(&misc[m_rmask], rm);
     }
     if (round == 0) PCP_TR(4);
-    __syncthreads();
+    bar();
     if (round == 0) PCP_TR(5);
     if (ptime && round == 0) pta = __builtin_amdgcn_s_memtime();
     const uint32_t total = min(misc[m_count], kListCap);
@@ -876,7 +927,16 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     // (the count of narrowing threads also says whether this round was a cascade: only then is the next round's cover priced)
     if (ptime && round == 0) ptb = __builtin_amdgcn_s_memtime();
     if (round == 0) PCP_TR(7);
-    const uint32_t n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
+    uint32_t n_narrowing;
+    if constexpr (PF) {
+      const uint32_t mine = (uint32_t)__popcll(__ballot(ctr.narrow != narrow_before)), slot = (round & 1u) ? N_SC1 : N_SC0;
+      if (lane == 0 && mine) atomicAdd(&misc[slot], mine);
+      bar();
+      n_narrowing = misc[slot];
+      if (tid == 0) misc[(round & 1u) ? N_SC0 : N_SC1] = 0;  // (last read a round ago, next added to behind the next round's list barrier)
+    } else {
+      n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
+    }
     if (round == 0) PCP_TR(8);
     if (ptime && round == 0) ptc = __builtin_amdgcn_s_memtime();
     const bool narrowed = n_narrowing != 0;
@@ -909,7 +969,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
           }
         }
       }
-      __syncthreads();
+      bar();
     }
   }
 
@@ -968,7 +1028,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   PCP_TR(10);
-  __syncthreads();
+  bar();
   PCP_TR(11);
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
   {
@@ -1019,7 +1079,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
   }
   PCP_TR(12);
-  __syncthreads();
+  bar();
   PCP_TR(13);
   if (tid < nb) {
     const bool failed = (misc[N_FAIL] >> tid) & 1u, refused = (misc[N_OOB] >> tid) & 1u;
@@ -1074,7 +1134,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     PCP_TR(0);
   } else {
     // ---- the search step on the node just propagated (what dfs_step_kernel does for the generic kernels) ---------------------
-    __syncthreads();
+    bar();
     const bool failed = (misc[N_FAIL] & 1u) != 0, refused = (misc[N_OOB] & 1u) != 0, open = (misc[N_UNK] & 1u) != 0;
     dfs_resume_var = 0xFFFFFFFFu;
     uint32_t new_sp = dfs_sp - 1;
@@ -1106,10 +1166,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
       unsigned long long* best = reinterpret_cast<unsigned long long*>(list);  // (the round list is idle here)
       if (lane == 0) best[wv] = key;
-      __syncthreads();
+      bar();
       key = best[0];
       for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
-      __syncthreads();
+      bar();
       if (key == ~0ull) {
         c_err = 3; dfs_stop = 1;  // Unknown, yet nothing to branch on: the reference panics (first_smallest_var.rs:36)
         new_sp = dfs_sp;
@@ -1127,7 +1187,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         if (tid == 0) {
           if constexpr (PACKED) dom[rowof(var)] = pack16(d.x, min(d.y, val)); else dom[rowof(var)] = make_int2(-d.x, min(d.y, val));
         }
-        __syncthreads();
+        bar();
         int32_t* l0 = a.lb_out + V;
         int32_t* u0 = a.ub_out + V;
         for (uint32_t v = tid; v < V; v += nth) { const int2 c = cell_bounds<PACKED>(dom[rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
@@ -1137,7 +1197,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     }
     if (a.dfs.node_limit && c_nodes >= a.dfs.node_limit) dfs_stop = 1;  // StopNode (stop_node.rs:57-62)
     dfs_sp = new_sp;
-    __syncthreads();
+    bar();
   }
   }  // the DFS loop / the tile loop
   if (tid == 0) {
@@ -1163,17 +1223,20 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4, bool DFS, int BT>
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool PF = false>
 static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT, PF>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 template <bool DFS, int BT>
 static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if constexpr (!DFS && BT == 16) {  // the prefetching form: one instantiation, the headline's (16-bit cells, 4-byte payloads); the plan asks for it
+    if (a.prefetch && a.adjp4 && a.packed && p.block == 512 && !a.node_index) return launch_neq_k<true, true, false, 16, true>(a, p, stream);
+  }
   if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS, BT>(a, p, stream) : launch_neq_k<false, true, DFS, BT>(a, p, stream);
   return a.packed ? launch_neq_k<true, false, DFS, BT>(a, p, stream) : launch_neq_k<false, false, DFS, BT>(a, p, stream);
 }

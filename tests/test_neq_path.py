@@ -204,3 +204,39 @@ def test_two_pass_launches(ctx, seed, hull):
     finally:
         ctx.set_option("neq_wave", 0)
         ctx.set_option("neq_wave_max", 4)
+
+
+def test_prefetching_form(ctx):
+    """Option neq_prefetch = 1: one 512-thread workgroup per CU that requests tile k+1's rows before it computes on tile k (pcp_neq.hip, PF;
+    measured slower and off by default).  Same results as the default launch on a batch large enough to take it (more than two tiles per CU),
+    with assigned variables, failing nodes and a ragged last tile."""
+    n = 64
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    ctx.set_hull(1, n)
+    rng = np.random.default_rng(77)
+    N = 16 * 2 * 300 + 5
+    L = np.ones((N, n), np.int32); U = np.full((N, n), n, np.int32)
+    for i in range(N):
+        k = int(rng.integers(0, 6))
+        vs = rng.choice(n, size=k, replace=False)
+        vals = rng.integers(1, n + 1, size=k)
+        L[i, vs] = vals; U[i, vs] = vals
+        w = rng.choice(n, size=4, replace=False)
+        L[i, w] = np.maximum(L[i, w], rng.integers(1, n // 2, size=4)); U[i, w] = np.maximum(L[i, w], U[i, w] - rng.integers(0, n // 2, size=4))
+    for k, v in {"small_path": 0, "neq_prefetch": 0}.items():
+        ctx.set_option(k, v)
+    try:
+        ref = ctx.propagate_implicit(L, U)
+        plan0 = ctx.last_plan()
+        ctx.set_option("neq_prefetch", 1)
+        got = ctx.propagate_implicit(L, U)
+        plan1 = ctx.last_plan()
+    finally:
+        ctx.set_option("neq_prefetch", 0); ctx.set_option("small_path", 1)
+    assert plan0["path"] == 1 and plan1["path"] == 1
+    assert plan1["grid"] < plan0["grid"] and plan1["block"] == 512 and plan1["lds_bytes"] >= plan0["lds_bytes"], (plan0, plan1)  # one workgroup per CU
+    assert np.array_equal(ref[3], got[3])
+    ok = ref[3] != 0
+    assert np.array_equal(ref[0][ok], got[0][ok]) and np.array_equal(ref[1][ok], got[1][ok])
+    assert (ref[3] == 0).any() and (ref[3] == 2).any()
