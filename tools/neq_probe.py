@@ -24,7 +24,7 @@ for d in (500, 3000):
         batches[f"deep{d}"] = (lb, ub)
 
 def timeit(lb, ub, opts, reps=5):
-    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, "neq_wgs": 2, "neq_persist": 1, "neq_prefetch": 1, **opts}.items():
+    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, "neq_wgs": 2, "neq_persist": 1, "neq_prefetch": 0, **opts}.items():
         ctx.set_option(k, v)
     N = lb.shape[0]
     st = torch.zeros(N, dtype=torch.uint8, device=dev)
