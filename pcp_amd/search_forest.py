@@ -191,7 +191,7 @@ def run_forest_loop(launch, fs: ForestStacks, stop_on_solution: bool = False, no
     import time
     import torch
     T = int(fs.sp.shape[0])
-    launches = steals = 0
+    launches = steals = fatal = 0
     xinfo = {"moved_rows": 0, "moved_bytes": 0}
     exchange_s = 0.0
     multi = dist is not None and dist.get_world_size() > 1
@@ -202,7 +202,7 @@ def run_forest_loop(launch, fs: ForestStacks, stop_on_solution: bool = False, no
         live = (sp > 0) & (stop == 0)
         err = counters[:, 3]
         full = err == 1  # stack full: the node stayed on top of its stack, uncounted (pcp_hip.h, pcp_dfs_device)
-        summary = torch.stack([live.sum(), counters[:, 0].sum(), counters[:, 1].sum(), full.sum(), ((err != 0) & ~full).sum()]).to(torch.int64)
+        summary = torch.stack([live.sum(), counters[:, 0].sum(), counters[:, 1].sum(), full.sum(), ((err != 0) & ~full).sum() + fatal]).to(torch.int64)
         mine = summary.cpu().tolist()  # (the launch's only synchronisation on one GPU)
         vals = mine
         if multi:
@@ -213,11 +213,14 @@ def run_forest_loop(launch, fs: ForestStacks, stop_on_solution: bool = False, no
         if vals[4] or (stop_on_solution and vals[2]) or (node_budget and vals[1] >= node_budget):
             break
         if mine[3]:
-            if not fs.grow():
+            if fs.grow():
+                idx = torch.nonzero(full).flatten()
+                fs.counters[idx, 3] = 0
+                fs.stop[idx] = 0
+            elif not multi:
                 break  # the ceiling is reached: the trees keep error 1 (the caller reports it)
-            idx = torch.nonzero(full).flatten()
-            fs.counters[idx, 3] = 0
-            fs.stop[idx] = 0
+            else:
+                fatal = 1  # (several ranks leave the loop TOGETHER: the flag travels with the next launch's summary)
         elif vals[0] == 0 and vals[3] == 0:
             break
         if not rebalance:

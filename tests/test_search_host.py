@@ -379,7 +379,7 @@ def test_forest_loop_grows_stacks_and_refills_locally():
     assert int(g.fs.counters[0, 3]) == 1
 
 
-def _forest_worker(rank, world, port, n, q):
+def _forest_worker(rank, world, port, n, q, max_capacity=64):
     import torch.distributed as dist
     from pcp_amd.search_forest import run_forest_loop
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -388,7 +388,7 @@ def _forest_worker(rank, world, port, n, q):
     try:
         # ALL the work starts on rank 0 (one root); the other ranks' trees are empty: they can only work on what the refill brings
         roots = [(np.ones(n, np.int32), np.full(n, n, np.int32))] if rank == 0 else []
-        f = _StandInForest(n, 3, 4, roots, max_capacity=64)
+        f = _StandInForest(n, 3, min(4, max_capacity), roots, max_capacity=max_capacity)
         r = run_forest_loop(lambda: f.launch(2), f.fs, dist=dist)
         q.put((rank, f.visited, f.solutions, int(f.fs.counters[:, 0].sum()), r["moved_rows"], r["launches"], int(f.fs.counters[:, 3].max())))
     finally:
@@ -418,6 +418,24 @@ def test_four_rank_forest_refill_gloo():
     assert sum(r[3] for r in res) == 779 and all(r[3] > 0 for r in res)
     assert res[0][4] > 0 and sum(r[4] for r in res) >= 3  # rank 0 gave rows away; at least one per starved rank
     assert len({r[5] for r in res}) == 1 and all(r[6] == 0 for r in res)
+
+
+def test_two_rank_forest_ceiling_ends_every_rank_gloo():
+    """A stack ceiling that is too low on the rank that holds the work: that rank cannot grow, and BOTH ranks leave the lockstep loop in the
+    same iteration (the flag travels with the all-reduced summary) — no rank is left waiting in a collective; the error is reported."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_forest_worker, args=(r, 2, port, 7, q, 2)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({r[5] for r in res}) == 1          # the same number of launches on both ranks
+    assert max(r[6] for r in res) == 1            # error 1 (stack full) is reported by the rank that hit the ceiling
 
 
 def test_plan_refill():
