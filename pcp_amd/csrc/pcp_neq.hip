@@ -61,11 +61,12 @@ namespace {
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
        N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */,
-       N_SC0 = 36, N_SC1 = 37 /* PF: the two alternating sums of the round-end vote (a __syncthreads_count without its fence) */ };
+       N_R0OVF = 38 /* round 0's direct list overflowed: the marks are scanned instead */, N_SC0 = 36, N_SC1 = 37 /* PF: the two alternating sums of the round-end vote (a __syncthreads_count without its fence) */ };
 constexpr uint32_t kMaxRounds = 1u << 22;  // a round that runs narrows something, so a fixpoint has far fewer; the cap only makes a runaway impossible
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
+constexpr uint32_t kR0Cap = 32;      // assigned variables of a tile that staging lists by itself (round 0's list built in passing); more: the marks are scanned
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
 constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
 constexpr uint32_t kNoWin = 0xFFFFu;
@@ -83,6 +84,7 @@ struct NeqCarve {
   size_t dom, chg, list, adj, win, misc, total;
   uint32_t sh;    // log2 of the rows between two paddings
   uint32_t wcap;  // jump windows that fit
+  size_t vmk;     // 16-node tiles: per slot, the 16-bit mask of the tile's nodes in which staging found it assigned (round 0's list, built in passing); = win
 };
 // cell index of (slot, node 0): rows of B cells, four cells of padding after every 2^sh rows (2^sh rows of packed cells = 256 bytes)
 __host__ __device__ inline uint32_t neq_row(uint32_t slot, uint32_t B, uint32_t sh) { return slot * B + ((slot >> sh) << 2); }
@@ -104,6 +106,7 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   const size_t budget = o <= share ? share : 160 * 1024;
   c.wcap = (uint32_t)std::min<size_t>(kWinCap, o < budget ? (budget - o) / sizeof(Win) : 0);
   c.win = o; o = up(o + (size_t)c.wcap * sizeof(Win));
+  c.vmk = c.win;  // (the masks live in the window area: staging and round 0 use the masks, only later rounds use windows)
   c.total = o;
   return c;
 }
@@ -320,6 +323,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   Cell* const dom = reinterpret_cast<Cell*>(smem + cv.dom);
   uint32_t* const chg = reinterpret_cast<uint32_t*>(smem + cv.chg);
   uint4* const list = reinterpret_cast<uint4*>(smem + cv.list);  // (v | M << 16, list offset, degree, windows w0 | w1 << 16)
+  uint32_t* const vmk = reinterpret_cast<uint32_t*>(smem + cv.vmk);
   Win* const win = reinterpret_cast<Win*>(smem + cv.win);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);  // (the copy of the current tile: see the loop's end)
   const uint32_t n_eff = (!DFS && a.node_index) ? *a.n_index : a.n_nodes;  // (pass 2 of a two-pass launch: the length of the deep list)
@@ -382,7 +386,13 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     resume = dfs_resume_var != 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
-  if (PF && tid >= (uint32_t)N_SC0 && tid <= (uint32_t)N_SC1) misc[tid] = 0;
+  if (tid >= (uint32_t)N_SC0 && tid <= (uint32_t)N_R0OVF) misc[tid] = 0;
+  // Round 0's list — the assigned variables of the tile's nodes, each with the mask of the nodes it is assigned in — is built BY the staging
+  // loop where it finds a singleton (rare branch of put): the mask in vmk, the first node to see a variable appends it.  The ballot scan over
+  // the marks that used to build it was 3 000 of a frontier tile's 32 000 cycles, for one listed variable.
+  const bool r0_direct = !DFS && BT >= 16 && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0 && a.node_index == nullptr && !(a.debug & 16384u) &&
+                         (size_t)wcap * sizeof(Win) >= (((size_t)S + 1) / 2) * 4;  // (the masks borrow the window area)
+  if (r0_direct) for (uint32_t i = tid; i < (S + 1u) / 2u; i += nth) vmk[i] = 0;
   if (tid < nb) misc[N_NID + tid] = (!DFS && a.node_index) ? a.node_index[node0 + tid] : node0 + tid;
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   bar();
@@ -425,6 +435,18 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
           for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
           if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
           if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+          // (only while the tile has few assigned variables — a frontier: deep tiles, where most quads come through here, give up after
+          // kR0Cap variables and pay one LDS read per quad from then on; they are listed by the scan, which is a small part of THEIR time)
+          if (r0_direct && misc[N_R0OVF] == 0u) {
+            for (uint32_t m = nib; m; m &= m - 1u) {
+              const uint32_t v = v0 + (uint32_t)__builtin_ctz(m), hs = 16u * (v & 1u);
+              const uint32_t old = atomicOr(&vmk[v >> 1], (1u << b) << hs);
+              if (((old >> hs) & 0xffffu) == 0u) {  // the first node of the tile with this variable: it goes on the list
+                const uint32_t pos = atomicAdd(&misc[N_COUNT0], 1u);
+                if (pos < kR0Cap) list[pos].x = v; else misc[N_R0OVF] = 1u;
+              }
+            }
+          }
           return (((mn < -lim) | (mx > lim)) ? 2u : 0u) | (dmin < 0 ? 1u : 0u);
         }
         return 0u;
@@ -658,7 +680,24 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     // a word come out of ballots and readlanes alone: the lanes that still hold an unlisted bit are balloted, the first of them names
     // a bit, a second ballot over that bit is the variable's node mask.  (One ballot per bit position of every non-empty word, each
     // behind a dependent LDS read, made this pass 10 000 cycles of a frontier tile's 45 000 for ONE listed variable.)
-    {
+    const bool r0_listed = round == 0 && r0_direct && misc[N_R0OVF] == 0u;  // (workgroup-uniform: written before the staging barrier)
+    if (r0_listed) {
+      // round 0's list is there already (staging): complete its entries — mask without the failed and refused nodes, list offset, degree —
+      // and drop the marks staging set for the same variables (kept until here for the overflow case below)
+      for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
+      if (tid < misc[N_COUNT0]) {
+        const uint32_t v = list[tid].x;
+        const uint32_t M = (vmk[v >> 1] >> (16u * (v & 1u))) & 0xffffu & ~inert;
+        const uint32_t o0 = adjo[v], dg = adjo[v + 1] - o0;
+        list[tid] = make_uint4(v | (M << 16), o0, dg, kNoWin | (kNoWin << 16));
+        if (M) atomicOr(&misc[m_rmask], M);
+      }
+    } else {
+      if (round == 0 && r0_direct) {  // more assigned variables than the list holds: the marks are scanned as in every other round
+        bar();
+        if (tid == 0) misc[N_COUNT0] = 0;
+        bar();
+      }
       uint32_t rm = 0;
       bool list_full = false;
       for (uint32_t w0 = wv; w0 < Wv && !list_full; w0 += 4 * nwv) {
