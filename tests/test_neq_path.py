@@ -240,3 +240,62 @@ def test_prefetching_form(ctx):
     ok = ref[3] != 0
     assert np.array_equal(ref[0][ok], got[0][ok]) and np.array_equal(ref[1][ok], got[1][ok])
     assert (ref[3] == 0).any() and (ref[3] == 2).any()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_round0_list_built_by_staging(ctx, seed):
+    """16-node tiles (pcp_neq.hip, round 0's list built by the staging loop for up to 32 assigned variables per tile, the scan beyond): tiles
+    with 1-3, with exactly 32 and with 33-60 distinct assigned variables, variables assigned in several nodes of a tile (shared masks), Constant
+    neighbours (seed_always), failing nodes and — in a tile of their own — nodes outside the hull (refused: they must not appear in any mask).
+    Against the oracle and the generic kernel; the debug bit that turns the direct list off gives the same results."""
+    n, dom = 96, (0, 40)
+    props = neq_model(seed, n, 700, dom=dom, p_const=0.1, max_off=3)
+    om = orc.OracleModel(n, props)
+    ctx.set_model(n, props)
+    ctx.set_hull(dom[0], dom[1])
+    rng = np.random.default_rng(seed)
+    N = 16 * 6
+    L = np.full((N, n), dom[0], np.int32); U = np.full((N, n), dom[1], np.int32)
+    per_tile = [int(rng.integers(1, 4)), 32, int(rng.integers(33, 61)), int(rng.integers(1, 33)), 5, int(rng.integers(1, 33))]
+    for t, k in enumerate(per_tile):
+        vs = rng.choice(n, size=k, replace=False)              # the tile's assigned variables ...
+        for b in range(16):
+            mine = vs[rng.random(k) < 0.7] if k > 1 else vs     # ... each node has most of them
+            L[16 * t + b, mine] = U[16 * t + b, mine] = rng.integers(dom[0], dom[1] + 1, size=len(mine))
+            w = rng.choice(n, size=6, replace=False)
+            a_ = rng.integers(dom[0], dom[1] + 1, size=6); b_ = rng.integers(dom[0], dom[1] + 1, size=6)
+            free = L[16 * t + b, w] != U[16 * t + b, w]
+            L[16 * t + b, w[free]] = np.minimum(a_, b_)[free]; U[16 * t + b, w[free]] = np.maximum(a_, b_)[free]
+    for k, v in {"nodes_per_block": 16, "neq_debug": 0}.items():
+        ctx.set_option(k, v)
+    try:
+        ref, got, pl = run_both_paths(ctx, om, L, U, f"round-0 list seed={seed}")
+        assert pl["nodes_per_block"] == 16
+        assert (ref[3] == 0).any() and (ref[3] != 0).any()
+        ctx.set_option("neq_debug", 16384)  # the scan builds every round's list
+        ctx.set_option("small_path", 0)
+        alt = ctx.propagate_implicit(L, U)
+        assert_parity(ref[:4], alt[:4], "round-0 list by the scan")
+        # refused nodes (a bound beyond the 16-bit cells) sharing tiles with ordinary ones: left out of every mask, the others unaffected
+        import torch
+        L2, U2 = L[:32].copy(), U[:32].copy()
+        U2[3, 7] = 20000; L2[20, 9] = -20000
+        ctx.set_option("neq_debug", 0); ctx.set_option("neq_path", 1)
+        dev = torch.device("cuda", 0)
+        t_lb, t_ub = torch.from_numpy(L2).to(dev), torch.from_numpy(U2).to(dev)
+        t_st = torch.zeros(32, dtype=torch.uint8, device=dev)
+        ctx.propagate_device(32, t_lb, t_ub, t_lb, t_ub, None, None, t_st)
+        torch.cuda.synchronize()
+        st = t_st.cpu().numpy()
+        assert ctx.last_plan()["path"] == 1
+        assert st[3] == 0xFE and st[20] == 0xFE
+        others = np.ones(32, bool); others[[3, 20]] = False
+        assert np.array_equal(st[others], ref[3][:32][others])
+        ok = others & (ref[3][:32] != 0)
+        assert np.array_equal(t_lb.cpu().numpy()[ok], ref[0][:32][ok]) and np.array_equal(t_ub.cpu().numpy()[ok], ref[1][:32][ok])
+        with pytest.raises(E.PcpError):
+            ctx.stats_read()
+        ctx.stats_read()  # the flag was consumed
+    finally:
+        for k, v in {"nodes_per_block": 0, "neq_debug": 0, "small_path": 1}.items():
+            ctx.set_option(k, v)
