@@ -370,6 +370,17 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   // (in registers they cost the tile loop fourteen VGPRs it does not have)
   unsigned long long* const accl = reinterpret_cast<unsigned long long*>(misc_base + 2 * 48);
   if (!DFS && tid == 0) { for (int i = 0; i < 7; ++i) accl[i] = 0ull; }
+  // A persistent workgroup's per-thread counters (narrowings, pairs tested, full filter runs, wake-ups) are carried over its tiles in
+  // registers and added up ONCE, behind the last tile: the wave sums, the LDS atomics and the barrier they needed were 1 500 cycles of every
+  // tile.  (Not in profiling builds, whose timers read the per-tile words.)
+  constexpr bool DEFER = !DFS && !PCP_NEQ_PROFILE && PAY4;  // (the 8-byte-payload instantiations have no registers to spare: they spilled)
+  uint32_t tot_narrow = 0, tot_ev = 0, tot_full = 0, tot_later = 0;
+  // (a counter nobody touched — narrowings and full filter runs of a frontier tile — costs one ballot; the high halves likewise)
+  auto total = [&](uint32_t x) -> unsigned long long {
+    if (!__ballot(x != 0u)) return 0ull;
+    const unsigned long long lo = wave_sum(x & 0xffffu);
+    return __ballot((x >> 16) != 0u) ? lo + ((unsigned long long)wave_sum(x >> 16) << 16) : lo;
+  };
   for (uint32_t dfs_it = 0;; ++dfs_it) {  // DFS: the search loop's nodes; otherwise this workgroup's tiles
   bool resume = false;
   if constexpr (!DFS) {
@@ -1066,6 +1077,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   }
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
+  uint32_t wb_need = 0;
   PCP_TR(10);
   bar();
   PCP_TR(11);
@@ -1078,7 +1090,8 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     const bool vec_out = (V & 3u) == 0 && (((size_t)a.lb_out | (size_t)a.ub_out) & 15u) == 0;
     // a refused node's outputs are left alone; in place, the rows of an unchanged node already hold the result in HBM: a frontier
     // tile writes nothing and does not even look at its sixteen nodes one by one
-    for (uint32_t need = (in_place ? dirty : all_nodes) & ~refused & all_nodes; need; need &= need - 1u) {
+    wb_need = (in_place ? dirty : all_nodes) & ~refused & all_nodes;  // (workgroup-uniform)
+    for (uint32_t need = wb_need; need; need &= need - 1u) {
       const uint32_t b = (uint32_t)__builtin_ctz(need);
       auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
       int32_t* lbp = a.lb_out + (size_t)misc[N_NID + b] * V;
@@ -1102,13 +1115,9 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   // the counters: wave sums by DPP (VALU only), then one lane adds them to the tile's LDS words.  (The wave reductions that used to
   // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
   // address were tried instead and cost 8 800.)
-  {
-    // (a counter nobody touched — narrowings and full filter runs of a frontier tile — costs one ballot; the high halves likewise)
-    auto total = [&](uint32_t x) -> unsigned long long {
-      if (!__ballot(x != 0u)) return 0ull;
-      const unsigned long long lo = wave_sum(x & 0xffffu);
-      return __ballot((x >> 16) != 0u) ? lo + ((unsigned long long)wave_sum(x >> 16) << 16) : lo;
-    };
+  if constexpr (DEFER) {
+    tot_narrow += ctr.narrow; tot_ev += ctr.ev; tot_full += ctr.full; tot_later += ctr.ev - ev0;
+  } else {
     const unsigned long long s_narrow = total(ctr.narrow), s_ev = total(ctr.ev), s_full = total(ctr.full), s_later = total(ctr.ev - ev0);
     if (lane == 0) {
       if (s_narrow) atomicAdd(&misc[N_NARROW], (uint32_t)s_narrow);
@@ -1118,7 +1127,9 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     }
   }
   PCP_TR(12);
-  bar();
+  // (the write-back may fail a node — an empty cell found on the way out —: the statuses wait for it; a tile that wrote nothing back
+  // has nothing to wait for, its words are final since the barrier behind the status scan)
+  if (!DEFER || wb_need) bar();
   PCP_TR(13);
   if (tid < nb) {
     const bool failed = (misc[N_FAIL] >> tid) & 1u, refused = (misc[N_OOB] >> tid) & 1u;
@@ -1135,6 +1146,10 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
       // the counters are added up in registers and handed over once per launch: six same-address atomics per node are nothing for one
       // tree and serialise a forest of hundreds (pcp_dfs_forest_device)
       acc_steps += s2; acc_narrow += misc[N_NARROW]; acc_ev += sev; acc_full += sfu; acc_waves += nb + misc[N_WAVES]; acc_nodes += nb; acc_failed += nf;
+    } else if (DEFER) {
+      // (atomics: the wavefronts that are through with their last tile add their carried counters to the same words)
+      atomicAdd(&accl[0], (unsigned long long)active_nodes * a.m.n_recs); atomicAdd(&accl[4], (unsigned long long)(nb + misc[N_WAVES]));
+      atomicAdd(&accl[5], (unsigned long long)nb); if (nf) atomicAdd(&accl[6], (unsigned long long)nf);
     } else if (!PCP_NEQ_PROFILE || !(a.debug & (8u | 32u))) {
       accl[0] += s2; accl[1] += misc[N_NARROW]; accl[2] += sev; accl[3] += sfu; accl[4] += nb + misc[N_WAVES]; accl[5] += nb; accl[6] += nf;
     } else {  // (profiling builds of a launch: the counters carry timers, per tile)
@@ -1239,6 +1254,16 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     bar();
   }
   }  // the DFS loop / the tile loop
+  if constexpr (DEFER) {
+    const unsigned long long s_narrow = total(tot_narrow), s_ev = total(tot_ev), s_full = total(tot_full), s_later = total(tot_later);
+    if (lane == 0) {
+      if (s_later) atomicAdd(&accl[0], s_later);
+      if (s_narrow) atomicAdd(&accl[1], s_narrow);
+      if (s_ev) atomicAdd(&accl[2], s_ev);
+      if (s_full) atomicAdd(&accl[3], s_full);
+    }
+    bar();
+  }
   if (tid == 0) {
     if constexpr (!DFS) { acc_steps = accl[0]; acc_narrow = accl[1]; acc_ev = accl[2]; acc_full = accl[3]; acc_waves = accl[4]; acc_nodes = accl[5]; acc_failed = accl[6]; }
     if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
