@@ -327,6 +327,69 @@ def run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode
 _JSON_FD = None
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_local_ranks(args) -> int:
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start N local ranks of this same command, one process per device (RANK = LOCAL_RANK =
+    0..N-1, WORLD_SIZE = N, MASTER_ADDR 127.0.0.1, a free MASTER_PORT), exactly the environment torch.distributed.run would set.  Rank 0
+    inherits stdout (its ONE JSON line is this command's output); the other ranks' stdout goes to stderr.  Fails loudly when fewer than N
+    devices are visible.  Returns the exit code: 0 iff every rank returned 0; a rank that fails takes the others down."""
+    import subprocess
+    n = int(args.gpus)
+    if not args.spawn_dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(f"bench.py --gpus {n}: only {have} device(s) visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?) — not starting", file=sys.stderr, flush=True)
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:]]
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p_ in list(alive):
+            code = p_.poll()
+            if code is None:
+                continue
+            alive.remove(p_)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {procs.index(p_)} exited with {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:  # (exact PIDs this function started)
+                    q.terminate()
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def spawn_dry_run_rank(args) -> None:
+    """One self-spawned rank of --spawn-dry-run: the rendezvous and one all_reduce over gloo on CPU; rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if world != args.gpus or int(os.environ["LOCAL_RANK"]) != rank:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world} RANK={rank} LOCAL_RANK={os.environ['LOCAL_RANK']}")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1, 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        emit_json({"dry_run": True, "n_gpus": world, "ranks": int(t[1].item()), "rank_sum": int(t[0].item()), "master_port": int(os.environ["MASTER_PORT"])})
+    dist.destroy_process_group()
+
+
 def emit_json(obj) -> None:
     """Write the result line to the process's original stdout (see main)."""
     line = (json.dumps(obj) + "\n").encode()
@@ -377,17 +440,26 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0, help="--mode search, forest: nodes per tree and launch (0 = 1024 for intervals, 2048 for sets)")
     ap.add_argument("--domains", choices=["interval", "set"], default="interval",
                     help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
+    ap.add_argument("--spawn-dry-run", action="store_true",
+                    help="(tests) the self-spawned ranks only bring up a gloo group on CPU, all_reduce their ranks and rank 0 prints a small JSON line: checks the launcher without a GPU")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    # `python bench.py --gpus N` by itself (no torchrun: WORLD_SIZE unset) starts its own N ranks, one process per device; under
+    # torch.distributed.run the environment is already there and this process IS a rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_local_ranks(args))
     # The ONE JSON line is the only thing that reaches the real stdout: RCCL prints a version banner on fd 1 when a process group comes
-    # up, so fd 1 is pointed at stderr for the rest of the run and the line is written to the saved descriptor.
+    # up (gloo its connection report), so fd 1 is pointed at stderr for the rest of the run and the line is written to the saved descriptor.
     global _JSON_FD
     sys.stdout.flush()
     _JSON_FD = os.dup(1)
     os.dup2(2, 1)
+    if args.spawn_dry_run:
+        return spawn_dry_run_rank(args)
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -603,6 +675,7 @@ def main():
         put_ms("set_ms", "C2-set-mode-IntervalSet-frontier"); put_k("set_frac", "C2-set-mode-IntervalSet-frontier", "hbm_frac", 3)
         put_ms("expl_ms", "C2-frontier-explicit-active-rows"); put_k("expl_frac", "C2-frontier-explicit-active-rows", "hbm_frac", 3)
         put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
+        put_k("forest_chk", "C5-interval-forest", "parity_checked_nodes"); put_k("setf_chk", "C2-set-mode-device-search", "parity_checked_nodes")
         put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
     # ---- --gpus N > 1: the config-5 legs that exercise RCCL, AFTER the headline record is complete and under a watchdog: if a rank fails or a
     # collective hangs (this path cannot be run on more than one GPU where it was written), rank 0 still prints the headline line, with
@@ -743,8 +816,23 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         fr = forest_search(ctx, lb0, ub0, node_limit=500_000, n_trees=2048, steps_per_launch=256, capacity=capf)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        checked = None
+        if args.cpu_budget > 0:
+            # parity of the engine just timed, at this size and in its launch shape: four of the forest's own roots (the open nodes of the same
+            # expansion), six nodes each, node for node against the oracle's DFS from those roots — one node per launch and six in one launch
+            # (oracle/forest_check.py; raises on any difference)
+            from oracle import oracle as orc
+            from oracle import forest_check as FC
+            from pcp_amd.search_forest import seed_roots_interval
+            rl, ru, _ = seed_roots_interval(ctx, lb0, ub0, 2048)
+            pick = np.linspace(0, rl.shape[0] - 1, 4).astype(np.int64)
+            try:
+                checked = FC.check_interval_forest(ctx, orc.OracleModel(n, props), rl[pick].cpu().numpy(), ru[pick].cpu().numpy(), K=6)
+            except AssertionError as e:
+                raise SystemExit(f"PARITY FAILURE (interval forest leg): {e}")
+            del rl, ru
         legs.append({"name": "C5-interval-forest", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
-                     "trees": fr["trees"], "launches": fr["launches"], "error": fr["error"],
+                     "trees": fr["trees"], "launches": fr["launches"], "error": fr["error"], "parity_checked_nodes": checked,
                      "note": "pcp_dfs_forest_device: first 500 000 nodes, 2048 trees of 256 threads, 256 nodes per tree and launch; the timed region includes the expansion"})
     for dive in (500, 3000):
         if f"deep{dive}" in want:
@@ -828,7 +916,20 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         fs = ctx.stats_read()
+        checked = None
+        if args.cpu_budget > 0:  # as in the interval forest leg: three of this forest's roots, five nodes each, against the oracle's FDSpace DFS
+            from oracle import oracle as orc
+            from oracle import forest_check as FC
+            from pcp_amd.search_forest import seed_roots
+            roots, _ = seed_roots(ctx, lb0, ub0, 1, trees)
+            pick = np.linspace(0, roots.shape[0] - 1, 3).astype(np.int64)
+            try:
+                checked = FC.check_set_forest(ctx, orc.OracleModel(n, props), roots[pick].cpu().numpy().view(np.uint64).reshape(3, n, sw), 1, K=5)
+            except AssertionError as e:
+                raise SystemExit(f"PARITY FAILURE (set forest leg): {e}")
+            del roots
         legs.append({"name": "C2-set-mode-device-search", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
+                     "parity_checked_nodes": checked,
                      "steps_per_s": (fs["steps"] + fs["steps3"]) / dt, "evaluated_per_s": fs["evaluated"] / dt, "last_kernel_us": ctx.last_kernel_ms() * 1e3,
                      "failed_nodes": fr["failed"], "solutions": fr["solutions"], "trees": fr["trees"], "seeded_nodes": fr["seeded_nodes"], "launches": fr["launches"],
                      "error": fr["error"], "trail_entries_max": finfo.get("trail_max"), "levels_max": finfo.get("levels_max"),

@@ -107,6 +107,7 @@ def lib():
         L.orc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
         L.orc_consistency_set.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_search_set.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
+        L.orc_search_set_root.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32] + [C.c_void_p] * 9
         L.orc_set_op.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -221,8 +222,14 @@ class OracleModel:
         _check(lib().orc_consistency_set(self._h, n, _ptr(lb), _ptr(ub), _ptr(bits), sw, int(base), _ptr(active), _ptr(status), C.byref(st), int(check_dup)))
         return lb, ub, bits, active, status, st.as_dict()
 
-    def search_set(self, lb0, ub0, set_words: int, base: int, all_solutions=False, node_limit=0, check_dup=False, max_records=0):
-        """DFS over FDSpace (IntervalSet domains, the reference's default); returns (search_stats, prop_stats, records, first_solution)."""
+    def search_set(self, lb0, ub0, set_words: int, base: int, all_solutions=False, node_limit=0, check_dup=False, max_records=0, root_bits=None):
+        """DFS over FDSpace (IntervalSet domains, the reference's default); returns (search_stats, prop_stats, records, first_solution).
+        root_bits ([n_vars, set_words] uint64): the root's domains as sets instead of the intervals lb0..ub0 (a subtree below an open node
+        of a breadth-first expansion, whose domains have holes)."""
+        if root_bits is not None:
+            root_bits = np.ascontiguousarray(root_bits, dtype=np.uint64).reshape(self.n_vars, int(set_words))
+            lb0 = np.zeros(self.n_vars, np.int32) if lb0 is None else lb0
+            ub0 = np.zeros(self.n_vars, np.int32) if ub0 is None else ub0
         lb0 = np.ascontiguousarray(lb0, dtype=np.int32)
         ub0 = np.ascontiguousarray(ub0, dtype=np.int32)
         V, W, R, sw = self.n_vars, max(self.words, 1), int(max_records), int(set_words)
@@ -235,7 +242,7 @@ class OracleModel:
         nrec = C.c_uint32(0)
         ss, ps = OrcSearchStats(), OrcStats()
         first = np.zeros(V, np.int32)
-        _check(lib().orc_search_set(self._h, _ptr(lb0), _ptr(ub0), sw, int(base), int(all_solutions), int(node_limit), int(check_dup),
+        _check(lib().orc_search_set_root(self._h, _ptr(lb0), _ptr(ub0), _ptr(root_bits), sw, int(base), int(all_solutions), int(node_limit), int(check_dup),
                                     C.byref(ss), C.byref(ps), R, _ptr(rec["bits_in"]), _ptr(rec["bits_out"]), _ptr(rec["lb_out"]),
                                     _ptr(rec["ub_out"]), _ptr(rec["active_in"]), _ptr(rec["active_out"]), _ptr(rec["status"]),
                                     C.byref(nrec), _ptr(first)))

@@ -463,10 +463,12 @@ int orc_consistency_set(void* h, uint32_t n_nodes, int32_t* lb, int32_t* ub, uin
 // DFS over FDSpace (search/mod.rs:41-52): variables allocated as IntervalSet::new(lb0, ub0) (example/src/nqueens.rs:32-35).
 // Records as orc_search, plus the sets: rec_bits_in is the FOLDED input (the branch propagator x <= v / x > v applied to the
 // set), rec_bits_out the fixpoint.
-int orc_search_set(void* h, const int32_t* lb0, const int32_t* ub0, uint32_t set_words, int32_t base, int all_solutions, uint64_t node_limit,
-                   int check_dup, orc_search_stats_c* out, orc_stats_c* pstats, uint32_t max_records, uint64_t* rec_bits_in,
-                   uint64_t* rec_bits_out, int32_t* rec_lb_out, int32_t* rec_ub_out, uint64_t* rec_active_in, uint64_t* rec_active_out,
-                   uint8_t* rec_status, uint32_t* n_recorded, int32_t* first_solution) {
+// root_bits != NULL: the root's domains are these sets ([n_vars][set_words] words) instead of the intervals lb0..ub0 — a subtree of the
+// FDSpace search (an open node of a breadth-first expansion has holes: no interval describes it).  Same loop otherwise.
+int orc_search_set_root(void* h, const int32_t* lb0, const int32_t* ub0, const uint64_t* root_bits, uint32_t set_words, int32_t base, int all_solutions,
+                        uint64_t node_limit, int check_dup, orc_search_stats_c* out, orc_stats_c* pstats, uint32_t max_records, uint64_t* rec_bits_in,
+                        uint64_t* rec_bits_out, int32_t* rec_lb_out, int32_t* rec_ub_out, uint64_t* rec_active_in, uint64_t* rec_active_out,
+                        uint8_t* rec_status, uint32_t* n_recorded, int32_t* first_solution) {
   auto* m = static_cast<Model*>(h);
   return guard([&] {
     using T = fdset::Types;
@@ -474,7 +476,8 @@ int orc_search_set(void* h, const int32_t* lb0, const int32_t* ub0, uint32_t set
     fdset::Space sp;
     sp.cstore.check_dup = check_dup != 0;
     sp.cstore.stats = &st;
-    for (uint32_t v = 0; v < m->n_vars; ++v) sp.vstore.alloc(IntervalSet::from_interval(lb0[v], ub0[v]));
+    for (uint32_t v = 0; v < m->n_vars; ++v)
+      sp.vstore.alloc(root_bits ? set_from_bits(root_bits + (size_t)v * set_words, set_words, base) : IntervalSet::from_interval(lb0[v], ub0[v]));
     for (auto& u : m->units_of<T>()) sp.cstore.alloc(u->bclone());
     const size_t nu = m->units.size(), words = (nu + 63) / 64, V = m->n_vars;
     uint32_t nrec = 0;
@@ -519,6 +522,14 @@ int orc_search_set(void* h, const int32_t* lb0, const int32_t* ub0, uint32_t set
     if (out) *out = orc_search_stats_c{ss.num_solution, ss.num_failed_node, ss.num_prune, ss.num_nodes, ss.end_of_search ? 1u : 0u};
     if (pstats) *pstats = orc_stats_c{st.steps, st.pops, st.narrowings, st.nodes, st.failed_nodes, st.subscriptions};
   });
+}
+
+int orc_search_set(void* h, const int32_t* lb0, const int32_t* ub0, uint32_t set_words, int32_t base, int all_solutions, uint64_t node_limit,
+                   int check_dup, orc_search_stats_c* out, orc_stats_c* pstats, uint32_t max_records, uint64_t* rec_bits_in,
+                   uint64_t* rec_bits_out, int32_t* rec_lb_out, int32_t* rec_ub_out, uint64_t* rec_active_in, uint64_t* rec_active_out,
+                   uint8_t* rec_status, uint32_t* n_recorded, int32_t* first_solution) {
+  return orc_search_set_root(h, lb0, ub0, nullptr, set_words, base, all_solutions, node_limit, check_dup, out, pstats, max_records, rec_bits_in, rec_bits_out,
+                             rec_lb_out, rec_ub_out, rec_active_in, rec_active_out, rec_status, n_recorded, first_solution);
 }
 
 // IntervalSet algebra for the table tests: op 0 difference(a), 1 shrink_left(a), 2 shrink_right(a), 3 intersection with the second

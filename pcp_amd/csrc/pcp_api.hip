@@ -1080,12 +1080,19 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
         const uint32_t x = all[r].xk & kSlotMask, y = all[r].y, kind = all[r].xk >> 28;
         const int64_t d = all[r].d;
         if (kind > PCP_LT || (x >= nv && y >= nv)) { c->big_ok = false; break; }
+        // (the folded constant K is computed in 64 bits and must stay far inside int32: the kernel forms K - lo, K - 1 and K + 1; a model
+        // whose constant and offset add up to more than 2^30 in magnitude goes to the generic kernels instead of being wrapped)
+        constexpr int64_t kFoldMax = (int64_t)1 << 30;
         if (y >= nv) {         // x (kind) K,  K = c + d
           const uint32_t op = kind == PCP_LT ? 0u : kind == PCP_EQ ? 2u : 3u;
-          br[r] = BR{make_uint2(coord(x) | (op << 17) | (3u << 30), (uint32_t)(int32_t)(consts[y - nv] + d)), 3u};
+          const int64_t K = (int64_t)consts[y - nv] + d;
+          if (K < -kFoldMax || K > kFoldMax) { c->big_ok = false; break; }
+          br[r] = BR{make_uint2(coord(x) | (op << 17) | (3u << 30), (uint32_t)(int32_t)K), 3u};
         } else if (x >= nv) {  // c (kind) y + d:  LT  y > c - d  |  EQ  y = c - d  |  NEQ  y != c - d
           const uint32_t op = kind == PCP_LT ? 1u : kind == PCP_EQ ? 2u : 3u;
-          br[r] = BR{make_uint2(coord(y) | (op << 17) | (3u << 30), (uint32_t)(int32_t)(consts[x - nv] - d)), 3u};
+          const int64_t K = (int64_t)consts[x - nv] - d;
+          if (K < -kFoldMax || K > kFoldMax) { c->big_ok = false; break; }
+          br[r] = BR{make_uint2(coord(y) | (op << 17) | (3u << 30), (uint32_t)(int32_t)K), 3u};
         } else {
           if (d < -4095 || d > 4095) { c->big_ok = false; break; }
           br[r] = BR{make_uint2(coord(x) | (((uint32_t)(int32_t)d & 0x1fffu) << 17) | (kind << 30), coord(y)), kind};

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
         grouped |= 1ull << k;
         if (lane < 4) misc[S_TAKEN + lane] = 0;
         wave_sync();
-        s2 += on ? cnt - 1 : 0u;  // (a variable's step here stands for its cnt - 1 pair filters: counted as such, halves added up below)
+        if (lane == 0) s2 += cnt * (cnt - 1u) / 2u;  // the unit's cnt (cnt - 1) / 2 pair filters, what the reference (and small_alldiff = 0) runs and counts for it in one round
         const bool single = on && d.x == d.y;
         if (single) {
           const uint32_t b = (uint32_t)(d.x - lo);

@@ -336,9 +336,15 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
     while True:
         if search.size > 0 and (all_solutions or search.stats.num_solution == 0):
             # a rank's share of what is left of the node budget (the budget is global; it is checked at every exchange)
-            left = max(1, (node_limit - search.stats.num_nodes * world) // world) if node_limit else 0
-            search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0,
-                           node_limit=(search.stats.num_nodes + left) if node_limit else 0)
+            # One rank: the budget IS the search's StopNode limit (its limit node is counted as a node and as nothing else, stop_node.rs:57-62).
+            # Several ranks: the limit is checked on the all-reduced total at every exchange, so there is no single "node that reaches it";
+            # a rank's share only ends its chunk (stop_at) and every node it explored counts with its status.
+            if world == 1:
+                search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0, node_limit=node_limit)
+            else:
+                left = max(1, (node_limit - search.stats.num_nodes * world) // world) if node_limit else 0
+                search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0,
+                               stop_at=(search.stats.num_nodes + left) if node_limit else 0)
         t0 = time.perf_counter()
         moved += max(balance_stacks(search, dist, xinfo), 0)
         st = search.stats

@@ -332,7 +332,8 @@ class Context:
                 "first_solution": sol.cpu().numpy() if cn[1] else None}
 
     def dfs_forest(self, root_lb, root_ub, stop_on_solution: bool = False, node_limit_per_tree: int = 0, steps_per_launch: int = 256, capacity: int = 2048,
-                   max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False, rebalance: bool = True, info: dict | None = None, dist=None, max_capacity: int = 0):
+                   max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False, rebalance: bool = True, info: dict | None = None, dist=None, max_capacity: int = 0,
+                   sp0=None):
         """pcp_dfs_forest_device: the reference's search loop (interval mode, all-XNeqY models) on many subtrees at once, one workgroup per
         tree, each exactly a pcp_dfs_device instance.  root_lb / root_ub: [n_trees, n_vars] int32 (numpy or CUDA tensors): the roots, not yet
         propagated.  Launches of steps_per_launch nodes per tree are repeated until every stack is empty, a tree stopped (solution with
@@ -352,6 +353,8 @@ class Context:
         ub = torch.empty((T, capacity, V), dtype=torch.int32, device=dev)
         lb[:, 0] = rl; ub[:, 0] = ru
         sp = torch.ones(T, dtype=torch.int32, device=dev)
+        if sp0 is not None:  # (trees that start with an empty stack: a rank that only takes part in the collectives until a refill reaches it)
+            sp = torch.tensor(list(sp0), dtype=torch.int32, device=dev)
         stop = torch.zeros(T, dtype=torch.int32, device=dev)
         status = torch.zeros((T, capacity), dtype=torch.uint8, device=dev)
         counters = torch.zeros((T, 5), dtype=torch.int64, device=dev)

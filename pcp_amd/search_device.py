@@ -124,9 +124,12 @@ class DeviceSearch:
         self.stats = DeviceSearchStats()
         ctx.stats_reset(self._stream())
 
-    def advance(self, all_solutions: bool = True, node_limit: int = 0, max_rounds: int = 0, keep_solutions: int = 0, batch: int = 0) -> bool:
+    def advance(self, all_solutions: bool = True, node_limit: int = 0, max_rounds: int = 0, keep_solutions: int = 0, batch: int = 0, stop_at: int = 0) -> bool:
         """Run rounds on the current stack until it is empty, a limit is hit, or (not all_solutions) a solution is
-        found.  Returns True when the search is over (stack empty or solution found)."""
+        found.  Returns True when the search is over (stack empty or solution found).
+        ``node_limit`` is the search's StopNode limit (stop_node.rs:47-62): the node that reaches it is counted as a node and as nothing
+        else.  ``stop_at`` only ends this call after that many nodes in total (a caller's chunk of a larger budget, e.g. one rank's share
+        between two exchanges of parallel_search_device): every node's status counts."""
         torch, ctx, st = self.torch, self.ctx, self.stats
         stream = self._stream()
         batch = min(int(batch) if batch else self.batch, self.batch)
@@ -149,10 +152,11 @@ class DeviceSearch:
             if room < 2:
                 raise RuntimeError(f"open-node stack full ({self.size} of {self.cap}); raise `capacity`")
             n = min(batch, length, room // 2)
-            if node_limit:
-                n = min(n, node_limit - st.num_nodes)
-                if n <= 0:
-                    break
+            for cap_nodes in (node_limit, stop_at):
+                if cap_nodes:
+                    n = min(n, cap_nodes - st.num_nodes)
+            if n <= 0:
+                break
             lo = top - n
             lb, ub = self.lb[lo:top], self.ub[lo:top]
             act = None if self.act is None else self.act[lo:top]
@@ -171,16 +175,21 @@ class DeviceSearch:
             rounds += 1
             st.rounds += 1
             st.num_nodes += n
+            limit_row_true = False
             if node_limit and st.num_nodes >= node_limit:
                 # the node that reaches the limit (the last one in pop order: the lowest row of the round) is counted as a node, never as a
                 # solution or a failure: StopNode hands EndOfSearch to the monitor (stop_node.rs:57-62 under Monitor, stop_node.rs:90-97)
                 s_last = int(status[0].item())
+                limit_row_true = s_last == TRUE
                 n_true -= int(s_last == TRUE)
                 n_false -= int(s_last == FALSE)
             st.num_solution += n_true
             st.num_failed_node += n_false
             if n_true and len(st.solutions) < keep_solutions:
-                rows = torch.nonzero(status == TRUE).flatten()[: keep_solutions - len(st.solutions)]
+                rows = torch.nonzero(status == TRUE).flatten()
+                if limit_row_true:
+                    rows = rows[rows != 0]  # (not counted: not kept either)
+                rows = rows[: keep_solutions - len(st.solutions)]
                 for r in lb[rows].cpu().numpy():
                     st.solutions.append(r)
             # pop the parents; the children, already in left-first order (branch_reverse), become the new top segment

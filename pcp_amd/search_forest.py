@@ -280,10 +280,20 @@ def forest_search(ctx, lb0, ub0, node_limit: int = 0, n_trees: int = 768, steps_
     out = {"seeded_nodes": st.num_nodes if rank == 0 else 0, "trees": int(ml.shape[0]), "launches": 0,
            "nodes": st.num_nodes if rank == 0 else 0, "solutions": st.num_solution if rank == 0 else 0, "failed": st.num_failed_node if rank == 0 else 0, "error": 0}
     budget = share_of_budget(node_limit, st.num_nodes, rank, world) if node_limit else 0
-    if (node_limit and budget == 0) or ml.shape[0] == 0:
+    multi = dist is not None and world > 1
+    sp0 = None
+    if multi:
+        # the loop below is collective (an all_reduce and an all_gather per launch): every rank enters it or none does — decided on what is
+        # left of the GLOBAL budget, the same number on every rank.  A rank without a share, or without a tree, still takes part: it
+        # brings one tree with an empty stack, which the cross-rank refill can hand work to.
+        if (node_limit and node_limit - st.num_nodes <= 0) or rl.shape[0] == 0:  # (the expansion used the budget up / finished the tree)
+            return out
+        if ml.shape[0] == 0:
+            ml, mu = rl[:1].clone(), ru[:1].clone()
+            sp0 = [0]
+    elif (node_limit and budget == 0) or ml.shape[0] == 0:
         return out
     per_tree = -(-budget // ml.shape[0]) if budget else 0
-    multi = dist is not None and world > 1
     # a tree's stack grows by at most one row per node it explores: never more than its share of the budget; it starts at 128 rows
     # (1 MB per tree and bound array at V = 1000) and is doubled when a tree fills it, up to `stack_bytes` for the whole forest
     ceiling = max(64, int(stack_bytes) // (int(ml.shape[0]) * int(ml.shape[1]) * 8))
@@ -300,7 +310,7 @@ def forest_search(ctx, lb0, ub0, node_limit: int = 0, n_trees: int = 768, steps_
             upfront = max(upfront, torch.cuda.mem_get_info(ml.device)[0] // 8)
         capacity = ceiling if (per_tree and not multi and ceiling * row_bytes <= upfront) else min(128, ceiling)
     r = ctx.dfs_forest(ml, mu, node_limit_per_tree=0 if multi else per_tree, steps_per_launch=steps_per_launch, capacity=capacity, max_capacity=max(ceiling, capacity),
-                       node_budget=max(node_limit - st.num_nodes, 1) if multi else budget, dist=dist if multi else None, info=info)
+                       node_budget=max(node_limit - st.num_nodes, 1) if multi else budget, dist=dist if multi else None, info=info, sp0=sp0)
     out["nodes"] += r["nodes"]; out["solutions"] += r["solutions"]; out["failed"] += r["failed"]
     out["error"] = r["error"]; out["launches"] = r["launches"]
     return out

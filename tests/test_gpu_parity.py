@@ -517,6 +517,32 @@ def test_all_different_units_on_the_small_kernel(ctx):
             assert (ref[3] == 1).any()  # (every third node is a permutation: the unit, the only one, is entailed — True)
 
 
+def test_all_different_group_counts_the_units_pairs(ctx):
+    """a Distinct unit filtered as a group counts its cnt (cnt - 1) / 2 pair filters per round — what the pairwise path
+    (small_alldiff = 0) and the reference run — not twice that.  Nodes on which nothing narrows take one round either way: equal steps."""
+    V = 12
+    vs, cs = M.VStore(), M.CStore()
+    xs = [vs.alloc((0, 40)) for _ in range(V)]
+    cs.alloc(M.Distinct(xs))
+    props = cs.lower(V)
+    lb0, ub0 = vs.bounds()
+    N = 64
+    L = np.tile(lb0, (N, 1)).astype(np.int32); U = np.tile(ub0, (N, 1)).astype(np.int32)
+    L[1::2, 0] = U[1::2, 0] = 20  # an interior value: still nothing to narrow (a value is removed only at a bound, x_neq_y.rs:82-93)
+    ctx.set_model(V, props)
+    ctx.set_hull(0, 40)
+    ctx.set_option("neq_path", 0)  # (a store of XNeqY alone would take the assignment-driven kernel: this test is about the small kernel's counters)
+    steps = {}
+    for ad in (1, 0):
+        ctx.set_option("small_alldiff", ad)
+        lb, ub, act, st, stats = ctx.propagate_implicit(L, U)
+        assert ctx.last_plan()["path"] == 4 and np.array_equal(lb, L) and np.array_equal(ub, U) and (st == 2).all()
+        steps[ad] = (stats["steps"], stats["evaluated"])
+    ctx.set_option("small_alldiff", 1)
+    ctx.set_option("neq_path", 1)
+    assert steps[1] == steps[0] == (N * V * (V - 1) // 2, N * V * (V - 1) // 2), steps
+
+
 def test_golomb_distinct_sum_network(ctx):
     """BASELINE config 4: EQ3 sum network + ONE Distinct unit (a Conjunction group of 990 XNeqY) + LT chain, V=55;
     the search frontier after 12 BinarySplit levels, propagated in one launch (batch and team paths)."""

@@ -465,3 +465,44 @@ def test_node_limit_on_every_node_of_the_tree(n):
         nxt = om.search(lb0, ub0, all_solutions=True, node_limit=limit + 1)[0]
         kinds.add((nxt["num_solution"] - ss["num_solution"], nxt["num_failed_node"] - ss["num_failed_node"]))
     assert {(1, 0), (0, 1), (0, 0)} <= kinds  # the limit fell on solutions, failures and inner nodes
+
+
+def _budget_worker(rank, world, port, n, limit, q):
+    """parallel_search_device with a node budget over gloo: this rank's own counters and what is left on its stack."""
+    import torch
+    import torch.distributed as dist
+    from oracle_ctx import OracleDeviceCtx
+    from pcp_amd.search_device import DeviceSearch
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = OracleDeviceCtx(n, M.nqueens_props(n))
+        ds = DeviceSearch(ctx, batch=4, capacity=4096, device=torch.device("cpu"), implicit=True)
+        tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, node_limit=limit)
+        q.put((rank, tot, ds.stats.num_nodes, ds.stats.num_solution, ds.stats.num_failed_node, ds.size))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limit", [60, 200, 333])
+def test_two_rank_node_budget_drops_no_status_gloo(limit):
+    """with several ranks a rank's share of the node budget only ends its chunk — it is not the search's StopNode limit,
+    so no explored node loses its status.  Every branching adds one open node and every leaf removes one:
+    open = 1 + inner - leaves, nodes = inner + leaves  =>  solutions + failures = leaves = (nodes + 1 - open) / 2, exactly."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_budget_worker, args=(r, 2, port, 8, limit, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nodes, sols, fails = res[0][1][:3]
+    assert res[0][1] == res[1][1] and nodes >= limit
+    open_left = sum(r[5] for r in res)
+    assert nodes == sum(r[2] for r in res) and sols == sum(r[3] for r in res) and fails == sum(r[4] for r in res)
+    assert 2 * (sols + fails) == nodes + 1 - open_left, (nodes, sols, fails, open_left)
