@@ -99,6 +99,7 @@ class Leg:
         self.n = lb.shape[0]
         self.bytes = compulsory_bytes
         self.status = torch.zeros(self.n, dtype=torch.uint8, device=lb.device)
+        self.dirty = None  # optional pcp_device_batch.dirty_var ([n] int32)
 
     def out_bytes(self, per):
         """Compulsory HBM WRITE bytes per launch: the bounds rows (8 B per variable) of the nodes that changed, once — in place an
@@ -111,13 +112,13 @@ class Leg:
         copies = [(self.lb.clone(), self.ub.clone(), None if self.act is None else self.act.clone()) for _ in range(launches + warmup)]
         for i in range(warmup):
             l, u, a = copies[i]
-            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream)
+            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream, dirty=self.dirty)
         torch.cuda.synchronize()
         ctx.stats_reset(stream)
         ms = []
         for i in range(launches):
             l, u, a = copies[warmup + i]
-            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream)
+            ctx.propagate_device(self.n, l, u, l, u, a, a, self.status, stream, dirty=self.dirty)
             ms.append(ctx.last_kernel_ms())
         st = ctx.stats_read(stream)
         self.last_out = copies[-1][:2]  # the rows the LAST timed launch left behind (parity checks compare these, not a re-run)
@@ -669,6 +670,7 @@ def main():
                 flat[key] = float(f"{by[name][field]:.{digits}g}")
         put_ms("mix_ms", "MIX-nodes-along-the-dfs"); put_k("mix_nps", "MIX-nodes-along-the-dfs", "nodes_per_s"); put_k("mix_sps", "MIX-nodes-along-the-dfs", "evaluated_per_s")
         put_k("mix_frac", "MIX-nodes-along-the-dfs", "hbm_frac", 3)
+        put_ms("mixh_ms", "MIXH-children-with-dirty-var-hints"); put_ms("mixc_ms", "MIXC-children-no-hints"); put_k("mixh_nps", "MIXH-children-with-dirty-var-hints", "nodes_per_s")
         put_ms("d500_ms", "C2-deep-dive-500"); put_ms("d3000_ms", "C2-deep-dive-3000")
         put_ms("c3_ms", "C3-random-binary-csp-50k-vars-500k-props"); put_k("c3_sps", "C3-random-binary-csp-50k-vars-500k-props", "evaluated_per_s")
         put_ms("c4_ms", "C4-golomb-distinct-sum-network"); put_ms("f4_ms", "F4-cumulative-reified-layer")
@@ -803,7 +805,44 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                 raise SystemExit("PARITY FAILURE (mix leg): the timed launch differs from the oracle")
             res["parity_checked_nodes"] = int(len(pick))
         legs.append(res)
-        del leg, lbm, ubm
+        # The same nodes one step further, as a search's batched loop really produces them: every node of the launch above is a propagated
+        # row now; pcp_branch_device_hint makes the children of the Unknown ones and names, for every child, the one variable it was branched
+        # on (pcp_device_batch.dirty_var).  The children are timed with their hints ("mixh": the first round is that variable's lists) and
+        # without ("mixc": every node restarts from all of its assigned queens, what the mix leg above measures for the parents).
+        ph_lb, ph_ub = leg.last_out
+        nm = ph_lb.shape[0]
+        cl = torch.empty((2 * nm, n), dtype=torch.int32, device=dev); cu = torch.empty_like(cl)
+        cd = torch.full((2 * nm,), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(5, dtype=torch.int32, device=dev)
+        ctx.branch_device(nm, ph_lb, ph_ub, None, leg.status, cl, cu, None, cnt, torch.cuda.current_stream().cuda_stream, child_dirty=cd)
+        kc = min(int(cnt[0].item()), args.nodes)
+        if kc >= 1024:
+            cl, cu, cd = cl[:kc].clone(), cu[:kc].clone(), cd[:kc].clone()
+            results = {}
+            for name, hint in (("MIXC-children-no-hints", None), ("MIXH-children-with-dirty-var-hints", cd)):
+                lg = Leg(ctx, torch, name, cl, cu, None, kc * node_bytes(V, words, False),
+                         f"{kc} children of the mix leg's propagated nodes (pcp_branch_device_hint), " + ("with" if hint is not None else "without") + " their dirty-variable hints")
+                lg.dirty = hint
+                results[name] = (lg, lg.run(launches=5, warmup=1))
+            (lc, rc_), (lh, rh) = results["MIXC-children-no-hints"], results["MIXH-children-with-dirty-var-hints"]
+            same = bool(torch.equal(lc.status, lh.status))
+            okm = lc.status != 0
+            same = same and bool(torch.equal(lc.last_out[0][okm], lh.last_out[0][okm])) and bool(torch.equal(lc.last_out[1][okm], lh.last_out[1][okm]))
+            if not same:
+                raise SystemExit("PARITY FAILURE (mixh leg): hinted and unhinted launches differ")
+            rh["identical_to_unhinted_launch"] = True
+            if args.cpu_budget > 0:
+                from oracle import oracle as orc
+                pick = np.linspace(0, kc - 1, 12).astype(np.int64)
+                refm = orc.OracleModel(n, props).consistency(cl[pick].cpu().numpy(), cu[pick].cpu().numpy(), None)
+                g_lb, g_ub, g_st = lh.last_out[0][pick].cpu().numpy(), lh.last_out[1][pick].cpu().numpy(), lh.status[pick].cpu().numpy()
+                ok = np.array_equal(refm[3], g_st) and all(refm[3][i] == 0 or (np.array_equal(refm[0][i], g_lb[i]) and np.array_equal(refm[1][i], g_ub[i])) for i in range(len(pick)))
+                if not ok:
+                    raise SystemExit("PARITY FAILURE (mixh leg): the hinted launch differs from the oracle")
+                rh["parity_checked_nodes"] = int(len(pick))
+            legs.append(rc_); legs.append(rh)
+            del lc, lh, results
+        del leg, lbm, ubm, cl, cu, cd
     if "forest" in want:
         # the search loop itself on the device, interval domains: the root expanded to 2048 open nodes, one in-kernel DFS per node
         reset_opts()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 6
+#define PCP_ABI_VERSION 7
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -219,6 +219,16 @@ typedef struct {
   uint8_t* status;
   const uint64_t* bits_in; /* set mode only: [n_nodes][n_vars][set_words]; lb_in/ub_in are then ignored (may be NULL) */
   uint64_t* bits_out;      /* set mode only; may alias bits_in                                                        */
+  /* ABI v7, optional (NULL = none): [n_nodes] — per node the ONE variable whose domain differs from a fixpoint of this same model, or
+   * PCP_NOVAR (any value >= n_vars) = no promise, the node is propagated from scratch.  The caller PROMISES: take the node's row, give
+   * that variable back the domain it had, and the row is the result of a consistency() over this model (a parent's fixpoint; a
+   * child = the parent with one branch constraint folded in, which is what pcp_branch_device_hint writes).  Legal because a propagator
+   * that is entailed or quiescent at a fixpoint is a no-op until one of ITS variables changes (propagation/store.rs:191-198 wakes exactly
+   * the propagators of changed variables; the reference's prepare() re-schedules everything, store.rs:144-149, and finds the others
+   * no-ops — DESIGN.md 2): the fixpoint, the status and the derived `active` rows are the same with and without the hint, only the
+   * work differs.  Used by the all-XNeqY kernel (interval mode, implicit nodes); every other path ignores it.  A hint that breaks the
+   * promise gives an unspecified (sound but possibly not fully propagated) result. */
+  const uint32_t* dirty_var;
 } pcp_device_batch;
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 
@@ -238,6 +248,11 @@ int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_ba
 int32_t pcp_branch_device(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                           const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
                           uint32_t* counts, void* hip_stream);
+/* ABI v7: the same, and child_dirty [2*n_nodes] (capacity, nullable) receives for every child the variable it was branched on — the
+ * pcp_device_batch.dirty_var entry of that child when its parent was a propagated (fixpoint) row, as it is in every search loop. */
+int32_t pcp_branch_device_hint(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                               const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
+                               uint32_t* child_dirty, uint32_t* counts, void* hip_stream);
 
 /* The same over FDSpace (set mode): FirstSmallestVar compares CARDINALITIES (first_smallest_var.rs:30-39: Domain::size()), MiddleVal
  * is (lower + upper) / 2 of the set's bounds, the children keep the values <= value resp. > value of the variable's set.
@@ -377,9 +392,17 @@ int32_t pcp_last_plan(const pcp_ctx* ctx, pcp_plan* out);
  *   "word_level" 0 = never use the word-group sweep, "solo_cascade" 0 = a wake-up round with one changed variable is an ordinary round
  *   (1, the default: its records are re-run in place and a bound jumps over the values assigned neighbours forbid), "branch_reverse" 1 = pcp_branch_device writes child k of the batch
  *   to row n_children-1-k (a caller appending the rows to a LIFO stack then pops the first node's left child first).
- * "neq_prefetch" 1 = large all-XNeqY batches run the prefetching form of the tile kernel (one workgroup per CU, the next tile's rows requested a tile ahead; 0, the default: measured slower, pcp_neq.hip), "time_kernels" 0 = no HIP events around the fixpoint launches: a call enqueues the kernel and nothing else, pcp_last_kernel_ms then has nothing to report (1, the default: two event records per launch, a few microseconds of queue time each), "small_path" 0 = small stores use the generic kernels too (1, the default: path 4; any option that asks for a geometry of the generic kernels — "nodes_per_block", "force_path", "team", "global_dom" — keeps them as well), "big_path" 0 = never use the 10-bit-cell kernel (path 2), "big_round" / "big_dense_k" its wake-up rounds (0 auto, 1 dense, 2 sparse; dense iff k * list entries >= records), "neq_persist" 0 = one workgroup per tile instead of persistent workgroups, "neq_dfs_block" threads per tree of the in-kernel search loop (0 = auto: 512 for one tree, 256 for a forest), "neq_dfs" 0 = pcp_dfs_device launches one step at a time on all-XNeqY models too
- *   (1, the default: the whole search loop runs in one workgroup, n_steps nodes per launch), "neq_wave" 1 = an all-XNeqY batch of 1024 or more implicit nodes runs two passes on the device — one wavefront per node finishes the nodes with at most "neq_wave_max" (4) assigned variables, tiles take the rest; pcp_plan.compact reports 1 — (0, the default: tiles only; the two-pass launch is bit-exact but measured 4x slower, pcp_neq.hip), "neq_path" 0 = all-XNeqY models use the generic kernels too (1, the default: the assignment-driven kernel when the nodes are implicit), "neq_block" threads
- *   per workgroup of that kernel (0 = auto).
+ * "time_kernels" 0 = no HIP events around the fixpoint launches: a call enqueues the kernel and nothing else, pcp_last_kernel_ms then has
+ *   nothing to report (1, the default: two event records per launch, a few microseconds of queue time each), "small_path" 0 = small stores
+ *   use the generic kernels too (1, the default: path 4; any option that asks for a geometry of the generic kernels — "nodes_per_block",
+ *   "force_path", "team", "global_dom" — keeps them as well), "big_path" 0 = never use the 10-bit-cell kernel (path 2), "big_round" /
+ *   "big_dense_k" its wake-up rounds (0 auto, 1 dense, 2 sparse; dense iff k * list entries >= records), "neq_persist" 0 = one workgroup
+ *   per tile instead of persistent workgroups, "neq_dfs_block" threads per tree of the in-kernel search loop (0 = auto: 512 for one tree,
+ *   256 for a forest), "neq_dfs" 0 = pcp_dfs_device launches one step at a time on all-XNeqY models too (1, the default: the whole search
+ *   loop runs in one workgroup, n_steps nodes per launch), "neq_path" 0 = all-XNeqY models use the generic kernels too (1, the default: the
+ *   assignment-driven kernel when the nodes are implicit), "neq_block" threads per workgroup of that kernel (0 = auto).
+ *   (Rounds 3-4 had "neq_wave" / "neq_prefetch": two measured-and-rejected launch forms of the all-XNeqY kernel; their code left the
+ *   library in round 5 — tools/micro/neq_rejected_r4.patch)
  * Unknown key -> PCP_ERR_ARG. */
 int32_t pcp_set_option(pcp_ctx* ctx, const char* key, int64_t value);
 

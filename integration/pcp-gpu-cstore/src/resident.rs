@@ -122,7 +122,7 @@ where
             lb_in: self.rows.lb[cur], ub_in: self.rows.ub[cur], lb_out: self.rows.lb[other], ub_out: self.rows.ub[other],
             active_in: if words > 0 { self.rows.act[cur] } else { ptr::null() },
             active_out: if words > 0 { self.rows.act[other] } else { ptr::null_mut() },
-            status: self.rows.status, bits_in: ptr::null(), bits_out: ptr::null_mut(),
+            status: self.rows.status, bits_in: ptr::null(), bits_out: ptr::null_mut(), dirty_var: ptr::null(),
         };
         let rc = unsafe { pcp_propagate_device(g.dev.ctx, 1, &batch, ptr::null_mut()) };
         g.check(rc);

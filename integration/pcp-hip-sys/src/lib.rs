@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PCP_ABI_VERSION: u32 = 6;
+pub const PCP_ABI_VERSION: u32 = 7;
 pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
 pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
 pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
@@ -69,6 +69,9 @@ pub struct pcp_device_batch {
     pub status: *mut u8,
     pub bits_in: *const u64, // set mode only
     pub bits_out: *mut u64,
+    /// ABI v7, nullable: [n_nodes] the ONE variable in which node i differs from a fixpoint of this model (a child of a propagated node:
+    /// `pcp_branch_device_hint` writes it), or any value >= n_vars = no promise.  Same results, less work (include/pcp_hip.h).
+    pub dirty_var: *const u32,
 }
 
 /// One node of a formula unit (logic/conjunction.rs, logic/disjunction.rs): type 0 leaf (first = index into the leaves), 1 Conjunction,
@@ -164,6 +167,9 @@ extern "C" {
     pub fn pcp_branch_device(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
                              child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, counts: *mut u32,
                              hip_stream: *mut c_void) -> i32; // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter
+    pub fn pcp_branch_device_hint(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
+                                  child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, child_dirty: *mut u32, counts: *mut u32,
+                                  hip_stream: *mut c_void) -> i32; // the same, and every child's pcp_device_batch.dirty_var entry
     pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
                                  status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
                                  hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains

@@ -77,7 +77,6 @@ struct pcp_ctx {
   uint32_t trusted_epoch = 0;   // epoch of the last packed launch without a retry launch (hull declared)
   uint64_t* d_live = nullptr; size_t cap_live = 0;       // working live mask when the caller passes none
   uint32_t* d_child_base = nullptr; size_t cap_child_base = 0;  // branching scratch
-  uint32_t* d_deep = nullptr; size_t cap_deep = 0;              // two-pass all-XNeqY launches: [0] = length, [4..] = the deep nodes' indices
   uint32_t* d_team = nullptr; size_t cap_team = 0;       // team-mode scratch (u32 words)
   // host-buffer path staging
   void* d_stage = nullptr; size_t cap_stage = 0;
@@ -109,14 +108,10 @@ struct pcp_ctx {
   int64_t opt_neq_persist = 1;      // 1 = the tile kernel's workgroups are persistent (at most what the chip holds at once; each runs several tiles)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
   int64_t opt_neq_trace = 0;        // profiling only: device pointer of NeqArgs::trace
-  int64_t opt_neq_prefetch = 0;     // 1 = large batches of 16-node tiles run the prefetching form of the all-XNeqY kernel (one workgroup per CU): measured, slower (pcp_neq.hip)
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
-  int64_t opt_neq_wave = 0;         // 1 = batches of >= 1024 implicit nodes of an all-XNeqY model run two passes (one wavefront per shallow node, then tiles for the deep ones), 0 (default: the first pass is 4x slower than the tiles, pcp_neq.hip) = tiles only
-  int64_t opt_neq_wave_block = 256;  // threads per block of the wave-per-node pass (64..1024)
-  int64_t opt_neq_wave_per_cu = 4;   // blocks of it per CU the grid is sized for
-  int64_t opt_neq_wave_max = 4;     // a node with more assigned variables than this is a deep one
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
+  int64_t opt_neq_hint = 1;         // 0 = pcp_device_batch.dirty_var is ignored (every node is propagated from scratch): A/B and parity tests
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_small_alldiff = 1;    // 1 = pcp_small.hip filters an all-different unit through its value mask, 0 = pair by pair
   int64_t opt_time_kernels = 1;     // 1 = a pair of HIP events brackets every fixpoint launch (pcp_last_kernel_ms); 0 = nothing but the kernel is enqueued
@@ -608,18 +603,8 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // few tiles: all the lanes a CU has on each; many tiles: 512 threads, so that two or three workgroups share a CU and one's
   // staging overlaps the other's list walk
   plan.block = c->opt_neq_block ? (uint32_t)c->opt_neq_block : (plan.grid <= (uint32_t)c->num_cu ? 1024u : 512u);
-  // many 16-node tiles of 16-bit cells: ONE 512-thread workgroup per CU that requests tile k+1's rows before it computes on tile k
-  // (pcp_neq.hip, PF) instead of two workgroups whose staging and compute overlap only by luck
-  uint32_t lds_wgs = (uint32_t)c->opt_neq_wgs;
-  const bool prefetch = c->opt_neq_prefetch && c->opt_neq_persist && B == 16 && packed && c->have_adjp4 && plan.block == 512 && !c->opt_neq_wave && !c->dfs_sp &&
-                        plan.grid > 2u * (uint32_t)c->num_cu && (V & 3u) == 0;
-  if (prefetch) {
-    lds_wgs = 1;
-    plan.lds_bytes = lds_bytes_neq(S, V, B, packed, 1);
-  }
-  if (prefetch) {
-    plan.grid = std::min<uint32_t>(plan.grid, (uint32_t)c->num_cu);
-  } else if (c->opt_neq_persist) {
+  const uint32_t lds_wgs = (uint32_t)c->opt_neq_wgs;
+  if (c->opt_neq_persist) {
     // persistent tiles: no more workgroups than the chip holds at once (LDS and threads per CU); each runs the tiles g, g + grid, ...
     const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)(c->lds_max / plan.lds_bytes), 2048u / plan.block));
     plan.grid = std::min<uint32_t>(plan.grid, per_cu * (uint32_t)c->num_cu);
@@ -633,34 +618,15 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.n_nodes = n_nodes; a.nodes_per_block = B; a.packed = packed ? 1u : 0u;
   a.violation = c->d_retry + 1; a.dbg = c->d_dbg;
   a.debug = (uint32_t)c->opt_neq_debug; a.trace = reinterpret_cast<unsigned long long*>(c->opt_neq_trace);
-  a.lds_wgs = lds_wgs; a.prefetch = prefetch ? 1u : 0u;
+  a.lds_wgs = lds_wgs;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
   a.stats = c->d_stats;
+  a.dirty = (c->opt_neq_hint && !c->dfs_sp) ? bt->dirty_var : nullptr;  // (pcp_device_batch.dirty_var: round 0 = that variable's lists only)
   c->dfs_team_words = 0;
-  // Two passes for large batches: one wavefront per node finishes the shallow nodes (at most neq_wave_max assigned variables) with no
-  // workgroup barrier at all and lists the others; the tile kernel then runs over that list (its workgroups beyond the list's length
-  // exit at once).  Nothing is asked of the host: the split is made on the device, per node.
-  const bool two_pass = c->opt_neq_wave && !c->dfs_sp && !(a.debug & ~0x700u) && n_nodes >= 1024 && S < 65536u;
-  uint32_t wgrid = 0, wblock = (uint32_t)c->opt_neq_wave_block;
-  size_t wlds = 0;
-  if (two_pass) {
-    int32_t rcd = ensure(c, c->d_deep, c->cap_deep, (size_t)n_nodes + 4);
-    if (rcd) return rcd;
-    a.wave_cache_entries = std::min<uint32_t>(c->max_deg, 4096u);
-    wlds = lds_bytes_neqwave(S, packed, wblock / 64, a.wave_cache_entries, c->have_adjp4);
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((size_t)c->opt_neq_wave_per_cu, c->lds_max / std::max<size_t>(wlds, 1)));
-    wgrid = std::min<uint32_t>((n_nodes + wblock / 64 - 1) / (wblock / 64), (uint32_t)c->num_cu * per_cu);
-    a.deep_count = c->d_deep; a.deep_list = c->d_deep + 4; a.wave_max_assigned = (uint32_t)c->opt_neq_wave_max;
-  }
-  c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, two_pass ? 1u : 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
-  if (two_pass) HIP_TRY(c, hipMemsetAsync(c->d_deep, 0, 4, stream));
+  c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
   if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
-  if (two_pass) {
-    HIP_TRY(c, launch_neqwave(a, wgrid, wblock, wlds, stream));
-    a.node_index = c->d_deep + 4; a.n_index = c->d_deep;
-  }
   HIP_TRY(c, launch_neqfix(a, plan, stream));
   if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
   if (bt->active_out && P) {
@@ -733,7 +699,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_ad_tab, c->d_ad_vars, c->d_ad_mask, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_deep, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_ad_tab, c->d_ad_vars, c->d_ad_mask, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -932,24 +898,12 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_round") {
     if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "big_round must be 0 (auto), 1 (dense rounds only) or 2 (sparse rounds only)");
     c->opt_big_round = value;
-  } else if (k == "neq_prefetch") {
-    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_prefetch must be 0 or 1");
-    c->opt_neq_prefetch = value;
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;
-  } else if (k == "neq_wave") {
-    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_wave must be 0 or 1");
-    c->opt_neq_wave = value;
-  } else if (k == "neq_wave_block") {
-    if (value != 64 && value != 128 && value != 256) return fail(c, PCP_ERR_ARG, "neq_wave_block must be 64, 128 or 256");
-    c->opt_neq_wave_block = value;
-  } else if (k == "neq_wave_per_cu") {
-    if (value < 1 || value > 32) return fail(c, PCP_ERR_ARG, "neq_wave_per_cu must be in [1,32]");
-    c->opt_neq_wave_per_cu = value;
-  } else if (k == "neq_wave_max") {
-    if (value < 0 || value > 65535) return fail(c, PCP_ERR_ARG, "neq_wave_max must be in [0,65535]");
-    c->opt_neq_wave_max = value;
+  } else if (k == "neq_hint") {
+    if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_hint must be 0 or 1");
+    c->opt_neq_hint = value;
   } else if (k == "neq_dfs_block") {
     if (value != 0 && value != 256 && value != 512) return fail(c, PCP_ERR_ARG, "neq_dfs_block must be 0, 256 or 512");
     c->opt_neq_dfs_block = value;
@@ -1482,6 +1436,12 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
 int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                           const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
                           uint32_t* counts, void* hip_stream) {
+  return pcp_branch_device_hint(c, n_nodes, lb, ub, active, status, child_lb, child_ub, child_active, nullptr, counts, hip_stream);
+}
+
+int32_t pcp_branch_device_hint(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,
+                               const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active,
+                               uint32_t* child_dirty, uint32_t* counts, void* hip_stream) {
   if (!c || !counts) return PCP_ERR_ARG;
   hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1492,7 +1452,7 @@ int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const
   int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
   if (rc) return rc;
   if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 20, stream)); return PCP_OK; }
-  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, active ? words : 0u, lb, ub, active, status, child_lb, child_ub, child_active, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
+  HIP_TRY(c, launch_branch(n_nodes, c->n_vars, active ? words : 0u, lb, ub, active, status, child_lb, child_ub, child_active, child_dirty, c->d_child_base, counts, (uint32_t)c->opt_branch_reverse, stream));
   return PCP_OK;
 }
 

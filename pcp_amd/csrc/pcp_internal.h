@@ -210,7 +210,7 @@ hipError_t launch_dfs_step(uint32_t n_vars, int32_t* lb, int32_t* ub, const uint
 
 // On-device branching (FirstSmallestVar / MiddleVal / BinarySplit): scan of the Unknown flags, then one block per node.
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
-                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
+                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_dirty, uint32_t* child_base,
                          uint32_t* counts, uint32_t reverse, hipStream_t stream);
 
 }  // namespace pcp

@@ -2499,7 +2499,7 @@ __global__ void __launch_bounds__(1024) branch_scan_kernel(const uint8_t* __rest
 __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t words, const int32_t* __restrict__ lb, const int32_t* __restrict__ ub,
                                                      const uint64_t* __restrict__ active, const uint32_t* __restrict__ child_base,
                                                      int32_t* __restrict__ child_lb, int32_t* __restrict__ child_ub, uint64_t* __restrict__ child_active,
-                                                     const uint32_t* __restrict__ counts, uint32_t reverse) {
+                                                     uint32_t* __restrict__ child_dirty, const uint32_t* __restrict__ counts, uint32_t reverse) {
   const uint32_t node = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
   const uint32_t slot = child_base[node];
   if (slot == 0xFFFFFFFFu) return;  // not Unknown: nothing to branch on
@@ -2529,6 +2529,8 @@ __global__ void __launch_bounds__(256) branch_kernel(uint32_t n_vars, uint32_t w
     const long long s = (long long)plb[var] + (long long)pub[var];
     val = (int32_t)(s / 2);  // MiddleVal: C++ `/` truncates toward zero like Rust's
   }
+  // the children differ from the parent's row — a fixpoint, if the caller propagated it — in this one variable (pcp_device_batch.dirty_var)
+  if (child_dirty && tid == 0) { child_dirty[rowL] = var; child_dirty[rowR] = var; }
   int32_t* l0 = child_lb + (size_t)rowL * n_vars;
   int32_t* u0 = child_ub + (size_t)rowL * n_vars;
   int32_t* l1 = child_lb + (size_t)rowR * n_vars;
@@ -2647,13 +2649,13 @@ hipError_t launch_branch_scan(uint32_t n_nodes, const uint8_t* status, uint32_t*
 }
 
 hipError_t launch_branch(uint32_t n_nodes, uint32_t n_vars, uint32_t words, const int32_t* lb, const int32_t* ub, const uint64_t* active,
-                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_base,
+                         const uint8_t* status, int32_t* child_lb, int32_t* child_ub, uint64_t* child_active, uint32_t* child_dirty, uint32_t* child_base,
                          uint32_t* counts, uint32_t reverse, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(counts, 0, 5 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(branch_scan_kernel, dim3(1), dim3(1024), 0, stream, status, n_nodes, child_base, counts);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  hipLaunchKernelGGL(branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, words, lb, ub, active, child_base, child_lb, child_ub, child_active, counts, reverse);
+  hipLaunchKernelGGL(branch_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, words, lb, ub, active, child_base, child_lb, child_ub, child_active, child_dirty, counts, reverse);
   return hipGetLastError();
 }
 

@@ -15,7 +15,6 @@ struct NeqArgs {
   uint32_t nodes_per_block;     // B <= 16 nodes per workgroup, domains in LDS node-major
   uint32_t packed;              // 1 = 16-bit (-lb, ub) cells (declared hull within +-kPackedMax), 0 = int2 cells
   uint32_t lds_wgs;             // workgroups meant to share a CU's LDS (sizes the jump-window area; must match lds_bytes_neq's argument)
-  uint32_t prefetch;            // 1 = the prefetching instantiation (one 512-thread workgroup per CU, the next tile's rows in flight during the rounds)
   uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL
   unsigned long long* dbg;      // [PCP_DBG_COUNT] diagnostic counters of the context (pcp_debug_counters); slots 5..15: phase timers under debug & 32
@@ -32,15 +31,7 @@ struct NeqArgs {
     uint32_t stop_on_solution;
     unsigned long long node_limit;
   } dfs;
-  // Two-pass launches (pcp_neq.hip, neqwave_kernel): pass 1 — one wavefront per node — finishes the nodes with at most
-  // wave_max_assigned assigned variables and appends the others to deep_list / *deep_count; pass 2 — this tile kernel — then runs
-  // with node_index = that list and n_index = its length (a workgroup beyond the length exits at once).
-  const uint32_t* node_index;   // null: the tile's nodes are node0 .. node0 + nb - 1
-  const uint32_t* n_index;      // device word: entries of node_index (with node_index only)
-  uint32_t* deep_list;
-  uint32_t* deep_count;
-  uint32_t wave_max_assigned;
-  uint32_t wave_cache_entries;  // payload entries of one list a block of neqwave_kernel keeps in LDS (0: none)
+  const uint32_t* dirty;        // pcp_device_batch.dirty_var: [n_nodes] the one variable in which node i differs from a fixpoint (>= n_vars: none), or null
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;
@@ -50,9 +41,6 @@ struct NeqArgs {
 };
 size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, uint32_t wgs = 2);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
-// pass 1 of a two-pass launch: grid x block threads, one wavefront per node (persistent: a wavefront takes nodes gw, gw + waves, ...)
-size_t lds_bytes_neqwave(uint32_t n_slots, bool packed, uint32_t waves_per_block, uint32_t cache_entries, bool pay4);
-hipError_t launch_neqwave(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream);
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
 // per workgroup (pcp_big.hip).

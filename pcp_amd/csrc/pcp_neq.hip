@@ -60,8 +60,9 @@ namespace {
 
 enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1 = 5, N_DIRTY = 6, N_WAVES = 7, N_UNK = 8, N_NARROW = 9,
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
-       N_NID = 19 /* .. 34: the global node index of the tile's node b (node0 + b unless the launch gathers through node_index) */,
-       N_R0OVF = 38 /* round 0's direct list overflowed: the marks are scanned instead */, N_SC0 = 36, N_SC1 = 37 /* PF: the two alternating sums of the round-end vote (a __syncthreads_count without its fence) */ };
+       N_NID = 19 /* .. 34: the global node index of the tile's node b */,
+       N_R0OVF = 38 /* round 0's direct list overflowed: the marks are scanned instead */,
+       N_HINT = 35 /* bit b: node b came with a dirty-variable hint (pcp_device_batch.dirty_var): round 0 walks that variable's lists only */ };
 constexpr uint32_t kMaxRounds = 1u << 22;  // a round that runs narrows something, so a fixpoint has far fewer; the cap only makes a runaway impossible
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
@@ -277,17 +278,8 @@ __device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type*
 // BT = the tile size as a compile-time constant — 16 (the batch default), 1 (the search loop) — or 0: taken from the launch.  With it the
 // cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
 // kernel does not have (it spills scalars into VGPR lanes as it is).
-// PF = one 512-thread workgroup per CU (256 VGPRs per lane instead of 128) that keeps the NEXT tile's rows in flight, in registers, while
-// it computes on the current tile: staging and compute overlap inside a workgroup instead of by luck between two (see the staging code).
-// MEASURED AND NOT USED BY DEFAULT ("neq_prefetch" = 0): bit-exact (tests/test_neq_path.py::test_prefetching_form), 186 VGPRs, no scratch,
-// no vmcnt wait at any barrier — and 66.2 us on the bench frontier where two plain workgroups per CU take 51.4.  Two reasons, both measured:
-// (1) loads return in order on gfx9 (ONE vmcnt counter), so the first payload load of the round-0 walk waits for the sixteen prefetched
-// rows issued before it: the "overlapped" compute starts when the prefetch has landed (66.2 = its staging-only 41.6 + the compute 24.6);
-// (2) eight wavefronts hold 131 KB in flight per CU and a round trip under load is ~10 us: 3.2 TB/s, where the sixteen wavefronts of two
-// workgroups reach 4.4.  What would be needed is a second memory counter (gfx10+ has one for stores only) or a loader wavefront with its
-// own LDS ring, for which 160 KB have no room next to a 64 KB tile and 128 KB of raw rows.
-template <bool PACKED, bool PAY4, bool DFS, int BT, bool PF = false>
-__global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
+template <bool PACKED, bool PAY4, bool DFS, int BT>
+__global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
   if (a.dbg) a.dbg += (size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT;
@@ -307,12 +299,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   const uint32_t nth = blockDim.x;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nth >> 6;
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = BT ? (uint32_t)BT : a.nodes_per_block;
-  // The workgroup barrier.  __syncthreads() is a fence + s_barrier, and on gfx9 the fence waits for EVERY outstanding memory operation of
-  // the wavefront (one counter for loads and stores): it would drain the prefetched rows at the first barrier of the compute phase.  The
-  // wavefronts of a tile talk through LDS only, so PF waits for its LDS operations alone.
-  auto bar = [&]() {
-    if constexpr (PF) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
-  };
+  auto bar = [&]() { __syncthreads(); };
   const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
   const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
   const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
@@ -326,7 +313,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   uint32_t* const vmk = reinterpret_cast<uint32_t*>(smem + cv.vmk);
   Win* const win = reinterpret_cast<Win*>(smem + cv.win);
   uint32_t* misc = reinterpret_cast<uint32_t*>(smem + cv.misc);  // (the copy of the current tile: see the loop's end)
-  const uint32_t n_eff = (!DFS && a.node_index) ? *a.n_index : a.n_nodes;  // (pass 2 of a two-pass launch: the length of the deep list)
+  const uint32_t n_eff = a.n_nodes;
   // PERSISTENT tiles: workgroup g runs the tiles g, g + gridDim.x, ... (the host launches at most as many workgroups as fit the chip at
   // once).  The kernel's entry (arguments, the lists' offsets) is paid once per workgroup, not per tile, and nothing drains between
   // a tile's last barrier and the next tile's first loads.
@@ -349,8 +336,6 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
   // (loaded behind the first tile's zeroing barrier, together with its row loads — hipcc drains outstanding loads at a barrier)
   uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
   bool adj_loaded = false, adj_stored = false;
-  int4 PL[8], PU[8];      // PF: the next tile's rows, requested a tile ahead (64 VGPRs that only a workgroup alone on its CU can spare)
-  bool pf_valid = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
@@ -397,14 +382,26 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     resume = dfs_resume_var != 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
-  if (tid >= (uint32_t)N_SC0 && tid <= (uint32_t)N_R0OVF) misc[tid] = 0;
+  if (tid == (uint32_t)N_R0OVF) misc[tid] = 0;
   // Round 0's list — the assigned variables of the tile's nodes, each with the mask of the nodes it is assigned in — is built BY the staging
   // loop where it finds a singleton (rare branch of put): the mask in vmk, the first node to see a variable appends it.  The ballot scan over
   // the marks that used to build it was 3 000 of a frontier tile's 32 000 cycles, for one listed variable.
-  const bool r0_direct = !DFS && BT >= 16 && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0 && a.node_index == nullptr && !(a.debug & 16384u) &&
-                         (size_t)wcap * sizeof(Win) >= (((size_t)S + 1) / 2) * 4;  // (the masks borrow the window area)
+  const bool r0_direct = !DFS && BT >= 16 && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0 && !(a.debug & 16384u) &&
+                         (size_t)wcap * sizeof(Win) >= (((size_t)S + 1) / 2) * 4 &&  // (the masks borrow the window area)
+                         a.dirty == nullptr;                                          // (hinted batches are deep nodes: their round 0 comes from the hints)
   if (r0_direct) for (uint32_t i = tid; i < (S + 1u) / 2u; i += nth) vmk[i] = 0;
-  if (tid < nb) misc[N_NID + tid] = (!DFS && a.node_index) ? a.node_index[node0 + tid] : node0 + tid;
+  if (tid < nb) misc[N_NID + tid] = node0 + tid;
+  if constexpr (!DFS) {
+    // Hinted nodes (pcp_device_batch.dirty_var): the row is a fixpoint of this model but for ONE variable — a child of a propagated node.
+    // At a fixpoint every propagator is a no-op until one of its variables changes (Store::react, store.rs:191-198), so the node's first
+    // round is that variable's lists instead of the lists of all its assigned variables: what the in-kernel search loop (DFS) does for a
+    // left child.  One wavefront, one lane per node of the tile; the variable is fetched again behind the barrier by the same lanes.
+    if (a.dirty && tid < 64u) {
+      const uint32_t dv = tid < nb ? a.dirty[node0 + tid] : 0xFFFFFFFFu;
+      const unsigned long long hm = __ballot(dv < V);
+      if (tid == 0) misc[N_HINT] = (uint32_t)hm;
+    }
+  }
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   bar();
   PCP_TR(1);
@@ -420,6 +417,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     if (tid == 0) chg[dfs_resume_var >> 5] = 1u << (dfs_resume_var & 31u);  // the left child: only the variable branched on has changed
   } else {
     uint32_t badm = 0, oobm = 0;
+    const uint32_t hintm = (!DFS && a.dirty) ? (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_HINT]) : 0u;  // (written before the barrier above)
     // returns bit 0 = an empty domain among the four, bit 1 = a bound out of range (the callers collect them per node)
     auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) -> uint32_t {
       if (PCP_PUT_FAST && cnt == 4) {
@@ -445,6 +443,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
 #pragma unroll
           for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
           if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
+          if ((hintm >> b) & 1u) nib = 0;  // a hinted node: its assigned variables' records ran at the parent's fixpoint
           if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
           // (only while the tile has few assigned variables — a frontier: deep tiles, where most quads come through here, give up after
           // kR0Cap variables and pay one LDS read per quad from then on; they are listed by the scan, which is a small part of THEIR time)
@@ -477,6 +476,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
       for (int i = 0; i < 4; ++i)
         if ((uint32_t)i < cnt) dom[rowof(v0 + i) + b] = cl[i];
       if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
+      if ((hintm >> b) & 1u) nib = 0;
       if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
       return (bad ? 1u : 0u) | (oob ? 2u : 0u);
     };
@@ -493,13 +493,12 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
       const uint32_t tid_o = tid;
       uint32_t bs = tid_o / SQ, qs = tid_o - bs * SQ;
       auto step = [&](uint32_t& bq, uint32_t& qq) { qq += dq; bq += db; if (qq >= SQ) { qq -= SQ; ++bq; } };
-      const bool gather = !DFS && a.node_index != nullptr;  // (pass 2 of a two-pass launch: the tile's nodes come through a list)
-      // (a tile's rows are contiguous otherwise: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
+      // (a tile's rows are contiguous: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
       // pair of loads, which lb and ub share; sixteen 64-bit addresses would take 32 of the VGPRs the loaded rows need)
       typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
       const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
-      if (BT >= 16 && !gather) {
+      if (BT >= 16) {
         // 16-node tiles.  A wavefront's task = FOUR nodes x SIXTEEN consecutive quads (lanes 0-15 node 4g, 16-31 node 4g+1, ...): the loads are
         // still 256 contiguous bytes per row, and the 64 cells a wavefront writes per store — word 68 q + b, q = 16 consecutive, b = 4 consecutive —
         // fall on all 32 LDS banks, two lanes each.  (64 consecutive quads of ONE node, the obvious mapping, put word 68 q + b on 8 banks: every
@@ -547,59 +546,26 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
           }
         };
         uint32_t ngs = ng_first, qcs = qc_first;
-        if constexpr (PF) {
-          // The first UF wave-tasks of this tile (all of them when 4 ceil(V / 64) <= UF x wavefronts: V <= 1024 on 512 threads) were requested
-          // while the LAST tile was being computed on; the rest, if any, is loaded here and now.
-          if (!pf_valid) loadw(rs_lb, rs_ub, nb, wv_s, ngs, qcs, PL, PU);
+        for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
+          int4 L[UF], U[UF];
+          loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
           store_adj();
-          putw(PL, PU, wv_s, ngs, qcs);
-          for (uint32_t w0 = wv_s + UF * nwv_s; w0 < wtasks; w0 += UF * nwv_s) {
-            int4 L[UF], U[UF];
-            loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
-            putw(L, U, w0, ngs, qcs);
-          }
-          // ... and the next tile of this workgroup is requested now: its rows travel while this tile's rounds and status scan run
-          const uint32_t tile_n = tile + gridDim.x;
-          pf_valid = tile_n < n_tiles;
-          if (pf_valid) {
-            const uint32_t node0_n = tile_n * B, nb_n = min(B, n_eff - node0_n);
-            const __amdgpu_buffer_rsrc_t rn_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0_n * V), 0, (int)(nb_n * V * 4u), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rn_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0_n * V), 0, (int)(nb_n * V * 4u), 0x00020000);
-            loadw(rn_lb, rn_ub, nb_n, wv_s, ng_first, qc_first, PL, PU);
-          }
-        } else {
-          for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
-            int4 L[UF], U[UF];
-            loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
-            store_adj();
-            putw(L, U, w0, ngs, qcs);
-          }
+          putw(L, U, w0, ngs, qcs);
         }
       } else
       for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
         int4 L[UF], U[UF];
         uint32_t bq = bs, qq = qs;
         uint32_t ro = bs * V * 4u;
-        if (!gather) {
 #pragma unroll
-          for (int j = 0; j < UF; ++j) {
-            const uint32_t off = t0 + j * nth < tasks ? ro + 16u * qq : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
-            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
-            L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
-            U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
-            // the row's byte offset moves with the node by additions (a 32-bit multiply per load pair is a quarter-rate instruction)
-            qq += dq; bq += db; ro += db * V * 4u;
-            if (qq >= SQ) { qq -= SQ; ++bq; ro += V * 4u; }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < UF; ++j) {
-            const bool on = t0 + j * nth < tasks;
-            const size_t row = (size_t)a.node_index[node0 + (on ? bq : 0u)] * V;
-            L[j] = reinterpret_cast<const int4*>(a.lb_in + row)[on ? qq : 0u];
-            U[j] = reinterpret_cast<const int4*>(a.ub_in + row)[on ? qq : 0u];
-            step(bq, qq);
-          }
+        for (int j = 0; j < UF; ++j) {
+          const uint32_t off = t0 + j * nth < tasks ? ro + 16u * qq : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
+          const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
+          L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
+          U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
+          // the row's byte offset moves with the node by additions (a 32-bit multiply per load pair is a quarter-rate instruction)
+          qq += dq; bq += db; ro += db * V * 4u;
+          if (qq >= SQ) { qq -= SQ; ++bq; ro += V * 4u; }
         }
         if (!adj_stored) {
           adj_stored = true;
@@ -642,6 +608,10 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     }
     if (badm) atomicOr(&misc[N_FAIL], badm);
     if (oobm) atomicOr(&misc[N_OOB], oobm);
+    if (hintm && tid < nb && ((hintm >> tid) & 1u)) {  // the hinted nodes' one changed variable
+      const uint32_t dv = a.dirty[node0 + tid];
+      atomicOr(&chg[tid * Wv + (dv >> 5)], 1u << (dv & 31u));
+    }
   }
   if (!adj_stored) {
     adj_stored = true;
@@ -977,16 +947,7 @@ __global__ void __launch_bounds__((DFS || PF) ? 512 : 1024) neqfix_kernel(const 
     // (the count of narrowing threads also says whether this round was a cascade: only then is the next round's cover priced)
     if (ptime && round == 0) ptb = __builtin_amdgcn_s_memtime();
     if (round == 0) PCP_TR(7);
-    uint32_t n_narrowing;
-    if constexpr (PF) {
-      const uint32_t mine = (uint32_t)__popcll(__ballot(ctr.narrow != narrow_before)), slot = (round & 1u) ? N_SC1 : N_SC0;
-      if (lane == 0 && mine) atomicAdd(&misc[slot], mine);
-      bar();
-      n_narrowing = misc[slot];
-      if (tid == 0) misc[(round & 1u) ? N_SC0 : N_SC1] = 0;  // (last read a round ago, next added to behind the next round's list barrier)
-    } else {
-      n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
-    }
+    const uint32_t n_narrowing = (uint32_t)__syncthreads_count(ctr.narrow != narrow_before);
     if (round == 0) PCP_TR(8);
     if (ptime && round == 0) ptc = __builtin_amdgcn_s_memtime();
     const bool narrowed = n_narrowing != 0;
@@ -1287,20 +1248,17 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4, bool DFS, int BT, bool PF = false>
+template <bool PACKED, bool PAY4, bool DFS, int BT>
 static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT, PF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT, PF>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 template <bool DFS, int BT>
 static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
-  if constexpr (!DFS && BT == 16) {  // the prefetching form: one instantiation, the headline's (16-bit cells, 4-byte payloads); the plan asks for it
-    if (a.prefetch && a.adjp4 && a.packed && p.block == 512 && !a.node_index) return launch_neq_k<true, true, false, 16, true>(a, p, stream);
-  }
   if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS, BT>(a, p, stream) : launch_neq_k<false, true, DFS, BT>(a, p, stream);
   return a.packed ? launch_neq_k<true, false, DFS, BT>(a, p, stream) : launch_neq_k<false, false, DFS, BT>(a, p, stream);
 }
@@ -1312,325 +1270,6 @@ hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stre
     return launch_neq_d<true, 1>(a, p, stream);
   }
   return a.nodes_per_block == 16 ? launch_neq_d<false, 16>(a, p, stream) : launch_neq_d<false, 0>(a, p, stream);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Pass 1 of a two-pass launch: ONE WAVEFRONT owns a node.  A node with one or two assigned variables (a breadth-first frontier) needs
-// its rows staged, one or two lists walked and a status scan; in the tile kernel that little work is spread over three workgroup
-// barriers, and the two workgroups of a CU stage and compute in lockstep, so HBM idles while they compute.  Here a wavefront stages
-// its node into its own LDS slice and runs the whole fixpoint alone — the same rounds (round 0 = the lists of the assigned variables,
-// round r = the lists of the variables changed in round r-1), the same filter (eval_record), the same status rule — with no
-// workgroup barrier anywhere: sixteen wavefronts per CU at sixteen different points keep HBM streaming.  It is correct for any node
-// and slow for a deep one (64 lanes per list instead of 512 and no node quads), so a node with more than wave_max_assigned assigned
-// variables is not run: its index goes to deep_list and the tile kernel (pass 2) takes it.
-// MEASURED AND NOT USED BY DEFAULT ("neq_wave" = 0): bit-exact (tests/test_neq_path.py::test_two_pass_launches), but on the bench
-// frontier this pass takes 250 us where the tile kernel takes 65 us for everything, whatever the block size (64..1024 threads) and
-// blocks per CU; with the rounds and the status scan compiled out it still takes 117-173 us for the staging alone (the tile kernel
-// stages the same rows in 36 us).  PMC: 1.4x the tile kernel's VALU instructions, but its wavefronts live six times longer and issue
-// a VALU instruction in 6.6 % of their cycles: one wavefront doing a node alone is a long chain of dependent LDS and memory reads, and
-// four such wavefronts per SIMD do not hide each other ("measured and rejected").  Kept as an option, with its tests.
-// ------------------------------------------------------------------------------------------------
-enum { W_FAIL = N_FAIL, W_OOB = N_OOB, W_DIRTY = N_DIRTY, W_UNK = N_UNK, W_WORDS = 16 };
-// payload sources of a list walk: two TYPES, so that the walk is instantiated per address space (one pointer type for both makes the
-// loads flat: they wait on both counters and were most of a node's time)
-template <class P> struct PayLds { const P* p; __device__ __forceinline__ P at(uint32_t i) const { return p[i]; } };
-template <class P> struct PayGlobal { const P* p; __device__ __forceinline__ P at(uint32_t i) const { return p[i]; } };
-constexpr uint32_t kWaveStatusCache = 256;  // entries of the status scan's list kept in LDS (its first chunks decide almost every node)
-
-__host__ __device__ inline size_t neqwave_slice(uint32_t S, bool packed) {
-  const size_t Wv = (S + 31) / 32;
-  return (((size_t)S * (packed ? 4 : 8) + 15) & ~(size_t)15) + 2 * ((Wv * 4 + 15) & ~(size_t)15) + W_WORDS * 4;
-}
-
-template <bool PACKED, bool PAY4>
-__global__ void __launch_bounds__(256) neqwave_kernel(const NeqArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  using Cell = typename NeqCell<PACKED>::type;
-  using TDom = typename TileDomOf<PACKED>::type;
-  using Pay = typename std::conditional<PAY4, uint32_t, uint2>::type;
-  const uint32_t tid = threadIdx.x, lane = tid & 63;
-  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = blockDim.x >> 6;
-  const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5;
-  unsigned char* const mine = smem + (size_t)wv * neqwave_slice(S, PACKED);
-  Cell* const dom = reinterpret_cast<Cell*>(mine);
-  uint32_t* chgA = reinterpret_cast<uint32_t*>(mine + (((size_t)S * sizeof(Cell) + 15) & ~(size_t)15));
-  uint32_t* chgB = chgA + (((Wv * 4 + 15) & ~15u) >> 2);
-  uint32_t* const misc = chgB + (((Wv * 4 + 15) & ~15u) >> 2);
-  const Pay* const pay = PAY4 ? reinterpret_cast<const Pay*>(a.adjp4) : reinterpret_cast<const Pay*>(a.m.adjp);
-  const uint32_t* const adjo = a.m.adj_off;
-  const int lim = PACKED ? kPackedMax : kBoundMax;
-  const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
-  const bool vec = (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in | (size_t)a.lb_out | (size_t)a.ub_out) & 15u) == 0;
-  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); };
-  // ---- prologue (the kernel's only workgroup barriers): the nodes of a frontier share their assigned variables, so the list of the
-  // FIRST assigned variable of this block's first node, and the head of the list of its first unassigned variable (the status scan's),
-  // go to LDS once; a wavefront that walks one of them reads the payloads from there.  Every node re-reading 12 KB from L2 with four
-  // loads in flight per lane was four times slower than the tile kernel, which decodes a list once for sixteen nodes.
-  const unsigned long long tk_start = __builtin_amdgcn_s_memtime();
-  Pay* const cacheA = reinterpret_cast<Pay*>(smem + (size_t)nwv * neqwave_slice(S, PACKED));
-  Pay* const cacheU = cacheA + a.wave_cache_entries;
-  __shared__ uint32_t tagA, tagU, lenA, lenU;
-  if (tid == 0) { tagA = tagU = 0xFFFFFFFFu; lenA = lenU = 0; }
-  __syncthreads();
-  {
-    const uint32_t n0 = blockIdx.x * nwv;
-    if (wv == 0 && n0 < a.n_nodes) {
-      uint32_t fa = 0xFFFFFFFFu, fu = 0xFFFFFFFFu;
-      for (uint32_t base = 0; base < V && (fa == 0xFFFFFFFFu || fu == 0xFFFFFFFFu); base += 64) {
-        const uint32_t v = base + lane;
-        int l = 0, u = 1;
-        if (v < V) { l = a.lb_in[(size_t)n0 * V + v]; u = a.ub_in[(size_t)n0 * V + v]; }
-        const uint64_t ba = __ballot(v < V && l == u), bu = __ballot(v < V && l < u);
-        if (fa == 0xFFFFFFFFu && ba) fa = base + (uint32_t)__builtin_ctzll(ba);
-        if (fu == 0xFFFFFFFFu && bu) fu = base + (uint32_t)__builtin_ctzll(bu);
-      }
-      if (lane == 0) {
-        if (fa != 0xFFFFFFFFu && adjo[fa + 1] - adjo[fa] <= a.wave_cache_entries) { tagA = fa; lenA = adjo[fa + 1] - adjo[fa]; }
-        if (fu != 0xFFFFFFFFu) { tagU = fu; lenU = min(adjo[fu + 1] - adjo[fu], kWaveStatusCache); }
-      }
-    }
-  }
-  __syncthreads();
-  const uint32_t cA = tagA, cU = tagU, nA = lenA, nU = lenU;
-  if (cA != 0xFFFFFFFFu) {
-    const Pay* src = pay + adjo[cA];
-    for (uint32_t i0 = tid; i0 < nA; i0 += 4 * blockDim.x) {
-      Pay q[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = src[min(i0 + j * blockDim.x, nA - 1)];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) if (i0 + j * blockDim.x < nA) cacheA[i0 + j * blockDim.x] = q[j];
-    }
-  }
-  if (cU != 0xFFFFFFFFu) { const Pay* src = pay + adjo[cU]; for (uint32_t i = tid; i < nU; i += blockDim.x) cacheU[i] = src[i]; }
-  __syncthreads();
-  const bool wtime = (a.debug & 1024u) != 0;  // profiling: s_memtime ticks per phase in the counters (results wrong)
-  unsigned long long tk_pro = 0, tk_load = 0, tk_put = 0, tk_rest = 0, tk_a = 0, tk_b = 0, tk_c = 0, tk0 = 0;
-  if (wtime) tk_pro = __builtin_amdgcn_s_memtime() - tk_start;
-  // counters of this wavefront, handed over once
-  unsigned long long acc_steps = 0, acc_ev = 0, acc_full = 0, acc_narrow = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;
-  const uint32_t gw = blockIdx.x * nwv + wv, nw = gridDim.x * nwv;
-
-  for (uint32_t node = gw; node < a.n_nodes; node += nw) {
-    const size_t row = (size_t)node * V;
-    if (wtime) tk0 = __builtin_amdgcn_s_memtime();
-    // ---- stage: rows -> cells, the assigned variables marked ------------------------------------------------------------------
-    for (uint32_t w = lane; w < Wv; w += 64) { chgA[w] = 0; chgB[w] = 0; }
-    if (lane < (uint32_t)W_WORDS) misc[lane] = 0;
-    wave_sync();
-    uint32_t n_assigned = 0;
-    bool bad = false, oob = false;
-    auto put = [&](uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) {
-      uint32_t nib = 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((uint32_t)i >= cnt) continue;
-        bad |= l[i] > u[i];
-        oob |= (l[i] < -lim) | (l[i] > lim) | (u[i] < -lim) | (u[i] > lim);
-        if (l[i] == u[i]) { nib |= 1u << i; ++n_assigned; }
-        if constexpr (PACKED) dom[v0 + i] = pack16(l[i], u[i]); else dom[v0 + i] = make_int2(-l[i], u[i]);
-      }
-      if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
-      if (nib) atomicOr(&chgA[v0 >> 5], nib << (v0 & 31u));
-    };
-    if (vec) {
-      const int4* L4 = reinterpret_cast<const int4*>(a.lb_in + row);
-      const int4* U4 = reinterpret_cast<const int4*>(a.ub_in + row);
-      const uint32_t Q = V >> 2;
-      for (uint32_t q0 = lane; q0 < Q; q0 += 4 * 64) {
-        int4 L[4], U[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t q = min(q0 + j * 64, Q - 1); L[j] = L4[q]; U[j] = U4[q]; }
-        if (wtime) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_load += t - tk0; tk0 = t; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (q0 + j * 64 >= Q) break;
-          const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
-          put(4 * (q0 + j * 64), l, u, 4);
-        }
-      }
-    } else {
-      for (uint32_t v0 = 4 * lane; v0 < V; v0 += 4 * 64) {
-        const uint32_t cnt = min(4u, V - v0);
-        int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
-        for (uint32_t i = 0; i < cnt; ++i) { l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i]; }
-        put(v0, l, u, cnt);
-      }
-    }
-    for (uint32_t s_ = V + lane; s_ < S; s_ += 64) {  // interned constants: singleton pseudo-variables behind the variables
-      const int c = a.m.const_val[s_ - V];
-      if constexpr (PACKED) dom[s_] = pack16(c, c); else dom[s_] = make_int2(-c, c);
-    }
-    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_put += t - tk0; tk0 = t; }
-    for (int o = 32; o > 0; o >>= 1) n_assigned += __shfl_xor(n_assigned, o);
-    const bool any_bad = __ballot(bad) != 0, any_oob = __ballot(oob) != 0;
-    if (n_assigned > a.wave_max_assigned && !any_bad && !any_oob) {  // a deep node: the tile kernel's (pass 2)
-      if (lane == 0) a.deep_list[atomicAdd(a.deep_count, 1u)] = node;
-      continue;
-    }
-    if (lane == 0) { if (any_bad) misc[W_FAIL] = 1u; if (any_oob) misc[W_OOB] = 1u; }
-    wave_sync();
-    Ctr ctr;
-    uint32_t my_ev = 0, ev0 = 0, waves = 0;
-    const TDom dmA{dom, 1u, 31u, chgA, misc, 1u, &ctr}, dmB{dom, 1u, 31u, chgB, misc, 1u, &ctr};
-
-    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_a += t - tk0; tk0 = t; }
-    // ---- rounds (wave-local): the lists of the marked variables; narrowings mark into the other mask ----------------------------
-#ifndef PCP_WAVE_STRIP  // (experiment builds: the rounds compiled out, to price the kernel's code size)
-    if (!any_bad && !any_oob && !(a.debug & 256u))  // (neq_debug 256 / 512: profiling only — no rounds / no status scan)
-      for (uint32_t round = 0;; ++round) {
-        if (round >= kMaxRounds) { if (lane == 0) misc[W_OOB] = 1u; wave_sync(); break; }  // (refused, not hung)
-        uint32_t* const cur = (round & 1u) ? chgB : chgA;
-        const TDom& dmn = (round & 1u) ? dmA : dmB;
-        bool any = false;
-        for (uint32_t w = 0; w < Wv; ++w) {
-          uint32_t m = __builtin_amdgcn_readfirstlane(cur[w]);
-          if (!m) continue;
-          any = true;
-          while (m) {
-            const uint32_t v = (w << 5) + (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            if (v >= V) continue;
-            const uint32_t o0 = adjo[v], deg = adjo[v + 1] - o0;
-            auto walk = [&](const auto src) {
-              for (uint32_t k0 = 0; k0 < deg; k0 += 4 * 64) {
-                Pay q[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = src.at(min(k0 + u * 64 + lane, deg - 1));
-                const Cell c0 = dom[v];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  if (k0 + u * 64 + lane >= deg) continue;
-                  const uint32_t other = pay_other(q[u]);
-                  const int t = pay_t(q[u]);
-                  const Cell oc = dom[other];
-                  bool hit;
-                  if constexpr (PACKED) hit = zero_half(neq_terms16(c0, oc, pack_mt(t)));
-                  else hit = (c0.x + oc.y == t) | (c0.y + oc.x == -t);
-                  ++my_ev;
-                  if (hit) {
-                    const bool is_y = pay_is_y(q[u]);
-                    Rec rec;
-                    rec.xk = (is_y ? other : v) | ((uint32_t)PCP_NEQ << 28);
-                    rec.y = is_y ? v : other;
-                    rec.z = 0;
-                    rec.d = is_y ? t : -t;
-                    ++ctr.full;
-                    eval_record(rec, dmn);
-                  }
-                }
-              }
-            };
-            if (v == cA) walk(PayLds<Pay>{cacheA}); else walk(PayGlobal<Pay>{pay + o0});
-          }
-          if (lane == 0) cur[w] = 0;
-        }
-        wave_sync();
-        if (round == 0) ev0 = my_ev;
-        if (!any) break;
-        if (round) ++waves;
-        if (__builtin_amdgcn_readfirstlane(misc[W_FAIL])) break;
-      }
-#endif
-    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_b += t - tk0; tk0 = t; }
-    // ---- status: an open record sits in the list of an unassigned variable (see the tile kernel) --------------------------------
-    const bool failed = __builtin_amdgcn_readfirstlane(misc[W_FAIL]) != 0, refused = __builtin_amdgcn_readfirstlane(misc[W_OOB]) != 0;
-    bool open = false;
-    if (!failed && !refused && !(a.debug & 512u)) {
-      for (uint32_t base = 0; base < V && !open; base += 64) {
-        const uint32_t vv = base + lane;
-        bool wide = false;
-        if (vv < V) { const int2 d = cell_bounds<PACKED>(dom[vv]); wide = d.x < d.y; }
-        uint64_t bal = __ballot(wide);
-        while (bal && !open) {
-          const uint32_t u = base + (uint32_t)__builtin_ctzll(bal);
-          bal &= bal - 1;
-          const int2 Ud = cell_bounds<PACKED>(dom[u]);
-          const uint32_t o0 = adjo[u], deg = adjo[u + 1] - o0;
-          for (uint32_t k = 0; k < deg && !open; k += 64) {
-            bool op = false;
-            if (k + lane < deg) {
-              Pay q;
-              if (u == cU && k + 64 <= nU) q = cacheU[k + lane];  // (wave-uniform: a whole chunk from the cached head, or from memory)
-              else q = pay[o0 + k + lane];
-              const int t = pay_t(q);
-              const int2 O = cell_bounds<PACKED>(dom[pay_other(q)]);
-              op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));
-            }
-            open = __ballot(op) != 0;
-          }
-        }
-      }
-    }
-    if (wtime) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tk_c += t - tk0; tk0 = t; }
-    // ---- write back, status, counters -----------------------------------------------------------------------------------------
-    bool emptied = false;
-    if (!refused && (!in_place || __builtin_amdgcn_readfirstlane(misc[W_DIRTY]))) {
-      int32_t* lbp = a.lb_out + row;
-      int32_t* ubp = a.ub_out + row;
-      if (vec) {
-        for (uint32_t q = lane; q < (V >> 2); q += 64) {
-          int l[4], u[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int2 d = cell_bounds<PACKED>(dom[4 * q + i]); l[i] = d.x; u[i] = d.y; emptied |= d.x > d.y; }
-          reinterpret_cast<int4*>(lbp)[q] = make_int4(l[0], l[1], l[2], l[3]);
-          reinterpret_cast<int4*>(ubp)[q] = make_int4(u[0], u[1], u[2], u[3]);
-        }
-      } else {
-        for (uint32_t v = lane; v < V; v += 64) { const int2 d = cell_bounds<PACKED>(dom[v]); emptied |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
-      }
-    }
-    const bool is_failed = failed || __ballot(emptied) != 0;
-    for (int o = 32; o > 0; o >>= 1) { my_ev += __shfl_xor(my_ev, o); ev0 += __shfl_xor(ev0, o); ctr.full += __shfl_xor(ctr.full, o); ctr.narrow += __shfl_xor(ctr.narrow, o); }
-    if (lane == 0) {
-      a.status[node] = refused ? kStatusRetry : is_failed ? (uint8_t)PCP_FALSE : (open ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
-      if (refused) atomicMax(a.violation, 1u);
-    }
-    // reference-equivalent steps: every propagator of the node once (init_scheduler) + the wake-ups of the later rounds
-    acc_steps += (refused ? 0ull : (unsigned long long)a.m.n_recs) + (unsigned long long)(my_ev - ev0);
-    if (wtime) tk_rest += __builtin_amdgcn_s_memtime() - tk0;
-    acc_ev += my_ev; acc_full += ctr.full; acc_narrow += ctr.narrow; acc_waves += 1 + waves; acc_nodes += 1; acc_failed += is_failed && !refused ? 1 : 0;
-  }
-  if (lane == 0 && wtime) { acc_steps = acc_narrow = acc_ev = acc_full = acc_waves = acc_failed = acc_nodes = 0; }
-  if (lane == 0) {
-    if (acc_steps) atomicAdd((unsigned long long*)&a.stats->steps, acc_steps);
-    if (acc_narrow) atomicAdd((unsigned long long*)&a.stats->narrowings, acc_narrow);
-    if (acc_ev) atomicAdd((unsigned long long*)&a.stats->evaluated, acc_ev);
-    if (acc_full) atomicAdd((unsigned long long*)&a.stats->full_evals, acc_full);
-    if (acc_waves) atomicAdd((unsigned long long*)&a.stats->waves, acc_waves);
-    if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
-    if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
-    if (wtime) {
-      atomicAdd((unsigned long long*)&a.stats->steps3, tk_pro);
-      atomicAdd((unsigned long long*)&a.stats->narrowings, tk_load);
-      atomicAdd((unsigned long long*)&a.stats->full_evals, tk_put);
-      atomicAdd((unsigned long long*)&a.stats->failed_nodes, tk_rest);
-      atomicAdd((unsigned long long*)&a.stats->waves, tk_a);
-      atomicAdd((unsigned long long*)&a.stats->evaluated, tk_b);
-      atomicAdd((unsigned long long*)&a.stats->steps, tk_c);
-      atomicAdd((unsigned long long*)&a.stats->nodes, (unsigned long long)(__builtin_amdgcn_s_memtime() - tk_start));  // the wavefront's lifetime
-    }
-  }
-}
-
-size_t lds_bytes_neqwave(uint32_t n_slots, bool packed, uint32_t waves_per_block, uint32_t cache_entries, bool pay4) {
-  return neqwave_slice(n_slots, packed) * waves_per_block + (((size_t)(cache_entries + kWaveStatusCache) * (pay4 ? 4 : 8) + 15) & ~(size_t)15);
-}
-
-template <bool PACKED, bool PAY4>
-static hipError_t launch_neqwave_k(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream) {
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqwave_kernel<PACKED, PAY4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((neqwave_kernel<PACKED, PAY4>), dim3(grid), dim3(block), lds, stream, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_neqwave(const NeqArgs& a, uint32_t grid, uint32_t block, size_t lds, hipStream_t stream) {
-  if (!a.m.adjp || !a.deep_list || !a.deep_count || a.m.n_slots >= 65536u) return hipErrorInvalidValue;
-  if (a.adjp4) return a.packed ? launch_neqwave_k<true, true>(a, grid, block, lds, stream) : launch_neqwave_k<false, true>(a, grid, block, lds, stream);
-  return a.packed ? launch_neqwave_k<true, false>(a, grid, block, lds, stream) : launch_neqwave_k<false, false>(a, grid, block, lds, stream);
 }
 
 }  // namespace pcp

@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -46,7 +46,8 @@ class PcpPlan(C.Structure):
 
 class DeviceBatch(C.Structure):
     _fields_ = [("lb_in", C.c_void_p), ("ub_in", C.c_void_p), ("lb_out", C.c_void_p), ("ub_out", C.c_void_p),
-                ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p), ("bits_in", C.c_void_p), ("bits_out", C.c_void_p)]
+                ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p), ("bits_in", C.c_void_p), ("bits_out", C.c_void_p),
+                ("dirty_var", C.c_void_p)]
 
 
 class DfsState(C.Structure):
@@ -114,6 +115,7 @@ def load_library():
     L.pcp_propagate.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
+    L.pcp_branch_device_hint.argtypes = [vp, u32] + [vp] * 10
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
@@ -126,7 +128,7 @@ def load_library():
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -152,6 +154,7 @@ class Context:
         self.n_vars = 0
         self.n_units = 0
         self.set_words = 0
+        self.supports_hints = True  # pcp_device_batch.dirty_var / pcp_branch_device_hint (ABI v7): search drivers keep a hint per open node
 
     def close(self):
         if getattr(self, "_h", None):
@@ -278,21 +281,23 @@ class Context:
 
     # ---- propagation, device-resident (pcp_propagate_device) ------------------------------------------------
     def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0,
-                         bits_in=None, bits_out=None):
+                         bits_in=None, bits_out=None, dirty=None):
         """All arguments are torch tensors on this context's device (or None for the optional masks); nothing is
         synchronised.  Tensors: lb/ub int32 [n,V]; active int64/uint64 [n,words]; status uint8 [n]; set mode: bits int64
-        [n,V,set_words] (lb_in/ub_in ignored)."""
+        [n,V,set_words] (lb_in/ub_in ignored); dirty int32 [n]: per node the one variable in which it differs from a fixpoint of this
+        model, -1 / >= n_vars = none (pcp_device_batch.dirty_var)."""
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
-        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out))
+        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out), p(dirty))
         self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
 
-    def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0):
-        """pcp_branch_device on torch tensors of this context's device (counts: int32[4]); nothing is synchronised."""
+    def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0, child_dirty=None):
+        """pcp_branch_device(_hint) on torch tensors of this context's device (counts: int32[5]; child_dirty: int32 [2 n] capacity, receives
+        the variable each child was branched on); nothing is synchronised."""
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
-        self._check(self._L.pcp_branch_device(self._h, n_nodes, p(lb), p(ub), p(active), p(status), p(child_lb), p(child_ub), p(child_active),
-                                              p(counts), C.c_void_p(stream_ptr)))
+        self._check(self._L.pcp_branch_device_hint(self._h, n_nodes, p(lb), p(ub), p(active), p(status), p(child_lb), p(child_ub), p(child_active),
+                                                   p(child_dirty), p(counts), C.c_void_p(stream_ptr)))
 
     def branch_device_set(self, n_nodes: int, bits, lb, ub, active, status, child_bits, child_active, counts, stream_ptr: int = 0):
         """pcp_branch_device_set (set mode) on torch tensors of this context's device (counts: int32[5])."""

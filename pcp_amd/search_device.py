@@ -35,7 +35,7 @@ class DeviceSearch:
     the children straight above them, in reverse order, as a new segment: nothing is copied or reordered.  The popped
     parents leave a hole below the new segment; it is reclaimed when that segment is used up (LIFO)."""
 
-    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None, implicit: bool = False):
+    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None, implicit: bool = False, hints=None):
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -56,6 +56,11 @@ class DeviceSearch:
         self.set_words = int(getattr(ctx, "set_words", 0))
         self.base = 0
         self.bits = torch.empty((self.cap, V, self.set_words), dtype=i64, device=self.dev) if self.set_words else None
+        # one hint per open node (pcp_device_batch.dirty_var): a child is its parent's fixpoint with ONE variable branched on, so the engine
+        # may start the child's propagation from that variable alone; the root has none (-1).  Interval mode, implicit nodes, an engine
+        # that knows the field (the CPU stand-in of the tests does not).
+        want = bool(getattr(ctx, "supports_hints", False)) and self.implicit and not self.set_words
+        self.dirty = torch.full((self.cap,), -1, dtype=i32, device=self.dev) if (want if hints is None else (hints and want)) else None
         self.status = torch.zeros(self.batch, dtype=u8, device=self.dev)
         self.counts = torch.zeros(5, dtype=i32, device=self.dev)
         self.segs: List[List[int]] = []  # [start, length], bottom to top
@@ -81,6 +86,8 @@ class DeviceSearch:
 
     def _rows(self):
         rows = (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
+        if self.dirty is not None:
+            rows = rows + (self.dirty,)
         return rows if self.bits is None else rows + (self.bits,)
 
     def _merge_top(self, want: int):
@@ -120,6 +127,8 @@ class DeviceSearch:
         self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
         if self.act is not None:
             self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
+        if self.dirty is not None:
+            self.dirty[0] = -1  # the root is propagated from scratch
         self.segs = [[0, 1]]
         self.stats = DeviceSearchStats()
         ctx.stats_reset(self._stream())
@@ -161,7 +170,11 @@ class DeviceSearch:
             lb, ub = self.lb[lo:top], self.ub[lo:top]
             act = None if self.act is None else self.act[lo:top]
             status = self.status[:n]
-            if self.bits is None:
+            if self.bits is None and self.dirty is not None:
+                ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream, dirty=self.dirty[lo:top])
+                ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
+                                  self.counts, stream, child_dirty=self.dirty[top:])
+            elif self.bits is None:
                 ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream)
                 ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
                                   self.counts, stream)

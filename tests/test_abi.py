@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
     assert declared == set(E.ABI_SYMBOLS), declared ^ set(E.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), f"libpcp_hip.so does not export {name}"
-    assert L.pcp_abi_version() == 6
+    assert L.pcp_abi_version() == 7
 
 
 def test_prop_struct_layout_matches_header():
@@ -34,7 +34,7 @@ def test_prop_struct_layout_matches_header():
     from pcp_amd.model import PROP_DTYPE
     assert PROP_DTYPE.itemsize == 32
     assert PROP_DTYPE.fields["var"][1] == 8 and PROP_DTYPE.fields["off"][1] == 20 and PROP_DTYPE.fields["group"][1] == 4
-    assert ctypes.sizeof(E.PcpStats) == 64 and ctypes.sizeof(E.DeviceBatch) == 72 and ctypes.sizeof(E.PcpPlan) == 52
+    assert ctypes.sizeof(E.PcpStats) == 64 and ctypes.sizeof(E.DeviceBatch) == 80 and ctypes.sizeof(E.PcpPlan) == 52
 
 
 def test_fails_loudly_without_gpu():

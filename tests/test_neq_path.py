@@ -172,76 +172,6 @@ def test_counters(ctx):
     assert st["narrowings"] > 0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", [11, 12, 13])
-@pytest.mark.parametrize("hull", [True, False])
-def test_two_pass_launches(ctx, seed, hull):
-    """With "neq_wave" = 1, batches of >= 1024 nodes run two passes on the device: one wavefront per shallow node (neqwave_kernel), the tile kernel over the
-    list of deep ones.  Mixed depths, 16- and 32-bit cells, Constant operands, failures and cascades, in place and out of place; the
-    threshold at both ends — 0: every node with an assigned variable goes through the gather list, 65535: every node is a wavefront's."""
-    V, P, dom = 36 + 5 * (seed % 5), 180 + 30 * (seed % 5), (0, 10 + seed % 4)
-    props = neq_model(seed, V, P, dom)
-    om = orc.OracleModel(V, props)
-    ctx.set_model(V, props)
-    if hull:
-        ctx.set_hull(dom[0], dom[1])
-    L, U = nodes_with_assignments(300 + seed, V, 1500, dom, p_assign=0.35, p_narrow=0.4)
-    ref = om.consistency(L, U, None)
-    assert (ref[3] == 0).any() and (ref[3] == 2).any()
-    try:
-        ctx.set_option("neq_wave", 1)  # (off by default: bit-exact but slower than the tiles alone)
-        for wmax in (4, 0, 3, 65535):
-            ctx.set_option("neq_wave_max", wmax)
-            for in_place in (True, False):
-                got = ctx.propagate_implicit(L, U, in_place=in_place)
-                pl = ctx.last_plan()
-                assert pl["path"] == 1 and pl["compact"] == 1, pl  # (compact = 1: the launch was two passes)
-                assert_parity(ref[:4], got[:4], f"two-pass seed={seed} hull={hull} wave_max={wmax} in_place={in_place}")
-        ctx.set_option("neq_wave", 0)
-        got = ctx.propagate_implicit(L, U)
-        assert ctx.last_plan()["compact"] == 0
-        assert_parity(ref[:4], got[:4], f"tiles only seed={seed} hull={hull}")
-    finally:
-        ctx.set_option("neq_wave", 0)
-        ctx.set_option("neq_wave_max", 4)
-
-
-def test_prefetching_form(ctx):
-    """Option neq_prefetch = 1: one 512-thread workgroup per CU that requests tile k+1's rows before it computes on tile k (pcp_neq.hip, PF;
-    measured slower and off by default).  Same results as the default launch on a batch large enough to take it (more than two tiles per CU),
-    with assigned variables, failing nodes and a ragged last tile."""
-    n = 64
-    props = M.nqueens_props(n)
-    ctx.set_model(n, props)
-    ctx.set_hull(1, n)
-    rng = np.random.default_rng(77)
-    N = 16 * 2 * 300 + 5
-    L = np.ones((N, n), np.int32); U = np.full((N, n), n, np.int32)
-    for i in range(N):
-        k = int(rng.integers(0, 6))
-        vs = rng.choice(n, size=k, replace=False)
-        vals = rng.integers(1, n + 1, size=k)
-        L[i, vs] = vals; U[i, vs] = vals
-        w = rng.choice(n, size=4, replace=False)
-        L[i, w] = np.maximum(L[i, w], rng.integers(1, n // 2, size=4)); U[i, w] = np.maximum(L[i, w], U[i, w] - rng.integers(0, n // 2, size=4))
-    for k, v in {"small_path": 0, "neq_prefetch": 0}.items():
-        ctx.set_option(k, v)
-    try:
-        ref = ctx.propagate_implicit(L, U)
-        plan0 = ctx.last_plan()
-        ctx.set_option("neq_prefetch", 1)
-        got = ctx.propagate_implicit(L, U)
-        plan1 = ctx.last_plan()
-    finally:
-        ctx.set_option("neq_prefetch", 0); ctx.set_option("small_path", 1)
-    assert plan0["path"] == 1 and plan1["path"] == 1
-    assert plan1["grid"] < plan0["grid"] and plan1["block"] == 512 and plan1["lds_bytes"] >= plan0["lds_bytes"], (plan0, plan1)  # one workgroup per CU
-    assert np.array_equal(ref[3], got[3])
-    ok = ref[3] != 0
-    assert np.array_equal(ref[0][ok], got[0][ok]) and np.array_equal(ref[1][ok], got[1][ok])
-    assert (ref[3] == 0).any() and (ref[3] == 2).any()
-
-
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_round0_list_built_by_staging(ctx, seed):
     """16-node tiles (pcp_neq.hip, round 0's list built by the staging loop for up to 32 assigned variables per tile, the scan beyond): tiles
