@@ -74,6 +74,40 @@ def cpu_baseline(n, props, lb, ub, act, budget_s):
     return obj, keep
 
 
+def box_ceilings(torch, t_a, t_b, stream):
+    """Side measurements on THIS box, untimed (tools/micro/box_probe.hip, its own small library): the streaming-read ceiling over the very
+    buffers a headline launch reads ("the measured ceiling of a plain copy/read kernel on the box") and the integer VALU
+    issue rate.  Returns a dict, or {} when the probe library is not there."""
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "micro", "libbox_probe.so")
+    if not os.path.exists(path):
+        return {}
+    lib = C.CDLL(path)
+    lib.box_stream_read_ms.restype = C.c_float
+    lib.box_stream_read_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.box_valu_issue.restype = C.c_double
+    lib.box_valu_issue.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+    nbytes = t_a.numel() * t_a.element_size()
+    best = None
+    for gpc, nt in ((2, 1), (2, 0), (8, 1)):
+        ms = lib.box_stream_read_ms(t_a.data_ptr(), t_b.data_ptr(), nbytes, 10, gpc, nt, C.c_void_p(stream))
+        if ms > 0 and (best is None or ms < best[0]):
+            best = (ms, gpc, nt)
+    out = {}
+    if best:
+        out.update(ceiling_gbs=2 * nbytes / best[0] / 1e6, ceiling_kernel_ms=best[0],
+                   ceiling_note=f"read-only streaming kernel over the same two {nbytes / 1e6:.1f} MB buffers, 16 B per lane and load, 8 loads in flight per lane, "
+                                f"{best[1]} x 256 threads per CU, {'nt' if best[2] else 'plain'} loads; best of three shapes, 10 passes each")
+    cyc, mhz = C.c_double(), C.c_double()
+    r = lib.box_valu_issue(0, 4, C.byref(cyc), C.byref(mhz), C.c_void_p(stream))
+    cyc2 = C.c_double()
+    r2 = lib.box_valu_issue(1, 4, C.byref(cyc2), C.byref(mhz), C.c_void_p(stream))
+    if r > 0:
+        out.update(valu_wave_inst_per_s_per_cu=r, valu_cycles_per_inst=cyc.value, valu_pk16_cycles_per_inst=cyc2.value if r2 > 0 else None, valu_clock_mhz=mhz.value)
+    torch.cuda.synchronize()
+    return out
+
+
 def profiled_traffic(tag_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*traffic.json, written
     by tools/profile_bench.sh + tools/traffic_json.py for exactly this workload), or None."""
@@ -577,6 +611,7 @@ def main():
         compulsory = args.nodes * node_bytes(V, words, not implicit) + 8 * V * min(args.nodes, per_step["narrowings"])
         tr = profiled_traffic({"n": n, "nodes_per_launch": args.nodes, "active": args.active})
         achieved = compulsory / (k_ms * 1e-3) / 1e9
+        box = box_ceilings(torch, pool[0][0], pool[0][1], stream) if world == 1 else {}
         out = {
             "metric": "propagator filter-steps/sec to fixpoint, N-queens-1000",
             "value": eval_all / dt_max,
@@ -622,6 +657,9 @@ def main():
                 "traffic_source": (tr or {}).get("source"),
                 "kernel": "pcp::neqfix_kernel" if plan.get("path") == 1 else "pcp::fixpoint_kernel", "kernel_ms": k_ms,
                 "compulsory_bytes_per_launch": compulsory,
+                "ceiling_gbs": box.get("ceiling_gbs"), "frac_of_ceiling": (achieved / box["ceiling_gbs"]) if box.get("ceiling_gbs") else None,
+                "ceiling_note": box.get("ceiling_note"),
+                "valu_cycles_per_wave_inst": box.get("valu_cycles_per_inst"), "valu_pk16_cycles_per_wave_inst": box.get("valu_pk16_cycles_per_inst"),
                 "model": "achieved = compulsory HBM bytes per launch (every node's lb/ub rows read once"
                          + ("" if implicit else " + its `active` row")
                          + ", the rows of changed nodes written once) / the kernel's average launch duration = HIP events around the K timed launches / K (kernel_ms); traffic = 2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 PMC passes, per launch",

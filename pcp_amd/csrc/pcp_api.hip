@@ -111,6 +111,7 @@ struct pcp_ctx {
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
+  int64_t opt_neq_stagger = 0;      // shader cycles by which the second workgroup of a CU delays its start in large all-XNeqY batches (pcp_neq.hip)
   int64_t opt_neq_hint = 1;         // 0 = pcp_device_batch.dirty_var is ignored (every node is propagated from scratch): A/B and parity tests
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
   int64_t opt_small_alldiff = 1;    // 1 = pcp_small.hip filters an all-different unit through its value mask, 0 = pair by pair
@@ -619,6 +620,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.violation = c->d_retry + 1; a.dbg = c->d_dbg;
   a.debug = (uint32_t)c->opt_neq_debug; a.trace = reinterpret_cast<unsigned long long*>(c->opt_neq_trace);
   a.lds_wgs = lds_wgs;
+  a.stagger = (c->opt_neq_persist && plan.grid > (uint32_t)c->num_cu && !c->dfs_sp) ? (uint32_t)c->opt_neq_stagger : 0u;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
@@ -901,6 +903,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;
+  } else if (k == "neq_stagger") {
+    if (value < 0 || value > 1000000) return fail(c, PCP_ERR_ARG, "neq_stagger must be in [0, 1000000] cycles");
+    c->opt_neq_stagger = value;
   } else if (k == "neq_hint") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_hint must be 0 or 1");
     c->opt_neq_hint = value;

@@ -53,6 +53,14 @@
 #ifndef PCP_PUT_FAST
 #define PCP_PUT_FAST 1
 #endif
+// A/B switches of two round-5 experiments (tools/build_neq_variant.py): the constant compared by exclusive-or instead of a second packed
+// add, and pieces shorter than 256 entries when a round walks few lists.
+#ifndef PCP_NEQ_XOR
+#define PCP_NEQ_XOR 1
+#endif
+#ifndef PCP_NEQ_PLEN
+#define PCP_NEQ_PLEN 0
+#endif
 
 namespace pcp {
 
@@ -131,23 +139,35 @@ __device__ __forceinline__ unsigned long long wave_sum64(uint32_t x) {
 
 __device__ __forceinline__ bool zero_half(uint32_t u) { return (u & 0xffffu) == 0u || (u >> 16) == 0u; }
 
-// cell(v) + swap(cell(o)) + (-t, t): a half is zero iff lb(v) + t == ub(o) (low) or ub(v) + t == lb(o) (high)
+// (cell(v) + swap(cell(o))) ^ (t, -t): a half is zero iff lb(v) + t == ub(o) (low) or ub(v) + t == lb(o) (high).  The constant is
+// compared by an exclusive-or, not added: v_pk_add_u16 issues at half the rate of a 32-bit VALU operation on gfx950 (4.6 against 2.5
+// cycles per wave instruction with four wavefronts per SIMD, tools/micro/box_probe.hip), v_xor_b32 at full rate.
 __device__ __forceinline__ uint32_t neq_terms16(uint32_t cv, uint32_t co, uint32_t k) {
   uint32_t u;
+#if PCP_NEQ_XOR
+  asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(u) : "v"(cv), "v"(co));
+  return u ^ k;
+#else
   asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
       "v_pk_add_u16 %0, %0, %3"
       : "=&v"(u) : "v"(cv), "v"(co), "v"(k));
   return u;
+#endif
 }
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y) {
   uint32_t r;
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
-// (-t, t) as two int16 halves; |t| beyond the packed range can never meet a sum of two packed bounds: clamp (pack_c0's argument)
+// (t, -t) as two int16 halves — what the halves of cell(v) + swap(cell(o)) are compared with; |t| beyond the packed range can never meet a
+// sum of two packed bounds: clamp (pack_c0's argument)
 __device__ __forceinline__ uint32_t pack_mt(int t) {
   const int tc = max(-32767, min(32767, t));
-  return ((uint32_t)(-tc) & 0xffffu) | ((uint32_t)tc << 16);
+#if PCP_NEQ_XOR
+  return ((uint32_t)tc & 0xffffu) | ((uint32_t)(-tc) << 16);
+#else
+  return ((uint32_t)(-tc) & 0xffffu) | ((uint32_t)tc << 16);  // (added, not compared: (-t, t))
+#endif
 }
 
 template <bool PACKED> struct NeqCell { using type = int2; };
@@ -288,6 +308,18 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (sp == 0 || *a.stop_ptr) return;
     const size_t off = (size_t)(sp - 1) * a.m.n_vars;
     a.lb_in += off; a.ub_in += off; a.lb_out += off; a.ub_out += off; a.status += sp - 1;
+  }
+  if constexpr (!DFS) {
+    // Two workgroups share a CU and start together: they stage together (every CU of the chip at once: HBM saturated), then compute
+    // together (HBM idle).  The one in the CU's second pair of wave slots may start late, so that one streams while the other computes.
+    if (a.stagger) {
+      uint32_t hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      if ((hw & 15u) >= 2u) {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (uint64_t)a.stagger) __builtin_amdgcn_s_sleep(16);
+      }
+    }
   }
   using Cell = typename NeqCell<PACKED>::type;
   using TDom = typename TileDomOf<PACKED>::type;
@@ -754,9 +786,21 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     // would wait for the load it copies).
     {
       struct Piece { uint32_t v, M, aoff, deg, k0, wsel; };
-      const uint32_t k_step = nwv * 64 * U4;
+      // The length of a piece: 4 x 64 entries, or — when the round walks so few lists that whole pieces per wavefront do not come out even —
+      // fewer: one list of 2997 entries (a frontier tile: the one queen its nodes have in common) is 12 pieces of 256 for 8 wavefronts,
+      // i.e. two rounds of pieces with half of the wavefronts idle in the second, but 16 pieces of 192: two even rounds, a quarter less time.
+      uint32_t plen = 64u * U4;
+      if (PCP_NEQ_PLEN && !one_piece && total <= 4u) {
+        uint32_t work = 0;
+        for (uint32_t e_ = 0; e_ < total; ++e_) work += list[e_].z;
+        work = (uint32_t)__builtin_amdgcn_readfirstlane(work);
+        const uint32_t per = nwv * 64u * U4, r = (work + per - 1u) / per;  // rounds of pieces at full length
+        if (r) plen = min(64u * U4, 64u * ((work + 64u * nwv * r - 1u) / (64u * nwv * r)));
+      }
+      const uint32_t nu = plen >> 6;  // payload loads / entries per lane of a piece (wave-uniform)
+      const uint32_t k_step = nwv * plen;
       const uint32_t e_step = one_piece ? nwv : 1u;
-      auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * 64 * U4; };
+      auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * plen; };
       uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
       // the next piece of this wavefront (deg == 0: none left; its loads then read entry 0 of list 0 and are ignored)
       auto next_piece = [&]() -> Piece {
@@ -776,6 +820,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       auto load = [&](const Piece& pc, Pay (&q)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+          if ((uint32_t)u >= nu) { q[u] = q[0]; continue; }  // (a short piece: entry 0's payload stands in, masked off below)
           const uint32_t idx = pc.k0 + u * 64 + lane;
           q[u] = pay[pc.aoff + (idx < pc.deg ? idx : 0u)];
         }
@@ -790,7 +835,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         bool valid[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          valid[u] = pc.k0 + u * 64 + lane < pc.deg;
+          valid[u] = (uint32_t)u < nu && pc.k0 + u * 64 + lane < pc.deg;
           other[u] = pay_other(q[u]);
           t[u] = pay_t(q[u]);  // v is the record's y: x != v + d  <=>  o != v + d (t = d);  v is x: o != v - d (t = -d)
         }
@@ -816,9 +861,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
               const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0);
               uint4 o0[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
+              for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
+                if ((uint32_t)u >= nu) continue;  // (a short piece)
                 uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
                 uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
                 acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
@@ -832,9 +878,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
               const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0), c1 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g1);
               uint4 o0[4], o1[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
+              for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
+                if ((uint32_t)u >= nu) continue;
                 uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
                 uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
                 uint32_t m2 = pk_min_u16(neq_terms16(c1.x, o1[u].x, K[u]), neq_terms16(c1.y, o1[u].y, K[u]));

@@ -24,7 +24,7 @@ for d in (500, 3000):
         batches[f"deep{d}"] = (lb, ub)
 
 def timeit(lb, ub, opts, reps=5):
-    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, "neq_wgs": 2, "neq_persist": 1, "neq_prefetch": 0, **opts}.items():
+    for k, v in {"nodes_per_block": 0, "neq_block": 0, "neq_debug": 0, "neq_path": 1, "neq_wgs": 2, "neq_persist": 1, **opts}.items():
         ctx.set_option(k, v)
     N = lb.shape[0]
     st = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -60,7 +60,7 @@ def timeit(lb, ub, opts, reps=5):
         print(f"    timers (round 0, per wavefront avg): walk {s['steps3']/nw:.0f} ticks, node loops {s['failed_nodes']/nw:.0f} ticks, pieces {(s['waves']-N)/nw:.1f}; evaluated {s['evaluated']:.3e}")
     return float(np.median(ms)), pl
 
-configs = [{}, {"neq_persist": 0}, {"neq_debug": 1}, {"neq_debug": 2}, {"neq_debug": 3}, {"neq_debug": 4}, {"neq_prefetch": 1}, {"neq_wgs": 1}]
+configs = json.loads(os.environ["NEQ_CONFIGS"]) if "NEQ_CONFIGS" in os.environ else [{}, {"neq_persist": 0}, {"neq_debug": 1}, {"neq_debug": 2}, {"neq_debug": 3}, {"neq_debug": 4}, {"neq_wgs": 1}]
 if "frontier" in batches:  # one generation of tiles only (512 tiles = two per CU): what the first wave of workgroups costs by itself
     l8, u8 = batches["frontier"]
     batches["frontier-half"] = (l8[:8192].contiguous(), u8[:8192].contiguous())
