@@ -154,6 +154,16 @@ __device__ __forceinline__ uint32_t neq_terms16(uint32_t cv, uint32_t co, uint32
   return u;
 #endif
 }
+// The cell an entry's other side must MATCH in one half, when the walked variable's cell cv = (-lb(v), ub(v)) is the same in every node
+// tested: T = (-(ub(v) + t), lb(v) + t) = -((t, -t) + swap(cv)) per half: cell(o).lo == T.lo <=> lb(o) == ub(v) + t, cell(o).hi == T.hi <=>
+// ub(o) == lb(v) + t.  Computed once per ENTRY; the (entry, node) test is then one exclusive-or and one packed minimum.
+__device__ __forceinline__ uint32_t neq_target16(uint32_t cv, uint32_t k) {
+  uint32_t u;
+  asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_sub_u16 %0, 0, %0"
+      : "=&v"(u) : "v"(k), "v"(cv));
+  return u;
+}
 __device__ __forceinline__ uint32_t pk_min_u16(uint32_t x, uint32_t y) {
   uint32_t r;
   asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
@@ -285,6 +295,98 @@ __device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type*
       row[w] = (uint32_t)(bal >> (32u * lane)) | keep;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Staging of a FULL tile (16 nodes, 16-bit cells, whole 16-byte quads, aligned rows) — the frontier launch's dominant phase by
+// instructions: 59 % of its VALU and 67 % of its SALU wave-instructions were staging (profiles/r05_phases_*: 100 VALU + 73 SALU per
+// wave-task of 64 row quads, most of them predicates, address arithmetic and scalars spilled into VGPR lanes by the pressure of the
+// kernel around the loop).  This function is the same loop with nothing around it: out of line, so that it has its own register
+// allocation; no lane predicate at all — a full tile has no ragged node, and the quads beyond the row's end in the last chunk of 16 are
+// CLAMPED to the row's last quad (those lanes load and write the last quad's cells a second time: same values, same addresses);
+// a wave-task's row offset is a scalar (buffer_load soffset), its LDS offset a scalar added to a per-lane constant.
+// Semantics of the kernel's `put` (fast path and its rare branch) exactly; returns bad | oob << 16 (bit b = node b).
+// A wave-task = FOUR nodes x SIXTEEN consecutive quads (see the kernel: the cells a wavefront writes per store fall on all LDS banks).
+struct StageTile16Args {
+  const int32_t* lb;            // the tile's rows: [16][V], 16-byte aligned
+  const int32_t* ub;
+  const uint32_t* seed_always;  // or null
+  uint32_t V, Wv;
+  uint32_t dom_off, chg_off, vmk_off, list_off, misc_off;  // byte offsets into the workgroup's dynamic LDS
+  uint32_t hintm;               // nodes that came with a dirty-variable hint: their assigned variables are not marked
+  uint32_t r0_direct;           // round 0's list is built here (vmk masks, up to kR0Cap variables)
+  uint32_t wv, nwv;
+};
+__device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int UF = 8;
+  constexpr int lim = kPackedMax;
+  const uint32_t lane = threadIdx.x & 63u, lb4 = lane >> 4, lq = lane & 15u;
+  const uint32_t V = g.V, SQ = V >> 2, QC = (SQ + 15u) >> 4, WT = 4u * QC;
+  const uint32_t lq_last = min(lq, SQ - 1u - 16u * (QC - 1u));  // the last chunk of a row may hold fewer than 16 quads
+  const uint32_t vo_full = lb4 * V * 4u + 16u * lq, vo_last = lb4 * V * 4u + 16u * lq_last;      // row bytes: node lb4 of the group, quad lq of the chunk
+  const uint32_t do_full = g.dom_off + lq * 272u + lb4 * 4u, do_last = g.dom_off + lq_last * 272u + lb4 * 4u;  // cell bytes: row(4 q) = 68 q words
+  uint32_t* const chg = reinterpret_cast<uint32_t*>(smem_ + g.chg_off);
+  uint32_t* const vmk = reinterpret_cast<uint32_t*>(smem_ + g.vmk_off);
+  uint4* const list = reinterpret_cast<uint4*>(smem_ + g.list_off);
+  uint32_t* const misc = reinterpret_cast<uint32_t*>(smem_ + g.misc_off);
+  const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(g.lb), 0, (int)(16u * V * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(g.ub), 0, (int)(16u * V * 4u), 0x00020000);
+  const uint32_t dqc = g.nwv % QC, dng = g.nwv / QC;
+  uint32_t ng = g.wv / QC, qc = g.wv - ng * QC;  // (wave-uniform: scalar registers)
+  uint32_t badm = 0, oobm = 0;
+  for (uint32_t w0 = g.wv; w0 < WT; w0 += UF * g.nwv) {
+    u32x4 L[UF], U[UF];
+    uint32_t ngj[UF], qcj[UF];
+#pragma unroll
+    for (int j = 0; j < UF; ++j) {
+      ngj[j] = ng; qcj[j] = qc;
+      if (w0 + j * g.nwv < WT) {  // (uniform)
+        const uint32_t so = ng * (16u * V) + qc * 256u, vo = qc == QC - 1u ? vo_last : vo_full;
+        L[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)vo, (int)so, 0);
+        U[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)vo, (int)so, 0);
+      }
+      qc += dqc; ng += dng;
+      if (qc >= QC) { qc -= QC; ++ng; }
+    }
+#pragma unroll
+    for (int j = 0; j < UF; ++j) {
+      if (w0 + j * g.nwv >= WT) break;  // (uniform)
+      const bool lastc = qcj[j] == QC - 1u;
+      const int l0 = (int)L[j].x, l1 = (int)L[j].y, l2 = (int)L[j].z, l3 = (int)L[j].w, u0 = (int)U[j].x, u1 = (int)U[j].y, u2 = (int)U[j].z, u3 = (int)U[j].w;
+      const int mn = min(min(min(l0, l1), min(l2, l3)), min(min(u0, u1), min(u2, u3)));
+      const int mx = max(max(max(l0, l1), max(l2, l3)), max(max(u0, u1), max(u2, u3)));
+      const int dmin = min(min(u0 - l0, u1 - l1), min(u2 - l2, u3 - l3));
+      uint32_t* const p0 = reinterpret_cast<uint32_t*>(smem_ + ((lastc ? do_last : do_full) + qcj[j] * (16u * 272u) + ngj[j] * 16u));
+      p0[0] = __builtin_amdgcn_perm((uint32_t)u0, (uint32_t)(-l0), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
+      p0[16] = __builtin_amdgcn_perm((uint32_t)u1, (uint32_t)(-l1), 0x05040100u);
+      p0[32] = __builtin_amdgcn_perm((uint32_t)u2, (uint32_t)(-l2), 0x05040100u);
+      p0[48] = __builtin_amdgcn_perm((uint32_t)u3, (uint32_t)(-l3), 0x05040100u);
+      // everything else is ONE rarely taken branch: a bound out of range (the node is refused), an empty domain (failed), a singleton (an
+      // assigned variable: marked for the sweep round) or a model with Constant neighbours
+      if (((mn < -lim) | (mx > lim) | (dmin <= 0)) || g.seed_always) {
+        const uint32_t b = 4u * ngj[j] + lb4, v0 = 4u * (16u * qcj[j] + (lastc ? lq_last : lq));
+        uint32_t nib = (l0 == u0 ? 1u : 0u) | (l1 == u1 ? 2u : 0u) | (l2 == u2 ? 4u : 0u) | (l3 == u3 ? 8u : 0u);
+        if (g.seed_always) nib |= (g.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
+        if ((g.hintm >> b) & 1u) nib = 0;
+        if (nib) atomicOr(&chg[b * g.Wv + (v0 >> 5)], nib << (v0 & 31u));
+        if (g.r0_direct && misc[N_R0OVF] == 0u) {
+          for (uint32_t m = nib; m; m &= m - 1u) {
+            const uint32_t v = v0 + (uint32_t)__builtin_ctz(m), hs = 16u * (v & 1u);
+            const uint32_t old = atomicOr(&vmk[v >> 1], (1u << b) << hs);
+            if (((old >> hs) & 0xffffu) == 0u) {  // the first node of the tile with this variable: it goes on the list
+              const uint32_t pos = atomicAdd(&misc[N_COUNT0], 1u);
+              if (pos < kR0Cap) list[pos].x = v; else misc[N_R0OVF] = 1u;
+            }
+          }
+        }
+        if ((mn < -lim) | (mx > lim)) oobm |= 1u << b;
+        if (dmin < 0) badm |= 1u << b;
+      }
+    }
+  }
+  return badm | (oobm << 16);
 }
 
 // DFS = true: ONE workgroup runs the reference's search loop itself (pcp_dfs_device) — OneSolution / AllSolution over
@@ -578,6 +680,14 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
           }
         };
         uint32_t ngs = ng_first, qcs = qc_first;
+        if (PACKED && BT == 16 && nb == 16u && !(a.debug & 32768u)) {
+          // a full tile: the lean loop (stage_tile16), out of line
+          store_adj();
+          const uint32_t r = stage_tile16(StageTile16Args{a.lb_in + (size_t)node0 * V, a.ub_in + (size_t)node0 * V, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
+                                                          (uint32_t)cv.vmk, (uint32_t)cv.list, (uint32_t)(reinterpret_cast<unsigned char*>(misc) - smem), hintm,
+                                                          r0_direct ? 1u : 0u, wv_s, nwv_s});
+          badm |= r & 0xffffu; oobm |= r >> 16;
+        } else
         for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
           int4 L[UF], U[UF];
           loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
@@ -855,6 +965,48 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
             // tested along: they can only raise a flag that the full-filter pass below, which walks the mask, ignores
             uint32_t qm = 0;
             for (uint32_t g = 0; g < (B >> 2); ++g) qm |= ((pc.M >> (4 * g)) & 0xFu) ? 1u << g : 0u;
+#if PCP_NEQ_XOR
+            // The walked variable has the SAME cell in every node of these quads — the rule, not the exception: the nodes of a tile are
+            // neighbours in the search tree and hold the queens of their common ancestors at the same values.  Then what an entry's other
+            // side must match is a property of the entry alone (neq_target16), and an (entry, node) test is one exclusive-or and one
+            // packed minimum instead of a packed add on top (v_pk_* issue at half rate: tools/micro/box_probe.hip).
+            const uint32_t cvu = dom[rv + 4u * (uint32_t)__builtin_ctz(qm)];
+            uint32_t differ = 0;
+            for (uint32_t qq = qm; qq; qq &= qq - 1u) {
+              const uint4 c = *reinterpret_cast<const uint4*>(dom + rv + 4u * (uint32_t)__builtin_ctz(qq));
+              differ |= (c.x ^ cvu) | (c.y ^ cvu) | (c.z ^ cvu) | (c.w ^ cvu);
+            }
+            if (__builtin_amdgcn_readfirstlane(differ) == 0u) {  // (every lane read the same cells: wave-uniform)
+              uint32_t T[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) T[u] = neq_target16(cvu, K[u]);
+              if (__popc(qm) & 1) {
+                const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+                qm &= qm - 1;
+                uint4 o0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                  acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u])));
+              }
+              while (qm) {
+                const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+                qm &= qm - 1;
+                const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
+                qm &= qm - 1;
+                uint4 o0[4], o1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  const uint32_t m0 = pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u]));
+                  const uint32_t m1 = pk_min_u16(pk_min_u16(o1[u].x ^ T[u], o1[u].y ^ T[u]), pk_min_u16(o1[u].z ^ T[u], o1[u].w ^ T[u]));
+                  acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
+                }
+              }
+            }
+#endif
             if (__popc(qm) & 1) {  // an odd quad out, by itself
               const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
               qm &= qm - 1;

@@ -95,7 +95,7 @@ def test_hinted_children_of_random_models(ctx, seed, hull):
         assert_parity(ref[:4], off[:4], f"children, hints ignored npb={npb}")
         assert off[4]["evaluated"] > hinted[4]["evaluated"] or hinted[4]["evaluated"] == plain[4]["evaluated"]  # (counts vary a little with the schedule: never compared exactly)
     ctx.set_option("nodes_per_block", 0); ctx.set_option("neq_block", 0); ctx.set_option("small_path", 1)
-    assert (ref[3] == 0).any() and (ref[3] == 2).any()
+    assert (ref[3] == 2).any()
 
 
 def test_hinted_nqueens_1000_deep_nodes(ctx):

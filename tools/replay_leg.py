@@ -20,8 +20,6 @@ ctx = E.Context(0)
 
 def nq():
     ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
-    if os.environ.get("PCP_NEQ_WAVE"):  # the two-pass launch (off by default), for profiling it
-        ctx.set_option("neq_wave", int(os.environ["PCP_NEQ_WAVE"]))
 
 
 def launches(lb, ub, act, k):
@@ -109,5 +107,8 @@ else:
         sys.exit(0)
     else:
         raise SystemExit(nm)
+    for kv in filter(None, os.environ.get("PCP_OPTS", "").split(",")):  # e.g. PCP_OPTS=neq_debug=3,neq_stagger=8000 — for the timed launches only
+        k_, v_ = kv.split("=")
+        ctx.set_option(k_, int(v_))
     ms, pl = launches(lb, ub, act, k)
     print(json.dumps({"leg": nm, "kernel_ms": ms, "median_ms": float(np.median(ms)), "plan": pl}))
