@@ -108,6 +108,21 @@ def box_ceilings(torch, t_a, t_b, stream):
     return out
 
 
+def profiled_valu():
+    """VALU wave-instructions per launch of the compute-bound legs from the committed rocprofv3 PMC passes (profiles/*valu_counts.json,
+    tools/valu_json.py), newest file; {} when there is none."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*valu_counts.json")))
+    if not files:
+        return {}
+    try:
+        d = json.load(open(files[-1]))
+        d["_file"] = os.path.relpath(files[-1], ROOT)
+        return d
+    except (OSError, ValueError):
+        return {}
+
+
 def profiled_traffic(tag_key):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*traffic.json, written
     by tools/profile_bench.sh + tools/traffic_json.py for exactly this workload), or None."""
@@ -717,6 +732,24 @@ def main():
         put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
         put_k("forest_chk", "C5-interval-forest", "parity_checked_nodes"); put_k("setf_chk", "C2-set-mode-device-search", "parity_checked_nodes")
         put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
+        # The legs that HBM does not bound get their roofline against the bound they do have: integer VALU issue.  <leg>_vfrac = VALU
+        # wave-instructions per launch (committed PMC pass of the same launch, profiles/*valu_counts.json) / this run's launch time / (the VALU
+        # issue rate measured on this box just now x CUs).  1.0 would be every SIMD issuing a VALU instruction whenever it can.
+        pv = profiled_valu()
+        rate = box.get("valu_wave_inst_per_s_per_cu") if world == 1 else None
+        if pv and rate:
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            def put_v(key, prof_leg, ms):
+                if prof_leg in pv and ms and pv[prof_leg].get("valu_per_launch"):
+                    flat[key] = float(f"{pv[prof_leg]['valu_per_launch'] / (ms * 1e-3) / (rate * ncu):.3g}")
+            put_v("hl_vfrac", "frontier", k_ms)
+            for key, prof_leg, name in (("mix_vfrac", "mix", "MIX-nodes-along-the-dfs"), ("d500_vfrac", "deep500", "C2-deep-dive-500"), ("d3000_vfrac", "deep3000", "C2-deep-dive-3000"),
+                                        ("c3_vfrac", "c3", "C3-random-binary-csp-50k-vars-500k-props"), ("c4_vfrac", "c4", "C4-golomb-distinct-sum-network")):
+                if name in by and isinstance(by[name].get("kernel_ms"), dict):
+                    put_v(key, prof_leg, by[name]["kernel_ms"]["median"])
+            out["roofline"]["valu_bound_note"] = (f"*_vfrac keys in config: bound 'valu' — VALU wave-instructions per launch from {pv.get('_file')} over this run's launch time, against "
+                                                  f"{rate:.3e} wave-instructions/s/CU x {ncu} CUs measured on this box (v_add_u32, four wavefronts per SIMD: {box.get('valu_cycles_per_inst'):.2f} SIMD cycles "
+                                                  f"per instruction at the reported clock; v_pk_add_u16: {box.get('valu_pk16_cycles_per_inst') or 0:.2f})")
     # ---- --gpus N > 1: the config-5 legs that exercise RCCL, AFTER the headline record is complete and under a watchdog: if a rank fails or a
     # collective hangs (this path cannot be run on more than one GPU where it was written), rank 0 still prints the headline line, with
     # `c5_error` in place of the c5 keys, and every rank leaves.

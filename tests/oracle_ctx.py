@@ -26,6 +26,8 @@ class OracleDeviceCtx(OracleCtx):
     def __init__(self, n_vars, props):
         super().__init__(n_vars, props)
         self.device = "cpu"
+        self.supports_hints = True  # (the engine's pcp_device_batch.dirty_var: DeviceSearch then keeps a hint row per open node and the drivers move it along)
+        self.hints_seen = 0
         self._opts = {}
         self._stats = {"steps": 0, "steps3": 0, "narrowings": 0, "nodes": 0, "evaluated": 0, "full_evals": 0, "waves": 0, "failed_nodes": 0}
 
@@ -39,7 +41,13 @@ class OracleDeviceCtx(OracleCtx):
     def stats_read(self, stream=0):
         return dict(self._stats)
 
-    def propagate_device(self, n, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream=0, bits_in=None, bits_out=None):
+    def propagate_device(self, n, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream=0, bits_in=None, bits_out=None, dirty=None):
+        if dirty is not None:
+            # a hint must name a variable of the node (or none: -1) and — the promise — giving that variable back its parent's bound must
+            # leave a fixpoint; the oracle ignores hints (same results by definition), the stand-in only checks their form
+            d = dirty[:n].numpy()
+            assert ((d == -1) | ((d >= 0) & (d < self.n_vars))).all(), d
+            self.hints_seen += int((d >= 0).sum())
         L, U = lb_in[:n].numpy().copy(), ub_in[:n].numpy().copy()
         A = None if active_in is None else active_in[:n].numpy().view(np.uint64).copy()
         bad = (L > U).any(axis=1)  # the device entry reports an empty input domain as a failed node
@@ -55,7 +63,7 @@ class OracleDeviceCtx(OracleCtx):
         self._stats["steps"] += s["steps"]
         self._stats["nodes"] += n
 
-    def branch_device(self, n, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream=0):
+    def branch_device(self, n, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream=0, child_dirty=None):
         import torch
         from pcp_amd import search as S
         st = status[:n].numpy()
@@ -68,6 +76,13 @@ class OracleDeviceCtx(OracleCtx):
             if self._opts.get("branch_reverse"):
                 cl, cu, ca = cl[::-1].copy(), cu[::-1].copy(), (None if ca is None else ca[::-1].copy())
             k = cl.shape[0]
+            if child_dirty is not None:  # the variable each child was branched on: where it differs from its parent's (propagated) row
+                pl_, pu_ = np.repeat(L, 2, axis=0), np.repeat(U, 2, axis=0)
+                if self._opts.get("branch_reverse"):
+                    pl_, pu_ = pl_[::-1], pu_[::-1]
+                diff = (cl != pl_) | (cu != pu_)
+                assert (diff.sum(axis=1) == 1).all()
+                child_dirty[:k] = torch.from_numpy(diff.argmax(axis=1).astype(np.int32))
             child_lb[:k] = torch.from_numpy(cl)
             child_ub[:k] = torch.from_numpy(cu)
             if ca is not None:

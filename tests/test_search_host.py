@@ -202,7 +202,7 @@ def test_two_rank_device_search_gloo(implicit):
     (r0, tot0, n0, x0, mb0, rb0, _), (r1, tot1, n1, x1, mb1, rb1, _) = res
     assert tot0 == tot1 and tot0[:3] == (779, 92, 298)   # nodes, solutions, failures of the reference's tree (all_solution.rs:70)
     assert tot0[4] > 0 and n0 > 0 and n1 > 0 and n0 + n1 == 779 and x0 == x1 > 1
-    assert rb0 == rb1 == 8 * 8 + (0 if implicit else 8 * ((3 * 28 + 63) // 64)) and mb0 + mb1 == tot0[4] * rb0  # only whole records moved
+    assert rb0 == rb1 == 8 * 8 + (4 if implicit else 8 * ((3 * 28 + 63) // 64)) and mb0 + mb1 == tot0[4] * rb0  # only whole records moved (implicit nodes: the bounds + the 4-byte dirty-variable hint)
 
 
 @pytest.mark.parametrize("n,batch", [(8, 4), (9, 8)])
@@ -228,7 +228,7 @@ def test_four_rank_device_search_gloo(n, batch):
     tot = res[0][1]
     assert tot[:3] == (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
     assert sum(r[2] for r in res) == ss["num_nodes"] and all(r[2] > 0 for r in res)
-    assert tot[4] > 0 and sum(r[4] for r in res) == tot[4] * res[0][5] and res[0][5] == 8 * n
+    assert tot[4] > 0 and sum(r[4] for r in res) == tot[4] * res[0][5] and res[0][5] == 8 * n + 4  # (bounds + the dirty-variable hint)
     share = max(r[6] for r in res)
     print(f"exchange seconds (max over ranks) {share:.3f} over {res[0][3]} exchanges, {tot[4]} records moved")
 
