@@ -730,6 +730,7 @@ def main():
         put_ms("set_ms", "C2-set-mode-IntervalSet-frontier"); put_k("set_frac", "C2-set-mode-IntervalSet-frontier", "hbm_frac", 3)
         put_ms("expl_ms", "C2-frontier-explicit-active-rows"); put_k("expl_frac", "C2-frontier-explicit-active-rows", "hbm_frac", 3)
         put_k("forest_nps", "C5-interval-forest", "nodes_per_s"); put_k("setforest_nps", "C2-set-mode-device-search", "nodes_per_s")
+        put_k("forest8k_nps", "C5-interval-forest-8192-trees", "nodes_per_s")
         put_k("forest_chk", "C5-interval-forest", "parity_checked_nodes"); put_k("setf_chk", "C2-set-mode-device-search", "parity_checked_nodes")
         put_k("dfs_us_node", "C2-dfs-256-device-side-stack", "us_per_node"); put_k("c2_us_node", "C2-dfs-256-one-node-per-call", "us_per_node")
         # The legs that HBM does not bound get their roofline against the bound they do have: integer VALU issue.  <leg>_vfrac = VALU
@@ -941,6 +942,17 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
             except AssertionError as e:
                 raise SystemExit(f"PARITY FAILURE (interval forest leg): {e}")
             del rl, ru
+        # the same engine at the operating point of `--mode search`: 2 M nodes, 8192 trees (128-thread trees, eight to a CU)
+        capw = -(-2_000_000 // 8192) + 64
+        forest_search(ctx, lb0, ub0, node_limit=100_000, n_trees=8192, steps_per_launch=8, capacity=capw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fw = forest_search(ctx, lb0, ub0, node_limit=2_000_000, n_trees=8192, steps_per_launch=256, capacity=capw)
+        torch.cuda.synchronize()
+        dtw = time.perf_counter() - t0
+        legs.append({"name": "C5-interval-forest-8192-trees", "nodes": fw["nodes"], "seconds": dtw, "us_per_node": dtw / fw["nodes"] * 1e6, "nodes_per_s": fw["nodes"] / dtw,
+                     "trees": fw["trees"], "launches": fw["launches"], "error": fw["error"], "plan": {k: v for k, v in ctx.last_plan().items() if k in ("block", "grid", "lds_bytes", "packed")},
+                     "note": "pcp_dfs_forest_device: first 2 000 000 nodes, 8192 trees of 128 threads (eight to a CU), 256 nodes per tree and launch; the timed region includes the expansion"})
         legs.append({"name": "C5-interval-forest", "nodes": fr["nodes"], "seconds": dt, "us_per_node": dt / fr["nodes"] * 1e6, "nodes_per_s": fr["nodes"] / dt,
                      "trees": fr["trees"], "launches": fr["launches"], "error": fr["error"], "parity_checked_nodes": checked,
                      "note": "pcp_dfs_forest_device: first 500 000 nodes, 2048 trees of 256 threads, 256 nodes per tree and launch; the timed region includes the expansion"})

@@ -90,7 +90,7 @@ def check_interval_forest(ctx, om, root_lb, root_ub, K: int, capacity: int = 64,
         ctx._check(ctx._L.pcp_dfs_forest_device(ctx._h, C.byref(st), T, steps, 0, 0, None))
         torch.cuda.synchronize()
         pl = ctx.last_plan()
-        want = (1, 1, 0, T, expect_block) if T > 1 else (1, 1, 0, 1, pl["block"])
+        want = (1, 1, 0, T, expect_block if expect_block else pl["block"]) if T > 1 else (1, 1, 0, 1, pl["block"])
         assert (pl["path"], pl["nodes_per_block"], pl["packed"], pl["grid"], pl["block"]) == want, f"forest launch off the measured shape: {pl}"
 
     # ---- stepwise: one node per launch -------------------------------------------------------------------------------------------

@@ -111,6 +111,7 @@ struct pcp_ctx {
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
+  int64_t opt_neq_dfs_wgs = 0;      // trees meant to share a CU's LDS in the in-kernel search loop (sizes the jump-window area): 0 = auto (4 in a forest, 2 for one tree)
   int64_t opt_neq_stagger = 0;      // shader cycles by which the second workgroup of a CU delays its start in large all-XNeqY batches (pcp_neq.hip)
   int64_t opt_neq_hint = 1;         // 0 = pcp_device_batch.dirty_var is ignored (every node is propagated from scratch): A/B and parity tests
   int64_t opt_neq_dfs = 1;          // 1 = pcp_dfs_device on an all-XNeqY model runs the whole search loop in one workgroup, 0 = one launch per step
@@ -903,6 +904,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;
+  } else if (k == "neq_dfs_wgs") {
+    if (value < 0 || value > 8) return fail(c, PCP_ERR_ARG, "neq_dfs_wgs must be in [0,8]");
+    c->opt_neq_dfs_wgs = value;
   } else if (k == "neq_stagger") {
     if (value < 0 || value > 1000000) return fail(c, PCP_ERR_ARG, "neq_stagger must be in [0, 1000000] cycles");
     c->opt_neq_stagger = value;
@@ -910,7 +914,7 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_hint must be 0 or 1");
     c->opt_neq_hint = value;
   } else if (k == "neq_dfs_block") {
-    if (value != 0 && value != 256 && value != 512) return fail(c, PCP_ERR_ARG, "neq_dfs_block must be 0, 256 or 512");
+    if (value != 0 && value != 128 && value != 256 && value != 512) return fail(c, PCP_ERR_ARG, "neq_dfs_block must be 0, 128, 256 or 512");
     c->opt_neq_dfs_block = value;
   } else if (k == "neq_dfs") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "neq_dfs must be 0 or 1");
@@ -1376,7 +1380,14 @@ static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_tr
   // 32-bit cells: a one-node tile has LDS to spare, and the 16-bit-cell instantiation of the search loop needs 147 VGPRs — one
   // 512-thread workgroup per CU — where this one needs 115: two trees per CU in a forest, no scratch either way
   const bool packed = false;
-  const size_t lds = lds_bytes_neq(S, V, 1, packed, 2);
+  // A forest shares a CU among FOUR trees (the kernel's 127 VGPRs allow four wavefronts per SIMD = four 256-thread trees; the jump windows
+  // get what is left of a quarter of the LDS), one tree alone keeps half a CU's LDS for its windows.  (Option "neq_dfs_wgs" overrides.)
+  // Measured on N-queens-1000, first 2 M nodes (tools: PCP_SET_OPTIONS=... bench.py --mode search): 4 096 trees 2 x 256 threads per CU
+  // (round 4) 4.3e7 nodes/s, 4 x 256 5.2e7, 8 x 128 5.6e7; 8 192 trees: 4 x 256 6.0e7, 8 x 128 7.2e7; 2 048 trees: 4 x 256 4.2e7, 8 x 128 3.5e7 —
+  // a tree is a latency chain, so a CU wants as many of them as its registers allow, and narrower trees once there are enough of them.
+  const bool many = n_trees >= 16u * (uint32_t)c->num_cu;
+  const uint32_t wgs = c->opt_neq_dfs_wgs ? (uint32_t)c->opt_neq_dfs_wgs : (n_trees > 1 ? (many ? 8u : 4u) : 2u);
+  const size_t lds = lds_bytes_neq(S, V, 1, packed, wgs);
   if (!lds || lds > c->lds_max || !n_steps) return 0;
   NeqArgs a;
   memset(&a, 0, sizeof(a));
@@ -1384,12 +1395,12 @@ static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_tr
   a.m.n_recs = (uint32_t)c->props.size(); a.m.n_vars = V; a.m.n_slots = S; a.m.uniform_kind = c->uniform_kind; a.m.max_deg = c->max_deg;
   a.seed_always = c->have_seed_always ? c->d_seed_always : nullptr;
   a.adjp4 = c->have_adjp4 ? c->d_adjp4 : nullptr;
-  a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.lds_wgs = 2;
+  a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.lds_wgs = wgs;
   a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
   a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
   a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
   LaunchPlan plan;
-  plan.grid = n_trees; plan.block = c->opt_neq_dfs_block ? (uint32_t)c->opt_neq_dfs_block : (n_trees > 1 ? 256u : 512u); plan.lds_bytes = lds;
+  plan.grid = n_trees; plan.block = c->opt_neq_dfs_block ? (uint32_t)c->opt_neq_dfs_block : (n_trees > 1 ? (many ? 128u : 256u) : 512u); plan.lds_bytes = lds;
   c->last_plan = pcp_plan{1u, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, n_trees, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
   if (c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_neqfix(a, plan, stream));

@@ -155,6 +155,9 @@ class Context:
         self.n_units = 0
         self.set_words = 0
         self.supports_hints = True  # pcp_device_batch.dirty_var / pcp_branch_device_hint (ABI v7): search drivers keep a hint per open node
+        for kv in filter(None, os.environ.get("PCP_SET_OPTIONS", "").split(",")):  # experiments: pcp_set_option on every new context (k=v,k=v)
+            k_, v_ = kv.split("=")
+            self.set_option(k_, int(v_))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -39,6 +39,23 @@ def test_interval_forest_node_for_node(env):
     assert checked == 2 * 8 * 12
 
 
+def test_interval_forest_narrow_trees(env):
+    """The shape a forest of 4096 or more trees takes (128-thread trees, eight to a CU: pcp_api.hip launch_neq_dfs), forced here on 8 trees by
+    option, node for node as above."""
+    from pcp_amd.search_forest import seed_roots_interval
+    ctx, om, props = env
+    ctx.set_model(N, props)
+    ctx.set_hull(1, N)
+    lb0, ub0 = np.ones(N, np.int32), np.full(N, N, np.int32)
+    rl, ru, st = seed_roots_interval(ctx, lb0, ub0, 8)
+    ctx.set_option("neq_dfs_block", 128); ctx.set_option("neq_dfs_wgs", 8)
+    try:
+        checked = FC.check_interval_forest(ctx, om, rl[:8].cpu().numpy(), ru[:8].cpu().numpy(), K=10, expect_block=128)
+    finally:
+        ctx.set_option("neq_dfs_block", 0); ctx.set_option("neq_dfs_wgs", 0)
+    assert checked == 2 * 8 * 10
+
+
 def test_interval_forest_deep_roots(env):
     """Roots further down: the top rows of the stack after a 300-node dive (about 30 queens assigned; propagation cascades and failures
     are common there), 4 subtrees x 10 nodes."""

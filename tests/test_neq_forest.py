@@ -56,6 +56,23 @@ def test_expansion_plus_forest_is_the_complete_tree(ctx, n, trees):
     assert tuple(sum(p[k] for p in parts) for k in ("nodes", "solutions", "failed")) == want
 
 
+@pytest.mark.parametrize("block,wgs", [(128, 8), (256, 4), (512, 2)])
+def test_tree_shapes(ctx, block, wgs):
+    """Threads per tree and trees per CU (options neq_dfs_block / neq_dfs_wgs; the defaults depend on the number of trees): the complete tree
+    of n = 10 from 64 roots in every shape, failures, solutions and jump windows included."""
+    from pcp_amd.search_forest import forest_search
+    n = 10
+    props, lb0, ub0 = nqueens(ctx, n)
+    want = oracle_tree(n, props, lb0, ub0)
+    ctx.set_option("neq_dfs_block", block); ctx.set_option("neq_dfs_wgs", wgs)
+    try:
+        one = forest_search(ctx, lb0, ub0, n_trees=64, steps_per_launch=16, capacity=256)
+        assert ctx.last_plan()["block"] == block
+    finally:
+        ctx.set_option("neq_dfs_block", 0); ctx.set_option("neq_dfs_wgs", 0)
+    assert one["error"] == 0 and (one["nodes"], one["solutions"], one["failed"]) == want
+
+
 def test_a_node_budget_stops_the_launches(ctx):
     from pcp_amd.search_forest import forest_search
     n = 12
