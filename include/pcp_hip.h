@@ -289,6 +289,11 @@ typedef struct {
   uint8_t* status;
   uint64_t* counters;
   int32_t* first_solution;
+  /* ABI v7, nullable: [capacity] uint32 (pcp_dfs_forest_device: [n_trees][capacity]), one word per stack row = the variable that row was
+   * branched on (the pcp_device_batch.dirty_var of the open node in that row), or >= n_vars for a row the caller put there (a root): the
+   * engine writes it when it pushes children and, when it pops a row, propagates from that variable alone instead of from every assigned
+   * variable of the node.  A caller that moves rows between stacks moves their words along.  All-XNeqY in-kernel loop only. */
+  uint32_t* dirty;
 } pcp_dfs_state;
 int32_t pcp_dfs_device(pcp_ctx* ctx, const pcp_dfs_state* st, uint32_t n_steps, uint32_t stop_on_solution, uint64_t node_limit, void* hip_stream);
 /* The same loop on n_trees independent stacks at once, one workgroup per tree (ABI v5): tree t is exactly a pcp_dfs_device instance on

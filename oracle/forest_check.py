@@ -62,7 +62,7 @@ def simulate_interval_stack(rec, K: int):
     return stack, (K, sols, fails)
 
 
-def check_interval_forest(ctx, om, root_lb, root_ub, K: int, capacity: int = 64, expect_block: int = 256) -> int:
+def check_interval_forest(ctx, om, root_lb, root_ub, K: int, capacity: int = 64, expect_block: int = 256, hints: bool = True) -> int:
     """root_lb / root_ub: [T, V] int32 numpy — subtree roots, not yet propagated.  Runs both launch shapes on fresh stacks and compares with
     the oracle's DFS from every root.  Returns the number of (tree, node) pairs compared.  Raises AssertionError on any difference."""
     import torch
@@ -83,7 +83,12 @@ def check_interval_forest(ctx, om, root_lb, root_ub, K: int, capacity: int = 64,
         stop = torch.zeros(T, dtype=torch.int32, device=dev)
         status = torch.full((T, capacity), 255, dtype=torch.uint8, device=dev)
         counters = torch.zeros((T, 5), dtype=torch.int64, device=dev)
-        st = E.DfsState(lb.data_ptr(), ub.data_ptr(), capacity, sp.data_ptr(), stop.data_ptr(), status.data_ptr(), counters.data_ptr(), None)
+        # (hints: the stack keeps, per row, the variable it was branched on — pcp_dfs_state.dirty, what engine.dfs_forest passes — and a popped
+        # row is propagated from that variable alone; the stepwise shape pops EVERY node from the stack)
+        dirty = torch.full((T, capacity), -1, dtype=torch.int32, device=dev) if hints else None
+        st = E.DfsState(lb.data_ptr(), ub.data_ptr(), capacity, sp.data_ptr(), stop.data_ptr(), status.data_ptr(), counters.data_ptr(), None,
+                        dirty.data_ptr() if hints else None)
+        st._keep = dirty
         return lb, ub, sp, stop, status, counters, st
 
     def launch(st, steps):

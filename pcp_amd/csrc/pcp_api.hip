@@ -1398,6 +1398,7 @@ static int32_t launch_neq_dfs(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_tr
   a.n_nodes = 1; a.nodes_per_block = 1; a.packed = packed ? 1u : 0u; a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.lds_wgs = wgs;
   a.lb_in = st->lb; a.ub_in = st->ub; a.lb_out = st->lb; a.ub_out = st->ub; a.status = st->status; a.stats = c->d_stats;
   a.dfs.sp = st->sp; a.dfs.stop = st->stop; a.dfs.counters = reinterpret_cast<unsigned long long*>(st->counters); a.dfs.first_solution = st->first_solution;
+  a.dfs.dirty = c->opt_neq_hint ? st->dirty : nullptr;
   a.dfs.capacity = st->capacity; a.dfs.n_steps = n_steps; a.dfs.stop_on_solution = stop_on_solution; a.dfs.node_limit = node_limit;
   LaunchPlan plan;
   plan.grid = n_trees; plan.block = c->opt_neq_dfs_block ? (uint32_t)c->opt_neq_dfs_block : (n_trees > 1 ? (many ? 128u : 256u) : 512u); plan.lds_bytes = lds;

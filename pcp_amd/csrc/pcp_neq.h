@@ -27,6 +27,7 @@ struct NeqArgs {
     uint32_t* stop;
     unsigned long long* counters;  // nodes, solutions, failed nodes, error, internal (pcp_hip.h)
     int32_t* first_solution;
+    uint32_t* dirty;            //   [capacity] per stack row: the variable it was branched on (>= n_vars: none), or null
     uint32_t capacity;
     uint32_t n_steps;
     uint32_t stop_on_solution;

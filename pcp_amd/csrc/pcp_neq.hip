@@ -471,13 +471,14 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
   bool adj_loaded = false, adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
-  uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu;
+  uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu, dfs_hint = 0xFFFFFFFFu;
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
   // the forest of one tree; pcp_dfs_forest_device launches many, each an independent instance of the same loop)
   const size_t tree_row0 = DFS ? (size_t)blockIdx.x * a_in.dfs.capacity : 0;
   if constexpr (DFS) {
     a.dfs.sp += blockIdx.x; a.dfs.stop += blockIdx.x; a.dfs.counters += (size_t)blockIdx.x * 5;
     if (a.dfs.first_solution) a.dfs.first_solution += (size_t)blockIdx.x * V;
+    if (a.dfs.dirty) a.dfs.dirty += tree_row0;
   }
   unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;  // DFS: the search counters, replicated in every thread
   unsigned long long acc_steps = 0, acc_narrow = 0, acc_ev = 0, acc_full = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;  // DFS: pcp_stats, per launch
@@ -514,6 +515,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     const size_t off = (tree_row0 + (dfs_sp - 1)) * V;
     a.lb_in = a_in.lb_in + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + tree_row0 + (dfs_sp - 1);
     resume = dfs_resume_var != 0xFFFFFFFFu;
+    // a popped row: the variable it was branched on, if the stack keeps them (pcp_dfs_state.dirty) — it is a propagated parent with that
+    // one variable moved, so its first round is that variable's lists (the rows of this very launch are read past the L1, like the bounds)
+    dfs_hint = (!resume && a.dfs.dirty) ? __hip_atomic_load(a.dfs.dirty + (dfs_sp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
   if (tid == (uint32_t)N_R0OVF) misc[tid] = 0;
@@ -551,7 +555,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (tid == 0) chg[dfs_resume_var >> 5] = 1u << (dfs_resume_var & 31u);  // the left child: only the variable branched on has changed
   } else {
     uint32_t badm = 0, oobm = 0;
-    const uint32_t hintm = (!DFS && a.dirty) ? (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_HINT]) : 0u;  // (written before the barrier above)
+    const uint32_t hintm = DFS ? (dfs_hint < V ? 1u : 0u) : a.dirty ? (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_HINT]) : 0u;  // (written before the barrier above)
     // returns bit 0 = an empty domain among the four, bit 1 = a bound out of range (the callers collect them per node)
     auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) -> uint32_t {
       if (PCP_PUT_FAST && cnt == 4) {
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (badm) atomicOr(&misc[N_FAIL], badm);
     if (oobm) atomicOr(&misc[N_OOB], oobm);
     if (hintm && tid < nb && ((hintm >> tid) & 1u)) {  // the hinted nodes' one changed variable
-      const uint32_t dv = a.dirty[node0 + tid];
+      const uint32_t dv = DFS ? dfs_hint : a.dirty[node0 + tid];
       atomicOr(&chg[tid * Wv + (dv >> 5)], 1u << (dv & 31u));
     }
   }
@@ -1397,6 +1401,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
         const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27: `/` truncates toward zero)
         // the right child x > val takes the parent's row (which holds the fixpoint: written back above if it changed)
         if (tid == 0) a.lb_out[var] = max(d.x, val + 1);
+        if (tid == 0 && a.dfs.dirty) { a.dfs.dirty[dfs_sp - 1] = var; a.dfs.dirty[dfs_sp] = var; }  // both children differ from this fixpoint in `var`
         // the left child x <= val: one bound of one LDS cell, and its row on top of the stack
         if (tid == 0) {
           if constexpr (PACKED) dom[rowof(var)] = pack16(d.x, min(d.y, val)); else dom[rowof(var)] = make_int2(-d.x, min(d.y, val));

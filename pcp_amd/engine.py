@@ -52,7 +52,7 @@ class DeviceBatch(C.Structure):
 
 class DfsState(C.Structure):
     _fields_ = [("lb", C.c_void_p), ("ub", C.c_void_p), ("capacity", C.c_uint32), ("sp", C.c_void_p), ("stop", C.c_void_p), ("status", C.c_void_p),
-                ("counters", C.c_void_p), ("first_solution", C.c_void_p)]
+                ("counters", C.c_void_p), ("first_solution", C.c_void_p), ("dirty", C.c_void_p)]
 
 
 class ForestState(C.Structure):
@@ -324,7 +324,8 @@ class Context:
         status = torch.zeros(capacity, dtype=torch.uint8, device=dev)
         counters = torch.zeros(5, dtype=torch.int64, device=dev)
         sol = torch.zeros(V, dtype=torch.int32, device=dev)
-        st = DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), sol.data_ptr())
+        dirty = torch.full((capacity,), -1, dtype=torch.int32, device=dev)  # per stack row: the variable it was branched on (the root: none)
+        st = DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), sol.data_ptr(), dirty.data_ptr())
         stream = torch.cuda.current_stream(dev).cuda_stream
         done = 0
         while done < n_steps:
@@ -341,7 +342,7 @@ class Context:
 
     def dfs_forest(self, root_lb, root_ub, stop_on_solution: bool = False, node_limit_per_tree: int = 0, steps_per_launch: int = 256, capacity: int = 2048,
                    max_launches: int = 1 << 30, node_budget: int = 0, want_solution: bool = False, rebalance: bool = True, info: dict | None = None, dist=None, max_capacity: int = 0,
-                   sp0=None):
+                   sp0=None, hints: bool = True):
         """pcp_dfs_forest_device: the reference's search loop (interval mode, all-XNeqY models) on many subtrees at once, one workgroup per
         tree, each exactly a pcp_dfs_device instance.  root_lb / root_ub: [n_trees, n_vars] int32 (numpy or CUDA tensors): the roots, not yet
         propagated.  Launches of steps_per_launch nodes per tree are repeated until every stack is empty, a tree stopped (solution with
@@ -367,16 +368,17 @@ class Context:
         status = torch.zeros((T, capacity), dtype=torch.uint8, device=dev)
         counters = torch.zeros((T, 5), dtype=torch.int64, device=dev)
         sol = torch.zeros((T, V), dtype=torch.int32, device=dev) if want_solution else None
+        dirty = torch.full((T, capacity), -1, dtype=torch.int32, device=dev) if hints else None  # pcp_dfs_state.dirty: one word per stack row
         from .search_forest import ForestStacks, run_forest_loop
         stream = torch.cuda.current_stream(dev).cuda_stream
         box = {}
 
         def point(fs):  # (re)build the pcp_dfs_state over the forest's current buffers
             box["st"] = DfsState(fs.lb.data_ptr(), fs.ub.data_ptr(), fs.capacity, sp.data_ptr(), stop.data_ptr(), fs.status.data_ptr(), counters.data_ptr(),
-                                 sol.data_ptr() if want_solution else None)
+                                 sol.data_ptr() if want_solution else None, fs.dirty.data_ptr() if fs.dirty is not None else None)
 
-        fs = ForestStacks(lb, ub, status, sp, stop, counters, max_capacity=max(max_capacity, capacity), on_grow=point)
-        del lb, ub, status
+        fs = ForestStacks(lb, ub, status, sp, stop, counters, max_capacity=max(max_capacity, capacity), on_grow=point, dirty=dirty)
+        del lb, ub, status, dirty
         point(fs)
 
         def launch():

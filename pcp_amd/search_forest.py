@@ -89,7 +89,7 @@ def plan_refill(idle, donors):
     return moves
 
 
-def refill_across_ranks(lb, ub, sp, spc, dist, info: dict | None = None) -> int:
+def refill_across_ranks(lb, ub, sp, spc, dist, info: dict | None = None, dirty=None) -> int:
     """One exchange of the interval forest: ranks whose trees ran dry receive open nodes from ranks that have trees with two or more.
     ``lb``/``ub``: [T, capacity, V] stacks, ``sp``: [T] int32 stack sizes (device or CPU tensors), ``spc``: this rank's sizes as a numpy
     array (updated in place).  A donor tree gives its BOTTOM row (its oldest open node: the subtree nearest its root), richest trees
@@ -114,16 +114,20 @@ def refill_across_ranks(lb, ub, sp, spc, dist, info: dict | None = None) -> int:
             trees = donor_t[gave:gave + k]
             gave += k
             idx = torch.tensor(trees, dtype=torch.int64, device=dev)
-            for t in (lb, ub):
+            for t in (lb, ub) if dirty is None else (lb, ub, dirty):
                 ops.append(dist.P2POp(dist.isend, t[idx, 0].contiguous(), dst))
             for d in trees:  # the donor's stack moves down by one row
                 n = int(spc[d])
                 lb[d, 0:n - 1] = lb[d, 1:n].clone(); ub[d, 0:n - 1] = ub[d, 1:n].clone()
+                if dirty is not None:
+                    dirty[d, 0:n - 1] = dirty[d, 1:n].clone()
                 spc[d] = n - 1
             sp[idx] -= 1
             delta += k
         elif rank == dst:
             bufs = [torch.empty((k, V), dtype=lb.dtype, device=dev) for _ in range(2)]
+            if dirty is not None:
+                bufs.append(torch.empty((k,), dtype=dirty.dtype, device=dev))  # the rows' hints travel with them
             for b in bufs:
                 ops.append(dist.P2POp(dist.irecv, b, src))
             incoming.append((bufs, idle_t[took:took + k]))
@@ -132,9 +136,11 @@ def refill_across_ranks(lb, ub, sp, spc, dist, info: dict | None = None) -> int:
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    for (bl, bu), trees in incoming:
+    for bufs, trees in incoming:
         idx = torch.tensor(np.asarray(trees), dtype=torch.int64, device=dev)
-        lb[idx, 0] = bl; ub[idx, 0] = bu
+        lb[idx, 0] = bufs[0]; ub[idx, 0] = bufs[1]
+        if dirty is not None:
+            dirty[idx, 0] = bufs[2]
         sp[idx] = 1
         spc[trees] = 1
     if info is not None:
@@ -148,8 +154,9 @@ class ForestStacks:
     ``counters`` [T, 5] (nodes, solutions, failed, error, ..).  ``grow()`` doubles the rows per tree (a tree's rows stay where they are
     within its slice) up to ``max_capacity``; ``on_grow`` lets the owner re-point its pcp_dfs_state."""
 
-    def __init__(self, lb, ub, status, sp, stop, counters, max_capacity: int = 0, on_grow=None):
+    def __init__(self, lb, ub, status, sp, stop, counters, max_capacity: int = 0, on_grow=None, dirty=None):
         self.lb, self.ub, self.status, self.sp, self.stop, self.counters = lb, ub, status, sp, stop, counters
+        self.dirty = dirty  # [T, capacity] int32 or None: per stack row the variable it was branched on (pcp_dfs_state.dirty); moves with its row
         self.max_capacity = int(max_capacity) if max_capacity else int(lb.shape[1])
         self.on_grow = on_grow
         self.grown = 0
@@ -175,6 +182,10 @@ class ForestStacks:
             t = torch.zeros((T, new), dtype=self.status.dtype, device=self.status.device)
             t[:, :cap] = self.status
             self.status = t
+        if self.dirty is not None:
+            t = torch.full((T, new), -1, dtype=self.dirty.dtype, device=self.dirty.device)
+            t[:, :cap] = self.dirty
+            self.dirty = t
         self.grown += 1
         if self.on_grow:
             self.on_grow(self)
@@ -238,6 +249,9 @@ def run_forest_loop(launch, fs: ForestStacks, stop_on_solution: bool = False, no
                 k = int(spc[d])
                 lb[r, 0] = lb[d, 0]; ub[r, 0] = ub[d, 0]
                 lb[d, 0:k - 1] = lb[d, 1:k].clone(); ub[d, 0:k - 1] = ub[d, 1:k].clone()
+                if fs.dirty is not None:  # a row's hint moves with it
+                    fs.dirty[r, 0] = fs.dirty[d, 0]
+                    fs.dirty[d, 0:k - 1] = fs.dirty[d, 1:k].clone()
                 sp[d] = k - 1; sp[r] = 1
                 spc[d] = k - 1; spc[r] = 1
                 steals += 1
@@ -245,7 +259,7 @@ def run_forest_loop(launch, fs: ForestStacks, stop_on_solution: bool = False, no
             t0 = time.perf_counter()
             if spc is None:
                 spc = sp.cpu().numpy().copy()
-            refill_across_ranks(lb, ub, sp, spc, dist, xinfo)
+            refill_across_ranks(lb, ub, sp, spc, dist, xinfo, dirty=fs.dirty)
             exchange_s += time.perf_counter() - t0
     return {"launches": launches, "steals": steals, "moved_rows": xinfo["moved_rows"], "moved_bytes": xinfo["moved_bytes"], "exchange_s": exchange_s,
             "grown": fs.grown, "capacity": fs.capacity}

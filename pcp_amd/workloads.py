@@ -69,7 +69,8 @@ def nqueens_dfs_samples(ctx, n: int, samples: int, stride: int, capacity: int = 
     state = torch.tensor([1, 0], dtype=torch.int32, device=dev)
     status = torch.zeros(capacity, dtype=torch.uint8, device=dev)
     counters = torch.zeros(5, dtype=torch.int64, device=dev)
-    st = E.DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), None)
+    dirty = torch.full((capacity,), -1, dtype=torch.int32, device=dev)  # (a popped row restarts from the variable it was branched on)
+    st = E.DfsState(lb.data_ptr(), ub.data_ptr(), capacity, state.data_ptr(), state.data_ptr() + 4, status.data_ptr(), counters.data_ptr(), None, dirty.data_ptr())
     out_lb = torch.empty((samples, n), dtype=torch.int32, device=dev)
     out_ub = torch.empty((samples, n), dtype=torch.int32, device=dev)
     depth = np.zeros(samples, np.int32)

@@ -37,6 +37,8 @@ def test_interval_forest_node_for_node(env):
     assert rl.shape[0] >= 8
     checked = FC.check_interval_forest(ctx, om, rl[:8], ru[:8], K=12)
     assert checked == 2 * 8 * 12
+    # ... and without the per-row hint words (pcp_dfs_state.dirty == NULL: every popped row is propagated from all its assigned queens)
+    assert FC.check_interval_forest(ctx, om, rl[:2], ru[:2], K=6, hints=False) == 2 * 2 * 6
 
 
 def test_interval_forest_narrow_trees(env):

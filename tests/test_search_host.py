@@ -308,8 +308,13 @@ class _StandInForest:
         sp = torch.zeros(trees, dtype=torch.int32)
         for t, (l, u) in enumerate(roots):
             lb[t, 0] = torch.from_numpy(l); ub[t, 0] = torch.from_numpy(u); sp[t] = 1
+        # one hint word per stack row (pcp_dfs_state.dirty): written with the children like the kernel does, checked on every pop against
+        # the reference tree (`hint_map`: node -> the variable its parent was branched on) — a row that moved (steal within a rank, refill
+        # across ranks, a grown stack) must still carry ITS word
         self.fs = ForestStacks(lb, ub, torch.zeros((trees, capacity), dtype=torch.uint8), sp, torch.zeros(trees, dtype=torch.int32),
-                               torch.zeros((trees, 5), dtype=torch.int64), max_capacity=max_capacity)
+                               torch.zeros((trees, 5), dtype=torch.int64), max_capacity=max_capacity,
+                               dirty=torch.full((trees, capacity), -1, dtype=torch.int32))
+        self.hint_map = _reference_hints(n)
         self.visited = []  # (lb, ub) of every node this rank counted, as tuples
         self.solutions = []
 
@@ -324,6 +329,7 @@ class _StandInForest:
                 l, u = fs.lb[t, sp - 1].numpy().copy(), fs.ub[t, sp - 1].numpy().copy()
                 pl, pu, _, st, _ = self.ctx.propagate(l[None], u[None])
                 key = (tuple(int(x) for x in l), tuple(int(x) for x in u))
+                assert int(fs.dirty[t, sp - 1]) == self.hint_map[key], (key, int(fs.dirty[t, sp - 1]))
                 if st[0] == 0:
                     fs.counters[t, 0] += 1; fs.counters[t, 2] += 1; fs.sp[t] = sp - 1
                     self.visited.append(key)
@@ -340,7 +346,30 @@ class _StandInForest:
                     import torch
                     fs.lb[t, sp - 1] = torch.from_numpy(cl[1]); fs.ub[t, sp - 1] = torch.from_numpy(cu[1])  # the right child takes the parent's row
                     fs.lb[t, sp] = torch.from_numpy(cl[0]); fs.ub[t, sp] = torch.from_numpy(cu[0])          # the left child goes on top
+                    var = int(np.nonzero((cl[0] != cl[1]) | (cu[0] != cu[1]))[0][0])
+                    fs.dirty[t, sp - 1] = var; fs.dirty[t, sp] = var                                          # both children differ from the parent's fixpoint in `var`
                     fs.sp[t] = sp + 1
+
+
+_HINTS = {}
+
+
+def _reference_hints(n):
+    """node (as entered) -> the variable its parent was branched on (-1: the root), over the whole n-queens tree."""
+    if n not in _HINTS:
+        from pcp_amd import search as S
+        ctx = OracleCtx(n, M.nqueens_props(n))
+        hints, stack = {}, [(np.ones(n, np.int32), np.full(n, n, np.int32), -1)]
+        while stack:
+            l, u, h = stack.pop()
+            hints[(tuple(int(x) for x in l), tuple(int(x) for x in u))] = h
+            pl, pu, _, st, _ = ctx.propagate(l[None], u[None])
+            if st[0] == 2:
+                cl, cu, _ = S.branch(pl, pu, None)
+                var = int(np.nonzero((cl[0] != cl[1]) | (cu[0] != cu[1]))[0][0])
+                stack.append((cl[1], cu[1], var)); stack.append((cl[0], cu[0], var))
+        _HINTS[n] = hints
+    return _HINTS[n]
 
 
 def _reference_tree(n):
