@@ -14,7 +14,12 @@ timeout 200 python bench.py --mode search --domains set > gpurun_out/$T/search_s
 timeout 300 python bench.py --legs none --cpu-budget 0 --c5-single > gpurun_out/$T/bench_c5_single.json 2> gpurun_out/$T/bench_c5_single.err
 timeout 400 bash tools/profile_cmd.sh $T/benchcmd python bench.py --legs none --cpu-budget 0 > gpurun_out/$T/prof_benchcmd.log 2>&1
 timeout 300 python tools/replay_leg.py save deep500 deep3000 > gpurun_out/$T/save.log 2>&1
-for L in frontier deep500 deep3000 mix search neqforest; do timeout 600 bash tools/profile_leg.sh $T $L neqfix > gpurun_out/$T/prof_$L.log 2>&1; done
+for L in frontier deep500 deep3000 mix mixh search neqforest; do timeout 600 bash tools/profile_leg.sh $T $L neqfix > gpurun_out/$T/prof_$L.log 2>&1; done
+PCP_FOREST_8K=1 timeout 600 bash tools/profile_leg.sh $T/forest8k neqforest neqfix > gpurun_out/$T/prof_neqforest8k.log 2>&1
+timeout 300 bash tools/pmc_phases.sh $T/phases > gpurun_out/$T/prof_phases.log 2>&1
+timeout 120 python tools/box_probe.py > gpurun_out/$T/box_probe.json 2> /dev/null
+(cd tools/micro && for D in 0 10000 20000; do timeout 60 ./stream_probe 16384 $D 5; done; timeout 60 ./stage_probe 16384 20000 5) > gpurun_out/$T/stream_probe.txt 2>&1
+NEQ_CONFIGS='[{}, {"neq_stagger": 6000}, {"neq_stagger": 12000}, {"neq_debug": 32768}, {"neq_debug": 3}, {"neq_debug": 32771}, {"neq_debug": 1}, {"neq_debug": 2}]' timeout 300 python tools/neq_probe.py frontier > gpurun_out/$T/neq_probe.txt 2>&1
 timeout 500 bash tools/profile_leg.sh $T c3 bigfix > gpurun_out/$T/prof_c3.log 2>&1
 timeout 500 bash tools/profile_leg.sh $T c4 smallfix > gpurun_out/$T/prof_c4.log 2>&1
 timeout 500 bash tools/profile_leg.sh $T f4 formfix > gpurun_out/$T/prof_f4.log 2>&1

@@ -22,6 +22,9 @@ def nq():
     ctx.set_model(n, M.nqueens_props(n)); ctx.set_hull(1, n)
 
 
+HINT = None
+
+
 def launches(lb, ub, act, k):
     N = lb.shape[0]
     st = torch.zeros(N, dtype=torch.uint8, device=dev)
@@ -30,7 +33,7 @@ def launches(lb, ub, act, k):
         l, u = lb.clone(), ub.clone()
         a = None if act is None else act.clone()
         torch.cuda.synchronize()
-        ctx.propagate_device(N, l, u, l, u, a, a, st)
+        ctx.propagate_device(N, l, u, l, u, a, a, st, dirty=HINT)
         if i:
             ms.append(ctx.last_kernel_ms())
     return ms, ctx.last_plan()
@@ -70,6 +73,19 @@ else:
         nq()
         lb, ub, _ = W.nqueens_dfs_samples(ctx, n, 16384, 12)
         nq()
+    elif nm == "mixh":
+        # the children of the mix nodes with their dirty-variable hints (bench.py's MIXH leg): propagate the mix batch, branch it with hints
+        nq()
+        pl, pu, _ = W.nqueens_dfs_samples(ctx, n, 16384, 12)
+        nq()
+        stp = torch.zeros(pl.shape[0], dtype=torch.uint8, device=dev)
+        ctx.propagate_device(pl.shape[0], pl, pu, pl, pu, None, None, stp)
+        cl = torch.empty((2 * pl.shape[0], n), dtype=torch.int32, device=dev); cu = torch.empty_like(cl)
+        cd = torch.full((2 * pl.shape[0],), -1, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(5, dtype=torch.int32, device=dev)
+        ctx.branch_device(pl.shape[0], pl, pu, None, stp, cl, cu, None, cnt, child_dirty=cd)
+        kc = min(int(cnt[0].item()), 16384)
+        lb, ub, HINT = cl[:kc].clone(), cu[:kc].clone(), cd[:kc].clone()
     elif nm == "explicit":
         nq()
         L, U, A = W.nqueens_frontier(ctx, n, 4096, share=0, shares=8, implicit=False)
@@ -88,7 +104,8 @@ else:
         from pcp_amd.search_forest import forest_search
         nq()
         t0 = time.perf_counter()
-        r = forest_search(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), node_limit=500_000, n_trees=2048, steps_per_launch=256)
+        big = os.environ.get("PCP_FOREST_8K")  # the forest at its operating point: 2 M nodes, 8192 trees of 128 threads
+        r = forest_search(ctx, np.ones(n, np.int32), np.full(n, n, np.int32), node_limit=2_000_000 if big else 500_000, n_trees=8192 if big else 2048, steps_per_launch=256)
         torch.cuda.synchronize()
         print(json.dumps({"leg": nm, "nodes": r["nodes"], "trees": r["trees"], "launches": r["launches"], "seconds_incl_expansion_and_allocation": time.perf_counter() - t0,
                           "last_kernel_ms": ctx.last_kernel_ms(), "plan": ctx.last_plan()}))
