@@ -62,6 +62,9 @@
 #define PCP_NEQ_PLEN 0
 #endif
 
+// profiling builds: one s_memtime stamp per wavefront and event (needs `tr_on`, `trbuf`, `lane`, `wv` in scope)
+#define PCP_TR(k) do { if (tr_on && lane == 0) trbuf[wv * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 namespace pcp {
 
 namespace {
@@ -297,6 +300,576 @@ __device__ __noinline__ void resweep_marks(const typename NeqCell<PACKED>::type*
   }
 }
 
+// What the phases of a tile share: its LDS arrays and its geometry.  (`tid`, `lane` are refreshed per tile by the kernel: see its loop.)
+template <bool PACKED>
+struct NeqTile {
+  using TDom = typename TileDomOf<PACKED>::type;
+  typename NeqCell<PACKED>::type* dom;
+  uint32_t* chg;
+  uint32_t* misc;
+  const uint32_t* adjo;
+  uint4* list;
+  Win* win;
+  uint32_t V, Wv, B, sh, nb;
+  uint32_t tid, lane, wv, nwv, nth;
+  __device__ __forceinline__ uint32_t rowof(uint32_t slot) const { return neq_row(slot, B, sh); }  // index of node 0's cell of a slot
+  __device__ __forceinline__ TDom dom_of(uint32_t b, Ctr* c) const { return TDom{dom + b, B, sh, chg + (size_t)b * Wv, misc, 1u << b, c}; }  // node b's store
+};
+
+// ---- status: is any record NOT entailed under the final domains? (store.rs:250-256) ------------------------------
+// Records of two assigned variables are entailed at a fixpoint that did not fail (two different values: disjoint), so only the
+// lists of unassigned variables can hold an open record; x != y + d is entailed iff the intervals are disjoint
+// (x_neq_y.rs:71-73 via x_eq_y.rs:87-93).
+// Two nodes per wavefront at a time, one per 32-lane half: a node's scan is a chain of dependent LDS and memory reads (cells -> the
+// list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
+// chains one after the other in every wavefront.  Sets bit b of misc[N_UNK] for a node with an open record.
+template <bool PACKED, bool DFS, class Tile, class Pay>
+__device__ __forceinline__ void neq_status_scan(const Tile& tl, const Pay* pay, bool skip) {
+const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB];
+  for (uint32_t b0 = tl.wv; b0 < tl.nb; b0 += 2 * tl.nwv) {
+    // (a wavefront with one node left gives it all 64 lanes: the search loop's single node, the odd node of a ragged tile)
+    const bool pair = !DFS && b0 + tl.nwv < tl.nb;                            // wave-uniform (the search loop has one node: folded away)
+    const uint32_t hw = pair ? 32u : 64u, hl = tl.lane & (hw - 1u), hb = pair ? tl.lane >> 5 : 0u;
+    const uint32_t b = b0 + hb * tl.nwv;                                   // this half's node
+    bool done = ((inert >> b) & 1u) || skip;                  // (uniform within a half)
+    bool open = false;
+    auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(tl.dom[tl.rowof(slot) + b]); };
+    auto mine = [&](unsigned long long bal) { return pair ? (unsigned long long)(uint32_t)(bal >> (32u * hb)) : bal; };
+    for (uint32_t base = 0; base < tl.V; base += hw) {
+      if (!__ballot(!done)) break;
+      const uint32_t vv = base + hl;
+      bool wide = false;
+      if (!done && vv < tl.V) { const int2 d = cellb(vv); wide = d.x < d.y; }
+      unsigned long long cand = mine(__ballot(wide));                   // this half's unassigned variables among these
+      for (;;) {
+        const bool has = !done && cand != 0ull;
+        if (!__ballot(has)) break;
+        const uint32_t u = has ? base + (uint32_t)__builtin_ctzll(cand) : 0u;
+        cand &= cand - 1ull;
+        int2 Ud = make_int2(0, 0);
+        uint32_t o0 = 0, deg = 0;
+        if (has) { Ud = cellb(u); o0 = tl.adjo[u]; deg = tl.adjo[u + 1] - o0; }
+        for (uint32_t k = 0;; k += hw) {
+          const bool go = has && !open && k < deg;
+          if (!__ballot(go)) break;
+          bool op = false;
+          if (go && k + hl < deg) {
+            const Pay q = pay[o0 + k + hl];
+            const int t = pay_t(q);
+            const int2 O = cellb(pay_other(q));
+            op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));  // not disjoint
+          }
+          if (mine(__ballot(op))) open = true;
+        }
+        if (open) done = true;
+      }
+    }
+    if (open && hl == 0) atomicOr(&tl.misc[N_UNK], 1u << b);
+  }
+}
+
+// ---- write back: the rows of the nodes that changed (every node when the call is not in place).  A refused node's outputs are left
+// alone.  An empty cell found on the way out fails its node (misc[N_FAIL]).  Returns the mask of the nodes written (workgroup-uniform).
+template <bool PACKED, class Tile>
+__device__ __forceinline__ uint32_t neq_write_back(const Tile& tl, const int32_t* lb_in, const int32_t* ub_in, int32_t* lb_out, int32_t* ub_out) {
+const bool in_place = lb_in == lb_out && ub_in == ub_out;
+  const uint32_t all_nodes = tl.nb >= 32 ? 0xFFFFFFFFu : ((1u << tl.nb) - 1u);
+  const uint32_t dirty = __builtin_amdgcn_readfirstlane(tl.misc[N_DIRTY]), refused = __builtin_amdgcn_readfirstlane(tl.misc[N_OOB]);
+  uint32_t badm = 0;
+  const bool vec_out = (tl.V & 3u) == 0 && (((size_t)lb_out | (size_t)ub_out) & 15u) == 0;
+  // a refused node's outputs are left alone; in place, the rows of an unchanged node already hold the result in HBM: a frontier
+  // tile writes nothing and does not even look at its sixteen nodes one by one
+  const uint32_t wb_need = (in_place ? dirty : all_nodes) & ~refused & all_nodes;  // (workgroup-uniform)
+  for (uint32_t need = wb_need; need; need &= need - 1u) {
+    const uint32_t b = (uint32_t)__builtin_ctz(need);
+    auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(tl.dom[tl.rowof(slot) + b]); };
+    int32_t* lbp = lb_out + (size_t)tl.misc[N_NID + b] * tl.V;
+    int32_t* ubp = ub_out + (size_t)tl.misc[N_NID + b] * tl.V;
+    bool bad = false;
+    if (vec_out) {
+      for (uint32_t q = tl.tid; q < (tl.V >> 2); q += tl.nth) {
+        int l[4], u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int2 d = cellb(4 * q + i); l[i] = d.x; u[i] = d.y; bad |= d.x > d.y; }
+        reinterpret_cast<int4*>(lbp)[q] = make_int4(l[0], l[1], l[2], l[3]);
+        reinterpret_cast<int4*>(ubp)[q] = make_int4(u[0], u[1], u[2], u[3]);
+      }
+    } else {
+      for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) { const int2 d = cellb(v); bad |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
+    }
+    if (bad) badm |= 1u << b;
+  }
+  if (badm) atomicOr(&tl.misc[N_FAIL], badm);
+  return wb_need;
+}
+
+// ---- the jumps of a round: each window's bound moves to the first value no assigned neighbour forbids (the windows were filled by the
+// list walk of one- and two-node masks: see the kernel's header).  Every skipped value is one the filter would remove at the bound.
+template <bool PACKED, class Tile>
+__device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, Ctr& ctr) {
+  for (uint32_t wi = tl.tid; wi < nwin; wi += tl.nth) {
+    const Win w = tl.win[wi];
+    const uint32_t v = w.vb & 0xffffu, b = w.vb >> 16;
+    if ((tl.misc[N_FAIL] >> b) & 1u) continue;
+    const auto dm = tl.dom_of(b, &ctr);
+    const int2 d = dm.load(v);
+    if (d.x > d.y) continue;
+    const unsigned long long Lm = ((unsigned long long)w.lo[1] << 32) | w.lo[0], Hm = ((unsigned long long)w.hi[1] << 32) | w.hi[0];
+    {
+      const uint32_t off = (uint32_t)(d.x - w.lb0);  // the bound may have moved during the walk
+      if (off < 64u) {
+        const unsigned long long m = Lm | ((1ull << off) - 1ull);
+        const int nl = w.lb0 + (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
+        if (nl > d.x) dm.raise_lb(v, nl);
+      }
+    }
+    {
+      const uint32_t off = (uint32_t)(w.ub0 - d.y);
+      if (off < 64u) {
+        const unsigned long long m = Hm | ((1ull << off) - 1ull);
+        const int nu = w.ub0 - (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
+        if (nu < d.y) dm.lower_ub(v, nu);
+      }
+    }
+  }
+}
+
+// The in-kernel search loop's registers (replicated in every thread of the tree's workgroup).
+struct NeqDfsRegs {
+  uint32_t sp, stop, resume_var, hint, err;
+  unsigned long long nodes, sols, fail;
+};
+
+// ---- the search step on the node the tile has just propagated: OneSolution / AllSolution over Propagation<Brancher<FirstSmallestVar,
+// MiddleVal, BinarySplit>> (one_solution.rs:92-105, brancher.rs:52-71) under StopNode (stop_node.rs:47-62).  `a` points at the node's
+// row (lb_out / ub_out: row sp - 1 of the tree's stack).  Count it; failed / solution: pop; Unknown: the right child x > v over the
+// parent's row, the left child x <= v on top and — its domains being in LDS already — marked as the node to continue with.
+template <bool PACKED, class Tile>
+__device__ __forceinline__ void neq_dfs_step(const Tile& tl, const NeqArgs& a, NeqDfsRegs& r) {
+  const bool failed = (tl.misc[N_FAIL] & 1u) != 0, refused = (tl.misc[N_OOB] & 1u) != 0, open = (tl.misc[N_UNK] & 1u) != 0;
+  r.resume_var = 0xFFFFFFFFu;
+  uint32_t new_sp = r.sp - 1;
+  // StopNode (stop_node.rs:57-62) replaces the status of the node that reaches the limit by EndOfSearch BEFORE the monitor sees it
+  // (Monitor<Statistics, StopNode<..>>, stop_node.rs:90-97): that node is counted as a node, never as a solution or a failure.
+  const bool last = a.dfs.node_limit && r.nodes + 1 >= a.dfs.node_limit;
+  if (refused) {
+    r.err = 2; r.stop = 1;  // a node the engine refused (PCP_STATUS_HULL)
+    ++r.nodes;
+  } else if (failed) {
+    ++r.nodes;
+    if (!last) ++r.fail;
+  } else if (!open) {  // True: a solution (monitor.rs:19-68); the first one is kept
+    ++r.nodes;
+    if (!last) {
+      if (r.sols == 0 && a.dfs.first_solution)
+        for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) a.dfs.first_solution[v] = cell_bounds<PACKED>(tl.dom[tl.rowof(v)]).x;
+      ++r.sols;
+      if (a.dfs.stop_on_solution) r.stop = 1;
+    }
+  } else {
+    // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (brancher.rs:52-71): the first variable of minimal size > 1
+    unsigned long long key = ~0ull;
+    for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) {
+      const int2 d = cell_bounds<PACKED>(tl.dom[tl.rowof(v)]);
+      const unsigned long long size = (unsigned long long)((long long)d.y - (long long)d.x + 1);
+      if (size > 1) key = min(key, (size << 32) | v);
+    }
+    for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(tl.list);  // (the round list is idle here)
+    if (tl.lane == 0) best[tl.wv] = key;
+    __syncthreads();
+    key = best[0];
+    for (uint32_t w = 1; w < tl.nwv; ++w) key = min(key, best[w]);
+    __syncthreads();
+    if (key == ~0ull) {
+      r.err = 3; r.stop = 1;  // Unknown, yet nothing to branch on: the reference panics (first_smallest_var.rs:36)
+      new_sp = r.sp;
+    } else if (r.sp >= a.dfs.capacity) {
+      r.err = 1; r.stop = 1;  // stack overflow: the node stays on the stack, uncounted
+      new_sp = r.sp;
+    } else {
+      ++r.nodes;
+      const uint32_t var = (uint32_t)key;
+      const int2 d = cell_bounds<PACKED>(tl.dom[tl.rowof(var)]);
+      const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27: `/` truncates toward zero)
+      // the right child x > val takes the parent's row (which holds the fixpoint: written back above if it changed)
+      if (tl.tid == 0) a.lb_out[var] = max(d.x, val + 1);
+      if (tl.tid == 0 && a.dfs.dirty) { a.dfs.dirty[r.sp - 1] = var; a.dfs.dirty[r.sp] = var; }  // both children differ from this fixpoint in `var`
+      // the left child x <= val: one bound of one LDS cell, and its row on top of the stack
+      if (tl.tid == 0) {
+        if constexpr (PACKED) tl.dom[tl.rowof(var)] = pack16(d.x, min(d.y, val)); else tl.dom[tl.rowof(var)] = make_int2(-d.x, min(d.y, val));
+      }
+      __syncthreads();
+      int32_t* l0 = a.lb_out + tl.V;
+      int32_t* u0 = a.ub_out + tl.V;
+      for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) { const int2 c = cell_bounds<PACKED>(tl.dom[tl.rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
+      new_sp = r.sp + 1;
+      r.resume_var = var;
+    }
+  }
+  if (a.dfs.node_limit && r.nodes >= a.dfs.node_limit) r.stop = 1;  // StopNode (stop_node.rs:57-62)
+  r.sp = new_sp;
+}
+
+// ---- (b) of a round: walk the lists.  Piece p (4 x 64 entries) of list e goes to wavefront (p + e) mod nwv: one long list is spread over
+// the workgroup, many lists are balanced to within a piece.  The payload loads of the next TWO pieces are in flight while a
+// piece is tested: three register stages in rotation, the loop unrolled three times so that no stage is ever copied (a copy
+// would wait for the load it copies).  A piece decodes its entries ONCE and tests them against every node of the entry's mask (quads of
+// nodes per ds_read_b128; masks of one or two nodes also fill the jump windows); only flagged entries run the full filter (eval_record).
+// Returns this thread's (entry, node) tests.
+template <bool PACKED, bool PAY4, class Tile, class Pay>
+__device__ __forceinline__ uint32_t neq_walk_lists(const Tile& tl, const NeqArgs& a, const Pay* pay, const uint32_t total, const bool one_piece, const uint32_t round, Ctr& ctr,
+                                                    const bool tr_on, unsigned long long* const trbuf) {
+  const uint32_t U4 = 4;
+  const uint32_t wv = tl.wv, nwv = tl.nwv, lane = tl.lane, B = tl.B;
+  auto* const dom = tl.dom;
+  uint4* const list = tl.list;
+  Win* const win = tl.win;
+  auto rowof = [&](uint32_t slot) { return tl.rowof(slot); };
+  auto dom_of = [&](uint32_t b, Ctr* c) { return tl.dom_of(b, c); };
+  struct Piece { uint32_t v, M, aoff, deg, k0, wsel; };
+  // The length of a piece: 4 x 64 entries, or — when the round walks so few lists that whole pieces per wavefront do not come out even —
+  // fewer: one list of 2997 entries (a frontier tile: the one queen its nodes have in common) is 12 pieces of 256 for 8 wavefronts,
+  // i.e. two rounds of pieces with half of the wavefronts idle in the second, but 16 pieces of 192: two even rounds, a quarter less time.
+  uint32_t plen = 64u * U4;
+  if (PCP_NEQ_PLEN && !one_piece && total <= 4u) {
+    uint32_t work = 0;
+    for (uint32_t e_ = 0; e_ < total; ++e_) work += list[e_].z;
+    work = (uint32_t)__builtin_amdgcn_readfirstlane(work);
+    const uint32_t per = nwv * 64u * U4, r = (work + per - 1u) / per;  // rounds of pieces at full length
+    if (r) plen = min(64u * U4, 64u * ((work + 64u * nwv * r - 1u) / (64u * nwv * r)));
+  }
+  const uint32_t nu = plen >> 6;  // payload loads / entries per lane of a piece (wave-uniform)
+  const uint32_t k_step = nwv * plen;
+  const uint32_t e_step = one_piece ? nwv : 1u;
+  auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * plen; };
+  uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
+  // the next piece of this wavefront (deg == 0: none left; its loads then read entry 0 of list 0 and are ignored)
+  auto next_piece = [&]() -> Piece {
+    while (e < total) {
+      const uint4 ent = list[e];
+      const uint32_t dg = __builtin_amdgcn_readfirstlane(ent.z);  // wave-uniform: keeps the loop control scalar
+      if (k0 < dg) {
+        const uint32_t vm = __builtin_amdgcn_readfirstlane(ent.x);
+        const Piece pc{vm & 0xffffu, vm >> 16, (uint32_t)__builtin_amdgcn_readfirstlane(ent.y), dg, k0, (uint32_t)__builtin_amdgcn_readfirstlane(ent.w)};
+        k0 += k_step;
+        return pc;
+      }
+      e += e_step; k0 = k_first(e);
+    }
+    return Piece{0u, 0u, 0u, 0u, 0u, 0u};
+  };
+  auto load = [&](const Piece& pc, Pay (&q)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if ((uint32_t)u >= nu) { q[u] = q[0]; continue; }  // (a short piece: entry 0's payload stands in, masked off below)
+      const uint32_t idx = pc.k0 + u * 64 + lane;
+      q[u] = pay[pc.aoff + (idx < pc.deg ? idx : 0u)];
+    }
+  };
+  uint32_t my_ev = 0;
+  const bool timing = PCP_NEQ_PROFILE && (a.debug & 8u) != 0;  // profiling: s_memtime ticks of the walk / of the node loops, pieces (counters overloaded)
+  uint64_t t_walk0 = 0, t_inner = 0, n_pieces = 0;
+  if (timing) t_walk0 = __builtin_amdgcn_s_memtime();
+  auto process = [&](const Piece& pc, const Pay (&q)[4]) {
+    uint32_t other[4];
+    int t[4];
+    bool valid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      valid[u] = (uint32_t)u < nu && pc.k0 + u * 64 + lane < pc.deg;
+      other[u] = pay_other(q[u]);
+      t[u] = pay_t(q[u]);  // v is the record's y: x != v + d  <=>  o != v + d (t = d);  v is x: o != v - d (t = -d)
+    }
+    bool hit[4] = {false, false, false, false};
+    uint64_t ti0 = 0;
+    if (timing) { ti0 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(other[0] ^ other[3] ^ (uint32_t)t[1]) & 0u); ++n_pieces; }
+    const uint32_t rv = rowof(pc.v);
+    uint32_t ro[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ro[u] = rowof(other[u]);
+    if constexpr (PACKED) {
+      uint32_t K[4], acc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { K[u] = pack_mt(t[u]); acc[u] = 0xffffffffu; }
+      if (B >= 4 && __popc(pc.M) > 2) {
+        // a quad of nodes per ds_read_b128, two quads per step (ten reads in flight); nodes of a quad outside the mask are
+        // tested along: they can only raise a flag that the full-filter pass below, which walks the mask, ignores
+        uint32_t qm = 0;
+        for (uint32_t g = 0; g < (B >> 2); ++g) qm |= ((pc.M >> (4 * g)) & 0xFu) ? 1u << g : 0u;
+#if PCP_NEQ_XOR
+        // The walked variable has the SAME cell in every node of these quads — the rule, not the exception: the nodes of a tile are
+        // neighbours in the search tree and hold the queens of their common ancestors at the same values.  Then what an entry's other
+        // side must match is a property of the entry alone (neq_target16), and an (entry, node) test is one exclusive-or and one
+        // packed minimum instead of a packed add on top (v_pk_* issue at half rate: tools/micro/box_probe.hip).
+        const uint32_t cvu = dom[rv + 4u * (uint32_t)__builtin_ctz(qm)];
+        uint32_t differ = 0;
+        for (uint32_t qq = qm; qq; qq &= qq - 1u) {
+          const uint4 c = *reinterpret_cast<const uint4*>(dom + rv + 4u * (uint32_t)__builtin_ctz(qq));
+          differ |= (c.x ^ cvu) | (c.y ^ cvu) | (c.z ^ cvu) | (c.w ^ cvu);
+        }
+        if (__builtin_amdgcn_readfirstlane(differ) == 0u) {  // (every lane read the same cells: wave-uniform)
+          uint32_t T[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) T[u] = neq_target16(cvu, K[u]);
+          if (__popc(qm) & 1) {
+            const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+            qm &= qm - 1;
+            uint4 o0[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u])));
+          }
+          while (qm) {
+            const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+            qm &= qm - 1;
+            const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
+            qm &= qm - 1;
+            uint4 o0[4], o1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint32_t m0 = pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u]));
+              const uint32_t m1 = pk_min_u16(pk_min_u16(o1[u].x ^ T[u], o1[u].y ^ T[u]), pk_min_u16(o1[u].z ^ T[u], o1[u].w ^ T[u]));
+              acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
+            }
+          }
+        }
+#endif
+        if (__popc(qm) & 1) {  // an odd quad out, by itself
+          const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+          qm &= qm - 1;
+          const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0);
+          uint4 o0[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if ((uint32_t)u >= nu) continue;  // (a short piece)
+            uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
+            uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
+            acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
+          }
+        }
+        while (qm) {
+          const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
+          qm &= qm - 1;
+          const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
+          qm &= qm - 1;
+          const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0), c1 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g1);
+          uint4 o0[4], o1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if ((uint32_t)u >= nu) continue;
+            uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
+            uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
+            uint32_t m2 = pk_min_u16(neq_terms16(c1.x, o1[u].x, K[u]), neq_terms16(c1.y, o1[u].y, K[u]));
+            uint32_t m3 = pk_min_u16(neq_terms16(c1.z, o1[u].z, K[u]), neq_terms16(c1.w, o1[u].w, K[u]));
+            acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(m0, m1), pk_min_u16(m2, m3)));
+          }
+        }
+      } else {
+        uint32_t k = 0;
+        for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
+          const uint32_t b = (uint32_t)__builtin_ctz(m);
+          const uint32_t c0 = dom[rv + b];
+          uint32_t oc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { oc[u] = dom[ro[u] + b]; acc[u] = pk_min_u16(acc[u], neq_terms16(c0, oc[u], K[u])); }
+          const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
+          if (wi != kNoWin) {
+            // the values assigned neighbours forbid for v, near its bounds (the bounds the window was opened with)
+            Win* wp = win + wi;
+            const int lb0 = wp->lb0, ub0 = wp->ub0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int2 O = unpack16(oc[u]);
+              if (valid[u] && O.x == O.y) {
+                const int f = O.x - t[u];  // lb(v) + t == O  <=>  lb(v) == f
+                const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
+                if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
+                if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hit[u] = valid[u] && zero_half(acc[u]);
+    } else {
+      uint32_t k = 0;
+      for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
+        const uint32_t b = (uint32_t)__builtin_ctz(m);
+        const int2 c0 = dom[rv + b];
+        const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
+        Win* wp = win + (wi != kNoWin ? wi : 0u);
+        int lb0 = 0, ub0 = 0;
+        if (wi != kNoWin) { lb0 = wp->lb0; ub0 = wp->ub0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // lb(v) + t == ub(o)  |  ub(v) + t == lb(o)
+          const int2 o = dom[ro[u] + b];
+          hit[u] |= (c0.x + o.y == t[u]) | (c0.y + o.x == -t[u]);
+          if (wi != kNoWin && valid[u] && -o.x == o.y) {
+            const int f = o.y - t[u];
+            const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
+            if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
+            if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hit[u] = hit[u] && valid[u];
+    }
+    if (timing) t_inner += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)hit[0] | (uint32_t)hit[3]) & 0u) - ti0;
+    const uint32_t nm = (uint32_t)__popc(pc.M);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) my_ev += valid[u] ? nm : 0u;
+    if (hit[0] | hit[1] | hit[2] | hit[3]) {
+      // flagged entries: the full filter, in the nodes whose domains meet the condition
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!hit[u]) continue;
+        const bool is_y = pay_is_y(q[u]);
+        Rec rec;
+        rec.xk = (is_y ? other[u] : pc.v) | ((uint32_t)PCP_NEQ << 28);
+        rec.y = is_y ? pc.v : other[u];
+        rec.z = 0;
+        rec.d = is_y ? t[u] : -t[u];
+        for (uint32_t m = pc.M; m; m &= m - 1) {
+          const uint32_t b = (uint32_t)__builtin_ctz(m);
+          const int2 Vd = cell_bounds<PACKED>(dom[rv + b]), O = cell_bounds<PACKED>(dom[ro[u] + b]);
+          if (Vd.x + t[u] != O.y && Vd.y + t[u] != O.x) continue;
+          ++ctr.full;
+          eval_record(rec, dom_of(b, &ctr));
+        }
+      }
+    }
+  };
+  Piece pa = next_piece(), pb, pc3;
+  Pay qA[4], qB[4], qC[4];
+  load(pa, qA);
+  if (round == 0) PCP_TR(6);
+  pb = next_piece(); load(pb, qB);
+  while (pa.deg) {
+    pc3 = next_piece(); load(pc3, qC);
+    process(pa, qA);
+    if (!pb.deg) break;
+    pa = next_piece(); load(pa, qA);
+    process(pb, qB);
+    if (!pc3.deg) break;
+    pb = next_piece(); load(pb, qB);
+    process(pc3, qC);
+  }
+  if (timing && lane == 0 && round == 0) {
+    atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_walk0));
+    atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)t_inner);
+    atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)n_pieces);
+  }
+  return my_ev;
+}
+
+// ---- (a) of a round: one list for the tile, (variable, mask of the nodes in which it changed).  The marks of the listed variables are
+// consumed here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
+// marks and are listed by the next round.
+// One WAVEFRONT per mask word, lane b = node b.  Four words per step with their LDS reads in flight together; the variables of
+// a word come out of ballots and readlanes alone: the lanes that still hold an unlisted bit are balloted, the first of them names
+// a bit, a second ballot over that bit is the variable's node mask.  (One ballot per bit position of every non-empty word, each
+// behind a dependent LDS read, made this pass 10 000 cycles of a frontier tile's 45 000 for ONE listed variable.)
+// Round 0 of a frontier tile finds its list built by the staging loop (`vmk`: the node masks) and only completes the entries.
+template <bool PACKED, class Tile>
+__device__ __forceinline__ void neq_build_list(const Tile& tl, uint32_t* const vmk, const uint32_t round, const bool r0_direct, const uint32_t inert, const uint32_t wcap) {
+  const uint32_t tid = tl.tid, nth = tl.nth, lane = tl.lane, wv = tl.wv, nwv = tl.nwv, nb = tl.nb, B = tl.B, V = tl.V, Wv = tl.Wv;
+  auto* const dom = tl.dom;
+  uint32_t* const chg = tl.chg;
+  uint32_t* const misc = tl.misc;
+  const uint32_t* const adjo = tl.adjo;
+  uint4* const list = tl.list;
+  Win* const win = tl.win;
+  auto rowof = [&](uint32_t slot) { return tl.rowof(slot); };
+  const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
+  const bool r0_listed = round == 0 && r0_direct && misc[N_R0OVF] == 0u;  // (workgroup-uniform: written before the staging barrier)
+  if (r0_listed) {
+    // round 0's list is there already (staging): complete its entries — mask without the failed and refused nodes, list offset, degree —
+    // and drop the marks staging set for the same variables (kept until here for the overflow case below)
+    for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
+    if (tid < misc[N_COUNT0]) {
+      const uint32_t v = list[tid].x;
+      const uint32_t M = (vmk[v >> 1] >> (16u * (v & 1u))) & 0xffffu & ~inert;
+      const uint32_t o0 = adjo[v], dg = adjo[v + 1] - o0;
+      list[tid] = make_uint4(v | (M << 16), o0, dg, kNoWin | (kNoWin << 16));
+      if (M) atomicOr(&misc[m_rmask], M);
+    }
+  } else {
+    if (round == 0 && r0_direct) {  // more assigned variables than the list holds: the marks are scanned as in every other round
+      __syncthreads();
+      if (tid == 0) misc[N_COUNT0] = 0;
+      __syncthreads();
+    }
+    uint32_t rm = 0;
+    bool list_full = false;
+    for (uint32_t w0 = wv; w0 < Wv && !list_full; w0 += 4 * nwv) {
+      uint32_t xs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const uint32_t w = w0 + j * nwv; xs[j] = (lane < nb && w < Wv) ? chg[lane * Wv + w] : 0u; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t w = w0 + j * nwv;
+        uint32_t x = xs[j];
+        if ((inert >> lane) & 1u) { if (x) chg[lane * Wv + w] = 0; x = 0; }  // a failed or refused node is inert  (lanes >= nb hold 0)
+        uint32_t taken = 0;  // wave-uniform: the bits of this word listed so far
+        while (!list_full) {
+          const unsigned long long holders = __ballot((x & ~taken) != 0u);
+          if (!holders) break;
+          const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)(x & ~taken), (int)__builtin_ctzll(holders));
+          const uint32_t i = (uint32_t)__builtin_ctz(xf);
+          const uint32_t M = (uint32_t)__ballot((x >> i) & 1u);
+          // lane 0 emits the entry (wave-uniform values: every lane computes them, one writes)
+          uint32_t pos = 0;
+          if (lane == 0) pos = atomicAdd(&misc[m_count], 1u);
+          pos = __builtin_amdgcn_readfirstlane(pos);
+          if (pos >= kListCap) {  // full: this variable and the rest wait for the next round
+            if (lane == 0) { atomicSub(&misc[m_count], 1u); misc[N_MORE] = round + 1; }
+            list_full = true;
+            break;
+          }
+          taken |= 1u << i;
+          const uint32_t v = (w << 5) + i;
+          const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
+          // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
+          uint32_t wsel = kNoWin | (kNoWin << 16);
+          if (round && wcap && __popc(M) <= 2) {
+            uint32_t k = 0;
+            for (uint32_t m = M; m; m &= m - 1, ++k) {
+              const uint32_t b = (uint32_t)__builtin_ctz(m);
+              const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
+              if (d.x >= d.y) continue;
+              uint32_t wi = 0;
+              if (lane == 0) wi = atomicAdd(&misc[m_win], 1u);
+              wi = __builtin_amdgcn_readfirstlane(wi);
+              if (wi >= wcap) continue;
+              if (lane == 0) {
+                Win nw;
+                nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
+                win[wi] = nw;
+              }
+              wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
+            }
+          }
+          if (lane == 0) list[pos] = make_uint4(v | (M << 16), o0, dg, wsel);
+          rm |= M;
+        }
+        if (lane < nb && (x & taken)) chg[lane * Wv + w] = x & ~taken;
+      }
+    }
+    if (rm && lane == 0) atomicOr(&misc[m_rmask], rm);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Staging of a FULL tile (16 nodes, 16-bit cells, whole 16-byte quads, aligned rows) — the frontier launch's dominant phase by
 // instructions: 59 % of its VALU and 67 % of its SALU wave-instructions were staging (profiles/r05_phases_*: 100 VALU + 73 SALU per
@@ -389,6 +962,228 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
   return badm | (oobm << 16);
 }
 
+// ---- phase 0 of a tile: stage the nodes' rows as cells (16-byte row loads where the rows allow it), find the assigned variables — they
+// are marked for round 0, or listed directly (`r0_direct`: vmk masks + the list's first kR0Cap entries) —, fail nodes with an empty
+// domain, refuse nodes with a bound outside the cells' range, and mark the ONE changed variable of hinted nodes instead of their assigned
+// ones.  The first tile of a workgroup also stores the list offsets it requested before (adj_pre) behind its row loads.
+template <bool PACKED, bool DFS, int BT, class Tile>
+__device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a, uint32_t* const vmk, const NeqCarve& cv, unsigned char* const smem, const uint32_t S,
+                                                const uint32_t node0, const bool r0_direct, const bool vec, const uint32_t dfs_hint, uint32_t (&adj_pre)[4], bool& adj_stored) {
+  using Cell = typename NeqCell<PACKED>::type;
+  const uint32_t tid = tl.tid, nth = tl.nth, nb = tl.nb, B = tl.B, V = tl.V, Wv = tl.Wv;
+  Cell* const dom = tl.dom;
+  uint32_t* const chg = tl.chg;
+  uint32_t* const misc = tl.misc;
+  uint32_t* const adjo = const_cast<uint32_t*>(tl.adjo);
+  uint4* const list = tl.list;
+  auto rowof = [&](uint32_t slot) { return tl.rowof(slot); };
+  const int lim = PACKED ? kPackedMax : kBoundMax;
+  uint32_t badm = 0, oobm = 0;
+  const uint32_t hintm = DFS ? (dfs_hint < V ? 1u : 0u) : a.dirty ? (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_HINT]) : 0u;  // (written before the barrier above)
+  // returns bit 0 = an empty domain among the four, bit 1 = a bound out of range (the callers collect them per node)
+  auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) -> uint32_t {
+    if (PCP_PUT_FAST && cnt == 4) {
+      // Four whole slots — every put of a store whose size is a multiple of four.  The kernel is bound by instruction issue (four
+      // wavefronts share a SIMD), so this is counted in instructions: the range check is a minimum and a maximum over the eight
+      // bounds (v_min3 / v_max3) instead of sixteen compares; an empty or a singleton domain shows as min(ub - lb) <= 0, and only
+      // then are the four looked at one by one; a cell is packed by one subtraction and one byte permute.
+      const int mn = min(min(min(l[0], l[1]), min(l[2], l[3])), min(min(u[0], u[1]), min(u[2], u[3])));
+      const int mx = max(max(max(l[0], l[1]), max(l[2], l[3])), max(max(u[0], u[1]), max(u[2], u[3])));
+      const int dmin = min(min(u[0] - l[0], u[1] - l[1]), min(u[2] - l[2], u[3] - l[3]));
+      // (v0 is a multiple of four: the four rows are B cells apart, no padding between them.  With 16-node tiles row(4q) = 68 q: a 24-bit
+      // multiply, full rate — the 32-bit v_mul_lo_u32 the compiler picks for "q * 272 bytes" is quarter rate, sixteen cycles per wavefront)
+      Cell* const p0 = dom + (BT >= 16 ? __umul24(v0 >> 2, 4u * B + 4u) : rowof(v0)) + b;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (PACKED) p0[i * B] = __builtin_amdgcn_perm((uint32_t)u[i], (uint32_t)(-l[i]), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
+        else p0[i * B] = make_int2(-l[i], u[i]);
+      }
+      // everything else is ONE rarely taken branch: a bound out of range (the node is refused, not wrapped: pcp_hip.h), an empty domain
+      // (the node is failed), a singleton (an assigned variable: marked for the sweep round) or a model with Constant neighbours
+      if (((mn < -lim) | (mx > lim) | (dmin <= 0)) || a.seed_always) {
+        uint32_t nib = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
+        if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
+        if ((hintm >> b) & 1u) nib = 0;  // a hinted node: its assigned variables' records ran at the parent's fixpoint
+        if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+        // (only while the tile has few assigned variables — a frontier: deep tiles, where most quads come through here, give up after
+        // kR0Cap variables and pay one LDS read per quad from then on; they are listed by the scan, which is a small part of THEIR time)
+        if (r0_direct && misc[N_R0OVF] == 0u) {
+          for (uint32_t m = nib; m; m &= m - 1u) {
+            const uint32_t v = v0 + (uint32_t)__builtin_ctz(m), hs = 16u * (v & 1u);
+            const uint32_t old = atomicOr(&vmk[v >> 1], (1u << b) << hs);
+            if (((old >> hs) & 0xffffu) == 0u) {  // the first node of the tile with this variable: it goes on the list
+              const uint32_t pos = atomicAdd(&misc[N_COUNT0], 1u);
+              if (pos < kR0Cap) list[pos].x = v; else misc[N_R0OVF] = 1u;
+            }
+          }
+        }
+        return (((mn < -lim) | (mx > lim)) ? 2u : 0u) | (dmin < 0 ? 1u : 0u);
+      }
+      return 0u;
+    }
+    uint32_t nib = 0;
+    bool bad = false, oob = false;
+    Cell cl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool on = (uint32_t)i < cnt;
+      bad |= on && l[i] > u[i];                                                    // empty input domain: the node is failed
+      oob |= on && ((l[i] < -lim) | (l[i] > lim) | (u[i] < -lim) | (u[i] > lim));  // refused, not wrapped (pcp_hip.h)
+      nib |= (on && l[i] == u[i]) ? 1u << i : 0u;
+      if constexpr (PACKED) cl[i] = pack16(l[i], u[i]); else cl[i] = make_int2(-l[i], u[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((uint32_t)i < cnt) dom[rowof(v0 + i) + b] = cl[i];
+    if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
+    if ((hintm >> b) & 1u) nib = 0;
+    if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+    return (bad ? 1u : 0u) | (oob ? 2u : 0u);
+  };
+  auto note = [&](uint32_t f, uint32_t b) { if (f) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; } };
+  const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
+  if (vec) {
+    // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight
+    // 16-byte pairs per lane = 64 VGPRs): one memory round trip per tile instead of two in a row
+    constexpr int UF = PACKED ? 8 : 6;  // (the int2-cell instantiations have fewer registers to spare)
+    // task t = (node t / SQ, quad t % SQ); a lane's tasks are nth apart: one division per lane, then (node, quad) move by a fixed step
+    const uint32_t dq = nth % SQ, db = nth / SQ;
+    // (opaque per tile: everything below depends on the thread index alone, and hoisted out of the tile loop it would sit in two dozen
+    // registers — spilled — for the whole kernel)
+    const uint32_t tid_o = tid;
+    uint32_t bs = tid_o / SQ, qs = tid_o - bs * SQ;
+    auto step = [&](uint32_t& bq, uint32_t& qq) { qq += dq; bq += db; if (qq >= SQ) { qq -= SQ; ++bq; } };
+    // (a tile's rows are contiguous: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
+    // pair of loads, which lb and ub share; sixteen 64-bit addresses would take 32 of the VGPRs the loaded rows need)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
+    if (BT >= 16) {
+      // 16-node tiles.  A wavefront's task = FOUR nodes x SIXTEEN consecutive quads (lanes 0-15 node 4g, 16-31 node 4g+1, ...): the loads are
+      // still 256 contiguous bytes per row, and the 64 cells a wavefront writes per store — word 68 q + b, q = 16 consecutive, b = 4 consecutive —
+      // fall on all 32 LDS banks, two lanes each.  (64 consecutive quads of ONE node, the obvious mapping, put word 68 q + b on 8 banks: every
+      // ds_write of the staging loop ran 8-way conflicted — most of the launch's SQ_LDS_BANK_CONFLICT cycles.)
+      const uint32_t QC = (SQ + 15u) >> 4;
+      const uint32_t lane_o = tid_o & 63u, lb4 = lane_o >> 4, lq = lane_o & 15u;
+      const uint32_t wv_s = __builtin_amdgcn_readfirstlane(tid_o >> 6), nwv_s = nth >> 6;
+      const uint32_t dqc = nwv_s % QC, dng = nwv_s / QC;
+      const uint32_t ng_first = wv_s / QC, qc_first = wv_s - ng_first * QC;  // (wave-uniform: scalar registers)
+      const uint32_t ro_lane = lb4 * V * 4u + 16u * lq;
+      // UF wave-tasks from (w0; ng, qc) of a tile of tnb nodes behind the descriptors (r_lb, r_ub): the loads / the cells
+      auto loadw = [&](const __amdgpu_buffer_rsrc_t r_lb, const __amdgpu_buffer_rsrc_t r_ub, uint32_t tnb, uint32_t w0, uint32_t ng, uint32_t qc, int4 (&L)[UF], int4 (&U)[UF]) {
+        const uint32_t wt = ((tnb + 3u) >> 2) * QC;
+#pragma unroll
+        for (int j = 0; j < UF; ++j) {
+          const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
+          const bool on = w0 + j * nwv_s < wt && q < SQ && b < tnb;
+          const uint32_t off = on ? ro_lane + ng * (16u * V) + qc * 256u : 0u;
+          const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(r_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(r_ub, (int)off, 0, 0);
+          L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
+          U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
+          qc += dqc; ng += dng;
+          if (qc >= QC) { qc -= QC; ++ng; }
+        }
+      };
+      const uint32_t wtasks = ((nb + 3u) >> 2) * QC;
+      auto putw = [&](const int4 (&L)[UF], const int4 (&U)[UF], uint32_t w0, uint32_t& ng, uint32_t& qc) {
+#pragma unroll
+        for (int j = 0; j < UF; ++j) {
+          if (w0 + j * nwv_s >= wtasks) break;  // (uniform)
+          const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
+          if (q < SQ && b < nb) {
+            const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
+            note(put(b, 4 * q, l, u, 4), b);
+          }
+          qc += dqc; ng += dng;
+          if (qc >= QC) { qc -= QC; ++ng; }
+        }
+      };
+      auto store_adj = [&]() {
+        if (!adj_stored) {
+          adj_stored = true;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+        }
+      };
+      uint32_t ngs = ng_first, qcs = qc_first;
+      if (PACKED && BT == 16 && nb == 16u && !(a.debug & 32768u)) {
+        // a full tile: the lean loop (stage_tile16), out of line
+        store_adj();
+        const uint32_t r = stage_tile16(StageTile16Args{a.lb_in + (size_t)node0 * V, a.ub_in + (size_t)node0 * V, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
+                                                        (uint32_t)cv.vmk, (uint32_t)cv.list, (uint32_t)(reinterpret_cast<unsigned char*>(misc) - smem), hintm,
+                                                        r0_direct ? 1u : 0u, wv_s, nwv_s});
+        badm |= r & 0xffffu; oobm |= r >> 16;
+      } else
+      for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
+        int4 L[UF], U[UF];
+        loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
+        store_adj();
+        putw(L, U, w0, ngs, qcs);
+      }
+    } else
+    for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
+      int4 L[UF], U[UF];
+      uint32_t bq = bs, qq = qs;
+      uint32_t ro = bs * V * 4u;
+#pragma unroll
+      for (int j = 0; j < UF; ++j) {
+        const uint32_t off = t0 + j * nth < tasks ? ro + 16u * qq : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
+        const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
+        L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
+        U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
+        // the row's byte offset moves with the node by additions (a 32-bit multiply per load pair is a quarter-rate instruction)
+        qq += dq; bq += db; ro += db * V * 4u;
+        if (qq >= SQ) { qq -= SQ; ++bq; ro += V * 4u; }
+      }
+      if (!adj_stored) {
+        adj_stored = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+      }
+      bq = bs; qq = qs;
+#pragma unroll
+      for (int j = 0; j < UF; ++j) {
+        if (t0 + j * nth >= tasks) break;
+        const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
+        note(put(bq, 4 * qq, l, u, 4), bq);
+        step(bq, qq);
+      }
+      bs = bq; qs = qq;
+    }
+  } else {
+    for (uint32_t t = tid; t < tasks; t += nth) {
+      const uint32_t b = t / SQ, q = t - b * SQ, v0 = 4 * q, cnt = min(4u, V - v0);
+      const size_t row = (size_t)misc[N_NID + b] * V;
+      int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((uint32_t)i < cnt) {
+          if constexpr (DFS) {
+            l[i] = __hip_atomic_load(a.lb_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u[i] = __hip_atomic_load(a.ub_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i];
+          }
+        }
+      note(put(b, v0, l, u, cnt), b);
+    }
+  }
+  // interned constants: singleton pseudo-variables behind the variables (term/constant.rs:43-68)
+  for (uint32_t t = tid; t < nb * (S - V); t += nth) {
+    const uint32_t b = t / (S - V), s = V + (t - b * (S - V));
+    const int c = a.m.const_val[s - V];
+    if constexpr (PACKED) dom[rowof(s) + b] = pack16(c, c); else dom[rowof(s) + b] = make_int2(-c, c);
+  }
+  if (badm) atomicOr(&misc[N_FAIL], badm);
+  if (oobm) atomicOr(&misc[N_OOB], oobm);
+  if (hintm && tid < nb && ((hintm >> tid) & 1u)) {  // the hinted nodes' one changed variable
+    const uint32_t dv = DFS ? dfs_hint : a.dirty[node0 + tid];
+    atomicOr(&chg[tid * Wv + (dv >> 5)], 1u << (dv & 31u));
+  }
+}
+
 // DFS = true: ONE workgroup runs the reference's search loop itself (pcp_dfs_device) — OneSolution / AllSolution over
 // Propagation<Brancher<FirstSmallestVar, MiddleVal, BinarySplit>> on a VectorStack (search/mod.rs:45-52, one_solution.rs:92-105),
 // under StopNode (stop_node.rs:47-62): up to a.dfs.n_steps nodes per launch, each popped from the device stack, propagated, counted
@@ -401,7 +1196,7 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
 // cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
 // kernel does not have (it spills scalars into VGPR lanes as it is).
 template <bool PACKED, bool PAY4, bool DFS, int BT>
-__global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs a_in) {
+__global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(4))) neqfix_kernel(const NeqArgs a_in) {  // (four wavefronts per SIMD: the forest runs 16 per CU)
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
   if (a.dbg) a.dbg += (size_t)(blockIdx.x & (kStatSlots - 1)) * PCP_DBG_COUNT;
@@ -438,7 +1233,6 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
   const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
   unsigned long long* const trbuf = reinterpret_cast<unsigned long long*>(smem + cv.win + (size_t)wcap * sizeof(Win));
-#define PCP_TR(k) do { if (tr_on && lane == 0) trbuf[wv * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
   PCP_TR(0);
   auto rowof = [&](uint32_t slot) { return neq_row(slot, B, sh); };  // index of node 0's cell of a slot
   Cell* const dom = reinterpret_cast<Cell*>(smem + cv.dom);
@@ -471,7 +1265,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
   bool adj_loaded = false, adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
-  uint32_t dfs_sp = 0, dfs_stop = 0, dfs_resume_var = 0xFFFFFFFFu, dfs_hint = 0xFFFFFFFFu;
+  NeqDfsRegs dfs{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0ull, 0ull, 0ull};
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
   // the forest of one tree; pcp_dfs_forest_device launches many, each an independent instance of the same loop)
   const size_t tree_row0 = DFS ? (size_t)blockIdx.x * a_in.dfs.capacity : 0;
@@ -480,10 +1274,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (a.dfs.first_solution) a.dfs.first_solution += (size_t)blockIdx.x * V;
     if (a.dfs.dirty) a.dfs.dirty += tree_row0;
   }
-  unsigned long long c_nodes = 0, c_sols = 0, c_fail = 0;  // DFS: the search counters, replicated in every thread
   unsigned long long acc_steps = 0, acc_narrow = 0, acc_ev = 0, acc_full = 0, acc_waves = 0, acc_nodes = 0, acc_failed = 0;  // DFS: pcp_stats, per launch
-  uint32_t c_err = 0;
-  if constexpr (DFS) { dfs_sp = *a.dfs.sp; dfs_stop = *a.dfs.stop; c_nodes = a.dfs.counters[0]; c_sols = a.dfs.counters[1]; c_fail = a.dfs.counters[2]; }
+  if constexpr (DFS) { dfs.sp = *a.dfs.sp; dfs.stop = *a.dfs.stop; dfs.nodes = a.dfs.counters[0]; dfs.sols = a.dfs.counters[1]; dfs.fail = a.dfs.counters[2]; }
   const int lim = PACKED ? kPackedMax : kBoundMax;
   uint32_t* const misc_base = misc;
   // a persistent workgroup's counters over its tiles: seven u64 in LDS behind the two copies of the status words, touched by thread 0 only
@@ -511,13 +1303,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     lane = tid & 63u;
   }
   if constexpr (DFS) {
-    if (dfs_sp == 0 || dfs_stop || dfs_it >= a.dfs.n_steps) break;
-    const size_t off = (tree_row0 + (dfs_sp - 1)) * V;
-    a.lb_in = a_in.lb_in + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + tree_row0 + (dfs_sp - 1);
-    resume = dfs_resume_var != 0xFFFFFFFFu;
+    if (dfs.sp == 0 || dfs.stop || dfs_it >= a.dfs.n_steps) break;
+    const size_t off = (tree_row0 + (dfs.sp - 1)) * V;
+    a.lb_in = a_in.lb_in + off; a.ub_in = a_in.ub_in + off; a.lb_out = a_in.lb_out + off; a.ub_out = a_in.ub_out + off; a.status = a_in.status + tree_row0 + (dfs.sp - 1);
+    resume = dfs.resume_var != 0xFFFFFFFFu;
     // a popped row: the variable it was branched on, if the stack keeps them (pcp_dfs_state.dirty) — it is a propagated parent with that
     // one variable moved, so its first round is that variable's lists (the rows of this very launch are read past the L1, like the bounds)
-    dfs_hint = (!resume && a.dfs.dirty) ? __hip_atomic_load(a.dfs.dirty + (dfs_sp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+    dfs.hint = (!resume && a.dfs.dirty) ? __hip_atomic_load(a.dfs.dirty + (dfs.sp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
   if (tid == (uint32_t)N_R0OVF) misc[tid] = 0;
@@ -552,212 +1344,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   // DFS rows may have been written by this very workgroup a moment ago: they are read past the L1 (relaxed agent-scope loads)
   const bool vec = !DFS && (V & 3u) == 0 && (((size_t)a.lb_in | (size_t)a.ub_in) & 15u) == 0;
   if (resume) {
-    if (tid == 0) chg[dfs_resume_var >> 5] = 1u << (dfs_resume_var & 31u);  // the left child: only the variable branched on has changed
+    if (tid == 0) chg[dfs.resume_var >> 5] = 1u << (dfs.resume_var & 31u);  // the left child: only the variable branched on has changed
   } else {
-    uint32_t badm = 0, oobm = 0;
-    const uint32_t hintm = DFS ? (dfs_hint < V ? 1u : 0u) : a.dirty ? (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_HINT]) : 0u;  // (written before the barrier above)
-    // returns bit 0 = an empty domain among the four, bit 1 = a bound out of range (the callers collect them per node)
-    auto put = [&](uint32_t b, uint32_t v0, const int (&l)[4], const int (&u)[4], uint32_t cnt) -> uint32_t {
-      if (PCP_PUT_FAST && cnt == 4) {
-        // Four whole slots — every put of a store whose size is a multiple of four.  The kernel is bound by instruction issue (four
-        // wavefronts share a SIMD), so this is counted in instructions: the range check is a minimum and a maximum over the eight
-        // bounds (v_min3 / v_max3) instead of sixteen compares; an empty or a singleton domain shows as min(ub - lb) <= 0, and only
-        // then are the four looked at one by one; a cell is packed by one subtraction and one byte permute.
-        const int mn = min(min(min(l[0], l[1]), min(l[2], l[3])), min(min(u[0], u[1]), min(u[2], u[3])));
-        const int mx = max(max(max(l[0], l[1]), max(l[2], l[3])), max(max(u[0], u[1]), max(u[2], u[3])));
-        const int dmin = min(min(u[0] - l[0], u[1] - l[1]), min(u[2] - l[2], u[3] - l[3]));
-        // (v0 is a multiple of four: the four rows are B cells apart, no padding between them.  With 16-node tiles row(4q) = 68 q: a 24-bit
-        // multiply, full rate — the 32-bit v_mul_lo_u32 the compiler picks for "q * 272 bytes" is quarter rate, sixteen cycles per wavefront)
-        Cell* const p0 = dom + (BT >= 16 ? __umul24(v0 >> 2, 4u * B + 4u) : rowof(v0)) + b;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if constexpr (PACKED) p0[i * B] = __builtin_amdgcn_perm((uint32_t)u[i], (uint32_t)(-l[i]), 0x05040100u);  // ub << 16 | (-lb & 0xffff)
-          else p0[i * B] = make_int2(-l[i], u[i]);
-        }
-        // everything else is ONE rarely taken branch: a bound out of range (the node is refused, not wrapped: pcp_hip.h), an empty domain
-        // (the node is failed), a singleton (an assigned variable: marked for the sweep round) or a model with Constant neighbours
-        if (((mn < -lim) | (mx > lim) | (dmin <= 0)) || a.seed_always) {
-          uint32_t nib = 0;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) nib |= (l[i] == u[i]) ? 1u << i : 0u;
-          if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
-          if ((hintm >> b) & 1u) nib = 0;  // a hinted node: its assigned variables' records ran at the parent's fixpoint
-          if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
-          // (only while the tile has few assigned variables — a frontier: deep tiles, where most quads come through here, give up after
-          // kR0Cap variables and pay one LDS read per quad from then on; they are listed by the scan, which is a small part of THEIR time)
-          if (r0_direct && misc[N_R0OVF] == 0u) {
-            for (uint32_t m = nib; m; m &= m - 1u) {
-              const uint32_t v = v0 + (uint32_t)__builtin_ctz(m), hs = 16u * (v & 1u);
-              const uint32_t old = atomicOr(&vmk[v >> 1], (1u << b) << hs);
-              if (((old >> hs) & 0xffffu) == 0u) {  // the first node of the tile with this variable: it goes on the list
-                const uint32_t pos = atomicAdd(&misc[N_COUNT0], 1u);
-                if (pos < kR0Cap) list[pos].x = v; else misc[N_R0OVF] = 1u;
-              }
-            }
-          }
-          return (((mn < -lim) | (mx > lim)) ? 2u : 0u) | (dmin < 0 ? 1u : 0u);
-        }
-        return 0u;
-      }
-      uint32_t nib = 0;
-      bool bad = false, oob = false;
-      Cell cl[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool on = (uint32_t)i < cnt;
-        bad |= on && l[i] > u[i];                                                    // empty input domain: the node is failed
-        oob |= on && ((l[i] < -lim) | (l[i] > lim) | (u[i] < -lim) | (u[i] > lim));  // refused, not wrapped (pcp_hip.h)
-        nib |= (on && l[i] == u[i]) ? 1u << i : 0u;
-        if constexpr (PACKED) cl[i] = pack16(l[i], u[i]); else cl[i] = make_int2(-l[i], u[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((uint32_t)i < cnt) dom[rowof(v0 + i) + b] = cl[i];
-      if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
-      if ((hintm >> b) & 1u) nib = 0;
-      if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
-      return (bad ? 1u : 0u) | (oob ? 2u : 0u);
-    };
-    auto note = [&](uint32_t f, uint32_t b) { if (f) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; } };
-    const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
-    if (vec) {
-      // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight
-      // 16-byte pairs per lane = 64 VGPRs): one memory round trip per tile instead of two in a row
-      constexpr int UF = PACKED ? 8 : 6;  // (the int2-cell instantiations have fewer registers to spare)
-      // task t = (node t / SQ, quad t % SQ); a lane's tasks are nth apart: one division per lane, then (node, quad) move by a fixed step
-      const uint32_t dq = nth % SQ, db = nth / SQ;
-      // (opaque per tile: everything below depends on the thread index alone, and hoisted out of the tile loop it would sit in two dozen
-      // registers — spilled — for the whole kernel)
-      const uint32_t tid_o = tid;
-      uint32_t bs = tid_o / SQ, qs = tid_o - bs * SQ;
-      auto step = [&](uint32_t& bq, uint32_t& qq) { qq += dq; bq += db; if (qq >= SQ) { qq -= SQ; ++bq; } };
-      // (a tile's rows are contiguous: buffer loads — a descriptor of the tile's rows in SGPRs and ONE 32-bit byte offset per
-      // pair of loads, which lb and ub share; sixteen 64-bit addresses would take 32 of the VGPRs the loaded rows need)
-      typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.lb_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(a.ub_in + (size_t)node0 * V), 0, (int)(nb * V * 4u), 0x00020000);
-      if (BT >= 16) {
-        // 16-node tiles.  A wavefront's task = FOUR nodes x SIXTEEN consecutive quads (lanes 0-15 node 4g, 16-31 node 4g+1, ...): the loads are
-        // still 256 contiguous bytes per row, and the 64 cells a wavefront writes per store — word 68 q + b, q = 16 consecutive, b = 4 consecutive —
-        // fall on all 32 LDS banks, two lanes each.  (64 consecutive quads of ONE node, the obvious mapping, put word 68 q + b on 8 banks: every
-        // ds_write of the staging loop ran 8-way conflicted — most of the launch's SQ_LDS_BANK_CONFLICT cycles.)
-        const uint32_t QC = (SQ + 15u) >> 4;
-        const uint32_t lane_o = tid_o & 63u, lb4 = lane_o >> 4, lq = lane_o & 15u;
-        const uint32_t wv_s = __builtin_amdgcn_readfirstlane(tid_o >> 6), nwv_s = nth >> 6;
-        const uint32_t dqc = nwv_s % QC, dng = nwv_s / QC;
-        const uint32_t ng_first = wv_s / QC, qc_first = wv_s - ng_first * QC;  // (wave-uniform: scalar registers)
-        const uint32_t ro_lane = lb4 * V * 4u + 16u * lq;
-        // UF wave-tasks from (w0; ng, qc) of a tile of tnb nodes behind the descriptors (r_lb, r_ub): the loads / the cells
-        auto loadw = [&](const __amdgpu_buffer_rsrc_t r_lb, const __amdgpu_buffer_rsrc_t r_ub, uint32_t tnb, uint32_t w0, uint32_t ng, uint32_t qc, int4 (&L)[UF], int4 (&U)[UF]) {
-          const uint32_t wt = ((tnb + 3u) >> 2) * QC;
-#pragma unroll
-          for (int j = 0; j < UF; ++j) {
-            const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
-            const bool on = w0 + j * nwv_s < wt && q < SQ && b < tnb;
-            const uint32_t off = on ? ro_lane + ng * (16u * V) + qc * 256u : 0u;
-            const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(r_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(r_ub, (int)off, 0, 0);
-            L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
-            U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
-            qc += dqc; ng += dng;
-            if (qc >= QC) { qc -= QC; ++ng; }
-          }
-        };
-        const uint32_t wtasks = ((nb + 3u) >> 2) * QC;
-        auto putw = [&](const int4 (&L)[UF], const int4 (&U)[UF], uint32_t w0, uint32_t& ng, uint32_t& qc) {
-#pragma unroll
-          for (int j = 0; j < UF; ++j) {
-            if (w0 + j * nwv_s >= wtasks) break;  // (uniform)
-            const uint32_t b = 4u * ng + lb4, q = 16u * qc + lq;
-            if (q < SQ && b < nb) {
-              const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
-              note(put(b, 4 * q, l, u, 4), b);
-            }
-            qc += dqc; ng += dng;
-            if (qc >= QC) { qc -= QC; ++ng; }
-          }
-        };
-        auto store_adj = [&]() {
-          if (!adj_stored) {
-            adj_stored = true;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
-          }
-        };
-        uint32_t ngs = ng_first, qcs = qc_first;
-        if (PACKED && BT == 16 && nb == 16u && !(a.debug & 32768u)) {
-          // a full tile: the lean loop (stage_tile16), out of line
-          store_adj();
-          const uint32_t r = stage_tile16(StageTile16Args{a.lb_in + (size_t)node0 * V, a.ub_in + (size_t)node0 * V, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
-                                                          (uint32_t)cv.vmk, (uint32_t)cv.list, (uint32_t)(reinterpret_cast<unsigned char*>(misc) - smem), hintm,
-                                                          r0_direct ? 1u : 0u, wv_s, nwv_s});
-          badm |= r & 0xffffu; oobm |= r >> 16;
-        } else
-        for (uint32_t w0 = wv_s; w0 < wtasks; w0 += UF * nwv_s) {
-          int4 L[UF], U[UF];
-          loadw(rs_lb, rs_ub, nb, w0, ngs, qcs, L, U);
-          store_adj();
-          putw(L, U, w0, ngs, qcs);
-        }
-      } else
-      for (uint32_t t0 = tid_o; t0 < tasks; t0 += UF * nth) {
-        int4 L[UF], U[UF];
-        uint32_t bq = bs, qq = qs;
-        uint32_t ro = bs * V * 4u;
-#pragma unroll
-        for (int j = 0; j < UF; ++j) {
-          const uint32_t off = t0 + j * nth < tasks ? ro + 16u * qq : 0u;  // < 16 rows * 4 bytes * n_vars: 32 bits are plenty
-          const u32x4 lv = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)off, 0, 0), uv = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)off, 0, 0);
-          L[j] = make_int4((int)lv.x, (int)lv.y, (int)lv.z, (int)lv.w);
-          U[j] = make_int4((int)uv.x, (int)uv.y, (int)uv.z, (int)uv.w);
-          // the row's byte offset moves with the node by additions (a 32-bit multiply per load pair is a quarter-rate instruction)
-          qq += dq; bq += db; ro += db * V * 4u;
-          if (qq >= SQ) { qq -= SQ; ++bq; ro += V * 4u; }
-        }
-        if (!adj_stored) {
-          adj_stored = true;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
-        }
-        bq = bs; qq = qs;
-#pragma unroll
-        for (int j = 0; j < UF; ++j) {
-          if (t0 + j * nth >= tasks) break;
-          const int l[4] = {L[j].x, L[j].y, L[j].z, L[j].w}, u[4] = {U[j].x, U[j].y, U[j].z, U[j].w};
-          note(put(bq, 4 * qq, l, u, 4), bq);
-          step(bq, qq);
-        }
-        bs = bq; qs = qq;
-      }
-    } else {
-      for (uint32_t t = tid; t < tasks; t += nth) {
-        const uint32_t b = t / SQ, q = t - b * SQ, v0 = 4 * q, cnt = min(4u, V - v0);
-        const size_t row = (size_t)misc[N_NID + b] * V;
-        int l[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if ((uint32_t)i < cnt) {
-            if constexpr (DFS) {
-              l[i] = __hip_atomic_load(a.lb_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              u[i] = __hip_atomic_load(a.ub_in + row + v0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-              l[i] = a.lb_in[row + v0 + i]; u[i] = a.ub_in[row + v0 + i];
-            }
-          }
-        note(put(b, v0, l, u, cnt), b);
-      }
-    }
-    // interned constants: singleton pseudo-variables behind the variables (term/constant.rs:43-68)
-    for (uint32_t t = tid; t < nb * (S - V); t += nth) {
-      const uint32_t b = t / (S - V), s = V + (t - b * (S - V));
-      const int c = a.m.const_val[s - V];
-      if constexpr (PACKED) dom[rowof(s) + b] = pack16(c, c); else dom[rowof(s) + b] = make_int2(-c, c);
-    }
-    if (badm) atomicOr(&misc[N_FAIL], badm);
-    if (oobm) atomicOr(&misc[N_OOB], oobm);
-    if (hintm && tid < nb && ((hintm >> tid) & 1u)) {  // the hinted nodes' one changed variable
-      const uint32_t dv = DFS ? dfs_hint : a.dirty[node0 + tid];
-      atomicOr(&chg[tid * Wv + (dv >> 5)], 1u << (dv & 31u));
-    }
+    neq_stage_tile<PACKED, DFS, BT>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, vmk, cv, smem, S, node0, r0_direct, vec, dfs.hint,
+                                    adj_pre, adj_stored);
   }
   if (!adj_stored) {
     adj_stored = true;
@@ -800,89 +1390,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       bar();
     }
 #endif
-    // (a) one list for the tile: (variable, mask of the nodes in which it changed).  The marks of the listed variables are consumed
-    // here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
-    // marks and are listed by the next round.
-    // One WAVEFRONT per mask word, lane b = node b.  Four words per step with their LDS reads in flight together; the variables of
-    // a word come out of ballots and readlanes alone: the lanes that still hold an unlisted bit are balloted, the first of them names
-    // a bit, a second ballot over that bit is the variable's node mask.  (One ballot per bit position of every non-empty word, each
-    // behind a dependent LDS read, made this pass 10 000 cycles of a frontier tile's 45 000 for ONE listed variable.)
-    const bool r0_listed = round == 0 && r0_direct && misc[N_R0OVF] == 0u;  // (workgroup-uniform: written before the staging barrier)
-    if (r0_listed) {
-      // round 0's list is there already (staging): complete its entries — mask without the failed and refused nodes, list offset, degree —
-      // and drop the marks staging set for the same variables (kept until here for the overflow case below)
-      for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
-      if (tid < misc[N_COUNT0]) {
-        const uint32_t v = list[tid].x;
-        const uint32_t M = (vmk[v >> 1] >> (16u * (v & 1u))) & 0xffffu & ~inert;
-        const uint32_t o0 = adjo[v], dg = adjo[v + 1] - o0;
-        list[tid] = make_uint4(v | (M << 16), o0, dg, kNoWin | (kNoWin << 16));
-        if (M) atomicOr(&misc[m_rmask], M);
-      }
-    } else {
-      if (round == 0 && r0_direct) {  // more assigned variables than the list holds: the marks are scanned as in every other round
-        bar();
-        if (tid == 0) misc[N_COUNT0] = 0;
-        bar();
-      }
-      uint32_t rm = 0;
-      bool list_full = false;
-      for (uint32_t w0 = wv; w0 < Wv && !list_full; w0 += 4 * nwv) {
-        uint32_t xs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const uint32_t w = w0 + j * nwv; xs[j] = (lane < nb && w < Wv) ? chg[lane * Wv + w] : 0u; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t w = w0 + j * nwv;
-          uint32_t x = xs[j];
-          if ((inert >> lane) & 1u) { if (x) chg[lane * Wv + w] = 0; x = 0; }  // a failed or refused node is inert  (lanes >= nb hold 0)
-          uint32_t taken = 0;  // wave-uniform: the bits of this word listed so far
-          while (!list_full) {
-            const unsigned long long holders = __ballot((x & ~taken) != 0u);
-            if (!holders) break;
-            const uint32_t xf = (uint32_t)__builtin_amdgcn_readlane((int)(x & ~taken), (int)__builtin_ctzll(holders));
-            const uint32_t i = (uint32_t)__builtin_ctz(xf);
-            const uint32_t M = (uint32_t)__ballot((x >> i) & 1u);
-            // lane 0 emits the entry (wave-uniform values: every lane computes them, one writes)
-            uint32_t pos = 0;
-            if (lane == 0) pos = atomicAdd(&misc[m_count], 1u);
-            pos = __builtin_amdgcn_readfirstlane(pos);
-            if (pos >= kListCap) {  // full: this variable and the rest wait for the next round
-              if (lane == 0) { atomicSub(&misc[m_count], 1u); misc[N_MORE] = round + 1; }
-              list_full = true;
-              break;
-            }
-            taken |= 1u << i;
-            const uint32_t v = (w << 5) + i;
-            const uint32_t o0 = v < V ? adjo[v] : 0u, dg = v < V ? adjo[v + 1] - o0 : 0u;
-            // jump windows: a list walked for one or two nodes only, not in the sweep round, the variable not assigned
-            uint32_t wsel = kNoWin | (kNoWin << 16);
-            if (round && wcap && __popc(M) <= 2) {
-              uint32_t k = 0;
-              for (uint32_t m = M; m; m &= m - 1, ++k) {
-                const uint32_t b = (uint32_t)__builtin_ctz(m);
-                const int2 d = cell_bounds<PACKED>(dom[rowof(v) + b]);
-                if (d.x >= d.y) continue;
-                uint32_t wi = 0;
-                if (lane == 0) wi = atomicAdd(&misc[m_win], 1u);
-                wi = __builtin_amdgcn_readfirstlane(wi);
-                if (wi >= wcap) continue;
-                if (lane == 0) {
-                  Win nw;
-                  nw.lo[0] = nw.lo[1] = nw.hi[0] = nw.hi[1] = 0u; nw.lb0 = d.x; nw.ub0 = d.y; nw.vb = v | (b << 16); nw.pad = 0u;
-                  win[wi] = nw;
-                }
-                wsel = k == 0 ? ((wsel & 0xffff0000u) | wi) : ((wsel & 0xffffu) | (wi << 16));
-              }
-            }
-            if (lane == 0) list[pos] = make_uint4(v | (M << 16), o0, dg, wsel);
-            rm |= M;
-          }
-          if (lane < nb && (x & taken)) chg[lane * Wv + w] = x & ~taken;
-        }
-      }
-      if (rm && lane == 0) atomicOr(&misc[m_rmask], rm);
-    }
+    // (a) one list for the tile: (variable, mask of the nodes in which it changed) — neq_build_list
+    neq_build_list<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, vmk, round, r0_direct, inert, wcap);
     if (round == 0) PCP_TR(4);
     bar();
     if (round == 0) PCP_TR(5);
@@ -894,254 +1403,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
       if (round) misc[N_WAVES] += __popc(misc[m_rmask]);
       misc[(round & 1u) ? N_COUNT0 : N_COUNT1] = 0; misc[(round & 1u) ? N_RMASK0 : N_RMASK1] = 0; misc[(round & 1u) ? N_WIN0 : N_WIN1] = 0;
     }
-    // (b) walk the lists.  Piece p (4 x 64 entries) of list e goes to wavefront (p + e) mod nwv: one long list is spread over
-    // the workgroup, many lists are balanced to within a piece.  The payload loads of the next TWO pieces are in flight while a
-    // piece is tested: three register stages in rotation, the loop unrolled three times so that no stage is ever copied (a copy
-    // would wait for the load it copies).
+    // (b) walk the lists (neq_walk_lists): every entry of every listed variable against the nodes of its mask
     {
-      struct Piece { uint32_t v, M, aoff, deg, k0, wsel; };
-      // The length of a piece: 4 x 64 entries, or — when the round walks so few lists that whole pieces per wavefront do not come out even —
-      // fewer: one list of 2997 entries (a frontier tile: the one queen its nodes have in common) is 12 pieces of 256 for 8 wavefronts,
-      // i.e. two rounds of pieces with half of the wavefronts idle in the second, but 16 pieces of 192: two even rounds, a quarter less time.
-      uint32_t plen = 64u * U4;
-      if (PCP_NEQ_PLEN && !one_piece && total <= 4u) {
-        uint32_t work = 0;
-        for (uint32_t e_ = 0; e_ < total; ++e_) work += list[e_].z;
-        work = (uint32_t)__builtin_amdgcn_readfirstlane(work);
-        const uint32_t per = nwv * 64u * U4, r = (work + per - 1u) / per;  // rounds of pieces at full length
-        if (r) plen = min(64u * U4, 64u * ((work + 64u * nwv * r - 1u) / (64u * nwv * r)));
-      }
-      const uint32_t nu = plen >> 6;  // payload loads / entries per lane of a piece (wave-uniform)
-      const uint32_t k_step = nwv * plen;
-      const uint32_t e_step = one_piece ? nwv : 1u;
-      auto k_first = [&](uint32_t e_) { return one_piece ? 0u : ((wv + nwv - (e_ % nwv)) % nwv) * plen; };
-      uint32_t e = one_piece ? wv : 0u, k0 = k_first(e);
-      // the next piece of this wavefront (deg == 0: none left; its loads then read entry 0 of list 0 and are ignored)
-      auto next_piece = [&]() -> Piece {
-        while (e < total) {
-          const uint4 ent = list[e];
-          const uint32_t dg = __builtin_amdgcn_readfirstlane(ent.z);  // wave-uniform: keeps the loop control scalar
-          if (k0 < dg) {
-            const uint32_t vm = __builtin_amdgcn_readfirstlane(ent.x);
-            const Piece pc{vm & 0xffffu, vm >> 16, (uint32_t)__builtin_amdgcn_readfirstlane(ent.y), dg, k0, (uint32_t)__builtin_amdgcn_readfirstlane(ent.w)};
-            k0 += k_step;
-            return pc;
-          }
-          e += e_step; k0 = k_first(e);
-        }
-        return Piece{0u, 0u, 0u, 0u, 0u, 0u};
-      };
-      auto load = [&](const Piece& pc, Pay (&q)[4]) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if ((uint32_t)u >= nu) { q[u] = q[0]; continue; }  // (a short piece: entry 0's payload stands in, masked off below)
-          const uint32_t idx = pc.k0 + u * 64 + lane;
-          q[u] = pay[pc.aoff + (idx < pc.deg ? idx : 0u)];
-        }
-      };
-      uint32_t my_ev = 0;
-      const bool timing = PCP_NEQ_PROFILE && (a.debug & 8u) != 0;  // profiling: s_memtime ticks of the walk / of the node loops, pieces (counters overloaded)
-      uint64_t t_walk0 = 0, t_inner = 0, n_pieces = 0;
-      if (timing) t_walk0 = __builtin_amdgcn_s_memtime();
-      auto process = [&](const Piece& pc, const Pay (&q)[4]) {
-        uint32_t other[4];
-        int t[4];
-        bool valid[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          valid[u] = (uint32_t)u < nu && pc.k0 + u * 64 + lane < pc.deg;
-          other[u] = pay_other(q[u]);
-          t[u] = pay_t(q[u]);  // v is the record's y: x != v + d  <=>  o != v + d (t = d);  v is x: o != v - d (t = -d)
-        }
-        bool hit[4] = {false, false, false, false};
-        uint64_t ti0 = 0;
-        if (timing) { ti0 = __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane(other[0] ^ other[3] ^ (uint32_t)t[1]) & 0u); ++n_pieces; }
-        const uint32_t rv = rowof(pc.v);
-        uint32_t ro[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) ro[u] = rowof(other[u]);
-        if constexpr (PACKED) {
-          uint32_t K[4], acc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { K[u] = pack_mt(t[u]); acc[u] = 0xffffffffu; }
-          if (B >= 4 && __popc(pc.M) > 2) {
-            // a quad of nodes per ds_read_b128, two quads per step (ten reads in flight); nodes of a quad outside the mask are
-            // tested along: they can only raise a flag that the full-filter pass below, which walks the mask, ignores
-            uint32_t qm = 0;
-            for (uint32_t g = 0; g < (B >> 2); ++g) qm |= ((pc.M >> (4 * g)) & 0xFu) ? 1u << g : 0u;
-#if PCP_NEQ_XOR
-            // The walked variable has the SAME cell in every node of these quads — the rule, not the exception: the nodes of a tile are
-            // neighbours in the search tree and hold the queens of their common ancestors at the same values.  Then what an entry's other
-            // side must match is a property of the entry alone (neq_target16), and an (entry, node) test is one exclusive-or and one
-            // packed minimum instead of a packed add on top (v_pk_* issue at half rate: tools/micro/box_probe.hip).
-            const uint32_t cvu = dom[rv + 4u * (uint32_t)__builtin_ctz(qm)];
-            uint32_t differ = 0;
-            for (uint32_t qq = qm; qq; qq &= qq - 1u) {
-              const uint4 c = *reinterpret_cast<const uint4*>(dom + rv + 4u * (uint32_t)__builtin_ctz(qq));
-              differ |= (c.x ^ cvu) | (c.y ^ cvu) | (c.z ^ cvu) | (c.w ^ cvu);
-            }
-            if (__builtin_amdgcn_readfirstlane(differ) == 0u) {  // (every lane read the same cells: wave-uniform)
-              uint32_t T[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) T[u] = neq_target16(cvu, K[u]);
-              if (__popc(qm) & 1) {
-                const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
-                qm &= qm - 1;
-                uint4 o0[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                  acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u])));
-              }
-              while (qm) {
-                const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
-                qm &= qm - 1;
-                const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
-                qm &= qm - 1;
-                uint4 o0[4], o1[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const uint32_t m0 = pk_min_u16(pk_min_u16(o0[u].x ^ T[u], o0[u].y ^ T[u]), pk_min_u16(o0[u].z ^ T[u], o0[u].w ^ T[u]));
-                  const uint32_t m1 = pk_min_u16(pk_min_u16(o1[u].x ^ T[u], o1[u].y ^ T[u]), pk_min_u16(o1[u].z ^ T[u], o1[u].w ^ T[u]));
-                  acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
-                }
-              }
-            }
-#endif
-            if (__popc(qm) & 1) {  // an odd quad out, by itself
-              const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
-              qm &= qm - 1;
-              const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0);
-              uint4 o0[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                if ((uint32_t)u >= nu) continue;  // (a short piece)
-                uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
-                uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
-                acc[u] = pk_min_u16(acc[u], pk_min_u16(m0, m1));
-              }
-            }
-            while (qm) {
-              const uint32_t g0 = (uint32_t)__builtin_ctz(qm);
-              qm &= qm - 1;
-              const uint32_t g1 = (uint32_t)__builtin_ctz(qm);
-              qm &= qm - 1;
-              const uint4 c0 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g0), c1 = *reinterpret_cast<const uint4*>(dom + rv + 4 * g1);
-              uint4 o0[4], o1[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) if ((uint32_t)u < nu) { o0[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g0); o1[u] = *reinterpret_cast<const uint4*>(dom + ro[u] + 4 * g1); }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                if ((uint32_t)u >= nu) continue;
-                uint32_t m0 = pk_min_u16(neq_terms16(c0.x, o0[u].x, K[u]), neq_terms16(c0.y, o0[u].y, K[u]));
-                uint32_t m1 = pk_min_u16(neq_terms16(c0.z, o0[u].z, K[u]), neq_terms16(c0.w, o0[u].w, K[u]));
-                uint32_t m2 = pk_min_u16(neq_terms16(c1.x, o1[u].x, K[u]), neq_terms16(c1.y, o1[u].y, K[u]));
-                uint32_t m3 = pk_min_u16(neq_terms16(c1.z, o1[u].z, K[u]), neq_terms16(c1.w, o1[u].w, K[u]));
-                acc[u] = pk_min_u16(acc[u], pk_min_u16(pk_min_u16(m0, m1), pk_min_u16(m2, m3)));
-              }
-            }
-          } else {
-            uint32_t k = 0;
-            for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
-              const uint32_t b = (uint32_t)__builtin_ctz(m);
-              const uint32_t c0 = dom[rv + b];
-              uint32_t oc[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) { oc[u] = dom[ro[u] + b]; acc[u] = pk_min_u16(acc[u], neq_terms16(c0, oc[u], K[u])); }
-              const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
-              if (wi != kNoWin) {
-                // the values assigned neighbours forbid for v, near its bounds (the bounds the window was opened with)
-                Win* wp = win + wi;
-                const int lb0 = wp->lb0, ub0 = wp->ub0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  const int2 O = unpack16(oc[u]);
-                  if (valid[u] && O.x == O.y) {
-                    const int f = O.x - t[u];  // lb(v) + t == O  <=>  lb(v) == f
-                    const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
-                    if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
-                    if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
-                  }
-                }
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) hit[u] = valid[u] && zero_half(acc[u]);
-        } else {
-          uint32_t k = 0;
-          for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
-            const uint32_t b = (uint32_t)__builtin_ctz(m);
-            const int2 c0 = dom[rv + b];
-            const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
-            Win* wp = win + (wi != kNoWin ? wi : 0u);
-            int lb0 = 0, ub0 = 0;
-            if (wi != kNoWin) { lb0 = wp->lb0; ub0 = wp->ub0; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {  // lb(v) + t == ub(o)  |  ub(v) + t == lb(o)
-              const int2 o = dom[ro[u] + b];
-              hit[u] |= (c0.x + o.y == t[u]) | (c0.y + o.x == -t[u]);
-              if (wi != kNoWin && valid[u] && -o.x == o.y) {
-                const int f = o.y - t[u];
-                const uint32_t dl = (uint32_t)(f - lb0), dh = (uint32_t)(ub0 - f);
-                if (dl < 64u) atomicOr(&wp->lo[dl >> 5], 1u << (dl & 31u));
-                if (dh < 64u) atomicOr(&wp->hi[dh >> 5], 1u << (dh & 31u));
-              }
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) hit[u] = hit[u] && valid[u];
-        }
-        if (timing) t_inner += __builtin_amdgcn_s_memtime() + (__builtin_amdgcn_readfirstlane((uint32_t)hit[0] | (uint32_t)hit[3]) & 0u) - ti0;
-        const uint32_t nm = (uint32_t)__popc(pc.M);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) my_ev += valid[u] ? nm : 0u;
-        if (hit[0] | hit[1] | hit[2] | hit[3]) {
-          // flagged entries: the full filter, in the nodes whose domains meet the condition
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (!hit[u]) continue;
-            const bool is_y = pay_is_y(q[u]);
-            Rec rec;
-            rec.xk = (is_y ? other[u] : pc.v) | ((uint32_t)PCP_NEQ << 28);
-            rec.y = is_y ? pc.v : other[u];
-            rec.z = 0;
-            rec.d = is_y ? t[u] : -t[u];
-            for (uint32_t m = pc.M; m; m &= m - 1) {
-              const uint32_t b = (uint32_t)__builtin_ctz(m);
-              const int2 Vd = cell_bounds<PACKED>(dom[rv + b]), O = cell_bounds<PACKED>(dom[ro[u] + b]);
-              if (Vd.x + t[u] != O.y && Vd.y + t[u] != O.x) continue;
-              ++ctr.full;
-              eval_record(rec, dom_of(b, &ctr));
-            }
-          }
-        }
-      };
-      Piece pa = next_piece(), pb, pc3;
-      Pay qA[4], qB[4], qC[4];
-      load(pa, qA);
-      if (round == 0) PCP_TR(6);
-      pb = next_piece(); load(pb, qB);
-      while (pa.deg) {
-        pc3 = next_piece(); load(pc3, qC);
-        process(pa, qA);
-        if (!pb.deg) break;
-        pa = next_piece(); load(pa, qA);
-        process(pb, qB);
-        if (!pc3.deg) break;
-        pb = next_piece(); load(pb, qB);
-        process(pc3, qC);
-      }
-      if (timing && lane == 0 && round == 0) {
-        atomicAdd((unsigned long long*)&a.stats->steps3, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_walk0));
-        atomicAdd((unsigned long long*)&a.stats->failed_nodes, (unsigned long long)t_inner);
-        atomicAdd((unsigned long long*)&a.stats->waves, (unsigned long long)n_pieces);
-      }
+      const uint32_t my_ev = neq_walk_lists<PACKED, PAY4>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, pay, total, one_piece, round, ctr,
+                                                           tr_on, trbuf);
       if (round == 0) ev0 += my_ev;
       ctr.ev += my_ev;
     }
@@ -1158,37 +1423,14 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (!narrowed && !nwin && misc[N_MORE] != round + 1) break;
     // (c) the jumps: each window's bound moves to the first value no assigned neighbour forbids
     if (nwin) {
-      for (uint32_t wi = tid; wi < nwin; wi += nth) {
-        const Win w = win[wi];
-        const uint32_t v = w.vb & 0xffffu, b = w.vb >> 16;
-        if ((misc[N_FAIL] >> b) & 1u) continue;
-        const TDom dm = dom_of(b, &ctr);
-        const int2 d = dm.load(v);
-        if (d.x > d.y) continue;
-        const unsigned long long Lm = ((unsigned long long)w.lo[1] << 32) | w.lo[0], Hm = ((unsigned long long)w.hi[1] << 32) | w.hi[0];
-        {
-          const uint32_t off = (uint32_t)(d.x - w.lb0);  // the bound may have moved during the walk
-          if (off < 64u) {
-            const unsigned long long m = Lm | ((1ull << off) - 1ull);
-            const int nl = w.lb0 + (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
-            if (nl > d.x) dm.raise_lb(v, nl);
-          }
-        }
-        {
-          const uint32_t off = (uint32_t)(w.ub0 - d.y);
-          if (off < 64u) {
-            const unsigned long long m = Hm | ((1ull << off) - 1ull);
-            const int nu = w.ub0 - (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
-            if (nu < d.y) dm.lower_ub(v, nu);
-          }
-        }
-      }
+      neq_apply_jumps<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, nwin, ctr);
       bar();
     }
   }
 
   if (ptime) pt2 = __builtin_amdgcn_s_memtime();
   PCP_TR(9);
+  const NeqTile<PACKED> tl{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth};
   // ---- status: is any record NOT entailed under the final domains? (store.rs:250-256) ------------------------
   // Records of two assigned variables are entailed at a fixpoint that did not fail (two different values: disjoint), so only the
   // lists of unassigned variables can hold an open record; x != y + d is entailed iff the intervals are disjoint
@@ -1196,49 +1438,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   // Two nodes per wavefront at a time, one per 32-lane half: a node's scan is a chain of dependent LDS and memory reads (cells -> the
   // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
   // chains one after the other in every wavefront.
-  {
-    const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
-    for (uint32_t b0 = wv; b0 < nb; b0 += 2 * nwv) {
-      // (a wavefront with one node left gives it all 64 lanes: the search loop's single node, the odd node of a ragged tile)
-      const bool pair = !DFS && b0 + nwv < nb;                            // wave-uniform (the search loop has one node: folded away)
-      const uint32_t hw = pair ? 32u : 64u, hl = lane & (hw - 1u), hb = pair ? lane >> 5 : 0u;
-      const uint32_t b = b0 + hb * nwv;                                   // this half's node
-      bool done = ((inert >> b) & 1u) || (a.debug & 2u);                  // (uniform within a half)
-      bool open = false;
-      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
-      auto mine = [&](unsigned long long bal) { return pair ? (unsigned long long)(uint32_t)(bal >> (32u * hb)) : bal; };
-      for (uint32_t base = 0; base < V; base += hw) {
-        if (!__ballot(!done)) break;
-        const uint32_t vv = base + hl;
-        bool wide = false;
-        if (!done && vv < V) { const int2 d = cellb(vv); wide = d.x < d.y; }
-        unsigned long long cand = mine(__ballot(wide));                   // this half's unassigned variables among these
-        for (;;) {
-          const bool has = !done && cand != 0ull;
-          if (!__ballot(has)) break;
-          const uint32_t u = has ? base + (uint32_t)__builtin_ctzll(cand) : 0u;
-          cand &= cand - 1ull;
-          int2 Ud = make_int2(0, 0);
-          uint32_t o0 = 0, deg = 0;
-          if (has) { Ud = cellb(u); o0 = adjo[u]; deg = adjo[u + 1] - o0; }
-          for (uint32_t k = 0;; k += hw) {
-            const bool go = has && !open && k < deg;
-            if (!__ballot(go)) break;
-            bool op = false;
-            if (go && k + hl < deg) {
-              const Pay q = pay[o0 + k + hl];
-              const int t = pay_t(q);
-              const int2 O = cellb(pay_other(q));
-              op = !((Ud.x + t > O.y) || (Ud.y + t < O.x));  // not disjoint
-            }
-            if (mine(__ballot(op))) open = true;
-          }
-          if (open) done = true;
-        }
-      }
-      if (open && hl == 0) atomicOr(&misc[N_UNK], 1u << b);
-    }
-  }
+  neq_status_scan<PACKED, DFS>(tl, pay, (a.debug & 2u) != 0);
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   uint32_t wb_need = 0;
@@ -1246,36 +1446,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   bar();
   PCP_TR(11);
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
-  {
-    const bool in_place = a.lb_in == a.lb_out && a.ub_in == a.ub_out;
-    const uint32_t all_nodes = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
-    const uint32_t dirty = __builtin_amdgcn_readfirstlane(misc[N_DIRTY]), refused = __builtin_amdgcn_readfirstlane(misc[N_OOB]);
-    uint32_t badm = 0;
-    const bool vec_out = (V & 3u) == 0 && (((size_t)a.lb_out | (size_t)a.ub_out) & 15u) == 0;
-    // a refused node's outputs are left alone; in place, the rows of an unchanged node already hold the result in HBM: a frontier
-    // tile writes nothing and does not even look at its sixteen nodes one by one
-    wb_need = (in_place ? dirty : all_nodes) & ~refused & all_nodes;  // (workgroup-uniform)
-    for (uint32_t need = wb_need; need; need &= need - 1u) {
-      const uint32_t b = (uint32_t)__builtin_ctz(need);
-      auto cellb = [&](uint32_t slot) { return cell_bounds<PACKED>(dom[rowof(slot) + b]); };
-      int32_t* lbp = a.lb_out + (size_t)misc[N_NID + b] * V;
-      int32_t* ubp = a.ub_out + (size_t)misc[N_NID + b] * V;
-      bool bad = false;
-      if (vec_out) {
-        for (uint32_t q = tid; q < (V >> 2); q += nth) {
-          int l[4], u[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) { const int2 d = cellb(4 * q + i); l[i] = d.x; u[i] = d.y; bad |= d.x > d.y; }
-          reinterpret_cast<int4*>(lbp)[q] = make_int4(l[0], l[1], l[2], l[3]);
-          reinterpret_cast<int4*>(ubp)[q] = make_int4(u[0], u[1], u[2], u[3]);
-        }
-      } else {
-        for (uint32_t v = tid; v < V; v += nth) { const int2 d = cellb(v); bad |= d.x > d.y; lbp[v] = d.x; ubp[v] = d.y; }
-      }
-      if (bad) badm |= 1u << b;
-    }
-    if (badm) atomicOr(&misc[N_FAIL], badm);
-  }
+  wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out);
   // the counters: wave sums by DPP (VALU only), then one lane adds them to the tile's LDS words.  (The wave reductions that used to
   // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
   // address were tried instead and cost 8 800.)
@@ -1353,69 +1524,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
   } else {
     // ---- the search step on the node just propagated (what dfs_step_kernel does for the generic kernels) ---------------------
     bar();
-    const bool failed = (misc[N_FAIL] & 1u) != 0, refused = (misc[N_OOB] & 1u) != 0, open = (misc[N_UNK] & 1u) != 0;
-    dfs_resume_var = 0xFFFFFFFFu;
-    uint32_t new_sp = dfs_sp - 1;
-    // StopNode (stop_node.rs:57-62) replaces the status of the node that reaches the limit by EndOfSearch BEFORE the monitor sees it
-    // (Monitor<Statistics, StopNode<..>>, stop_node.rs:90-97): that node is counted as a node, never as a solution or a failure.
-    const bool last = a.dfs.node_limit && c_nodes + 1 >= a.dfs.node_limit;
-    if (refused) {
-      c_err = 2; dfs_stop = 1;  // a node the engine refused (PCP_STATUS_HULL)
-      ++c_nodes;
-    } else if (failed) {
-      ++c_nodes;
-      if (!last) ++c_fail;
-    } else if (!open) {  // True: a solution (monitor.rs:19-68); the first one is kept
-      ++c_nodes;
-      if (!last) {
-        if (c_sols == 0 && a.dfs.first_solution)
-          for (uint32_t v = tid; v < V; v += nth) a.dfs.first_solution[v] = cell_bounds<PACKED>(dom[rowof(v)]).x;
-        ++c_sols;
-        if (a.dfs.stop_on_solution) dfs_stop = 1;
-      }
-    } else {
-      // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (brancher.rs:52-71): the first variable of minimal size > 1
-      unsigned long long key = ~0ull;
-      for (uint32_t v = tid; v < V; v += nth) {
-        const int2 d = cell_bounds<PACKED>(dom[rowof(v)]);
-        const unsigned long long size = (unsigned long long)((long long)d.y - (long long)d.x + 1);
-        if (size > 1) key = min(key, (size << 32) | v);
-      }
-      for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
-      unsigned long long* best = reinterpret_cast<unsigned long long*>(list);  // (the round list is idle here)
-      if (lane == 0) best[wv] = key;
-      bar();
-      key = best[0];
-      for (uint32_t w = 1; w < nwv; ++w) key = min(key, best[w]);
-      bar();
-      if (key == ~0ull) {
-        c_err = 3; dfs_stop = 1;  // Unknown, yet nothing to branch on: the reference panics (first_smallest_var.rs:36)
-        new_sp = dfs_sp;
-      } else if (dfs_sp >= a.dfs.capacity) {
-        c_err = 1; dfs_stop = 1;  // stack overflow: the node stays on the stack, uncounted
-        new_sp = dfs_sp;
-      } else {
-        ++c_nodes;
-        const uint32_t var = (uint32_t)key;
-        const int2 d = cell_bounds<PACKED>(dom[rowof(var)]);
-        const int val = (int)(((long long)d.x + (long long)d.y) / 2);  // MiddleVal (middle_val.rs:25-27: `/` truncates toward zero)
-        // the right child x > val takes the parent's row (which holds the fixpoint: written back above if it changed)
-        if (tid == 0) a.lb_out[var] = max(d.x, val + 1);
-        if (tid == 0 && a.dfs.dirty) { a.dfs.dirty[dfs_sp - 1] = var; a.dfs.dirty[dfs_sp] = var; }  // both children differ from this fixpoint in `var`
-        // the left child x <= val: one bound of one LDS cell, and its row on top of the stack
-        if (tid == 0) {
-          if constexpr (PACKED) dom[rowof(var)] = pack16(d.x, min(d.y, val)); else dom[rowof(var)] = make_int2(-d.x, min(d.y, val));
-        }
-        bar();
-        int32_t* l0 = a.lb_out + V;
-        int32_t* u0 = a.ub_out + V;
-        for (uint32_t v = tid; v < V; v += nth) { const int2 c = cell_bounds<PACKED>(dom[rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
-        new_sp = dfs_sp + 1;
-        dfs_resume_var = var;
-      }
-    }
-    if (a.dfs.node_limit && c_nodes >= a.dfs.node_limit) dfs_stop = 1;  // StopNode (stop_node.rs:57-62)
-    dfs_sp = new_sp;
+    neq_dfs_step<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, dfs);
     bar();
   }
   }  // the DFS loop / the tile loop
@@ -1439,9 +1548,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) neqfix_kernel(const NeqArgs 
     if (acc_nodes) atomicAdd((unsigned long long*)&a.stats->nodes, acc_nodes);
     if (acc_failed) atomicAdd((unsigned long long*)&a.stats->failed_nodes, acc_failed);
     if constexpr (DFS) {
-      *a.dfs.sp = dfs_sp; *a.dfs.stop = dfs_stop;
-      a.dfs.counters[0] = c_nodes; a.dfs.counters[1] = c_sols; a.dfs.counters[2] = c_fail;
-      if (c_err) a.dfs.counters[3] = c_err;
+      *a.dfs.sp = dfs.sp; *a.dfs.stop = dfs.stop;
+      a.dfs.counters[0] = dfs.nodes; a.dfs.counters[1] = dfs.sols; a.dfs.counters[2] = dfs.fail;
+      if (dfs.err) a.dfs.counters[3] = dfs.err;
     }
     if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : (n_tiles - 1 - blockIdx.x) / gridDim.x + 1));
   }
