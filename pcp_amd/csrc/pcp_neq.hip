@@ -216,25 +216,28 @@ struct TileDom16 {
   __device__ __forceinline__ int2 load(uint32_t v) const { return unpack16(*cell(v)); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); atomicOr(&misc[N_DIRTY], fbit); }
   __device__ __forceinline__ void set_fail() const { atomicOr(&misc[N_FAIL], fbit); }
-  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+  // A narrowing that need not wake the variable's propagators (a window jump that ended inside its window: see neq_apply_jumps): the node is
+  // dirty, the variable is marked only when it became assigned or empty.
+  __device__ __forceinline__ void touch(uint32_t v, bool wake) const { if (wake) mark(v); else atomicOr(&misc[N_DIRTY], fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb, bool quiet = false) const {
     uint32_t* p = cell(v);
     uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
       const int2 d = unpack16(old);
       if (nlb <= d.x) return;  // somebody else got there first
       const uint32_t prev = atomicCAS(p, old, pack16(min(nlb, d.y + 1), d.y));
-      if (prev == old) { ++c->narrow; mark(v); if (nlb > d.y) set_fail(); return; }
+      if (prev == old) { ++c->narrow; touch(v, !quiet || nlb >= d.y); if (nlb > d.y) set_fail(); return; }
       old = prev;
     }
   }
-  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub, bool quiet = false) const {
     uint32_t* p = cell(v);
     uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
       const int2 d = unpack16(old);
       if (nub >= d.y) return;
       const uint32_t prev = atomicCAS(p, old, pack16(d.x, max(nub, d.x - 1)));
-      if (prev == old) { ++c->narrow; mark(v); if (nub < d.x) set_fail(); return; }
+      if (prev == old) { ++c->narrow; touch(v, !quiet || nub <= d.x); if (nub < d.x) set_fail(); return; }
       old = prev;
     }
   }
@@ -252,15 +255,22 @@ struct TileDom32 {
   __device__ __forceinline__ int2 load(uint32_t v) const { const int2 d = *cell(v); return make_int2(-d.x, d.y); }
   __device__ __forceinline__ void mark(uint32_t v) const { atomicOr(&chg[v >> 5], 1u << (v & 31)); atomicOr(&misc[N_DIRTY], fbit); }
   __device__ __forceinline__ void set_fail() const { atomicOr(&misc[N_FAIL], fbit); }
-  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+  __device__ __forceinline__ void touch(uint32_t v, bool wake) const { if (wake) mark(v); else atomicOr(&misc[N_DIRTY], fbit); }
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb, bool quiet = false) const {
     int2* p = cell(v);
     const int old = atomicMin(&p->x, -nlb);
-    if (old > -nlb) { ++c->narrow; mark(v); if (nlb > __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) set_fail(); }
+    if (old > -nlb) {
+      const int ubv = __hip_atomic_load(&p->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ++c->narrow; touch(v, !quiet || nlb >= ubv); if (nlb > ubv) set_fail();
+    }
   }
-  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub, bool quiet = false) const {
     int2* p = cell(v);
     const int old = atomicMin(&p->y, nub);
-    if (old > nub) { ++c->narrow; mark(v); if (-__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > nub) set_fail(); }
+    if (old > nub) {
+      const int lbv = -__hip_atomic_load(&p->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ++c->narrow; touch(v, !quiet || nub <= lbv); if (lbv > nub) set_fail();
+    }
   }
 };
 template <bool PACKED> struct TileDomOf { using type = TileDom32; };
@@ -405,8 +415,14 @@ const bool in_place = lb_in == lb_out && ub_in == ub_out;
 
 // ---- the jumps of a round: each window's bound moves to the first value no assigned neighbour forbids (the windows were filled by the
 // list walk of one- and two-node masks: see the kernel's header).  Every skipped value is one the filter would remove at the bound.
+// QUIET jumps (round 5).  The walk that filled a window saw EVERY entry of the variable's list, so a bound that jumped to a value inside the
+// window is known not to be forbidden by any neighbour that was assigned when its cell was read.  Who could still act on the new bound?  Only
+// a neighbour assigned since — and that neighbour is a changed variable whose OWN list is walked next round and tests this bound from its
+// side — or, if the jump assigned the variable (or emptied it), the variable itself.  So a jump that ends inside its window and leaves the
+// variable with more than one value does not mark it changed: the reference would pop its 3V propagators once more and find every one a no-op
+// (x_neq_y.rs:82-93: no side is a singleton whose value is a bound of the other).  Option bit neq_debug 65536 switches the rule off (A/B, tests).
 template <bool PACKED, class Tile>
-__device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, Ctr& ctr) {
+__device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, Ctr& ctr, const bool quiet) {
   for (uint32_t wi = tl.tid; wi < nwin; wi += tl.nth) {
     const Win w = tl.win[wi];
     const uint32_t v = w.vb & 0xffffu, b = w.vb >> 16;
@@ -420,7 +436,7 @@ __device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, C
       if (off < 64u) {
         const unsigned long long m = Lm | ((1ull << off) - 1ull);
         const int nl = w.lb0 + (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
-        if (nl > d.x) dm.raise_lb(v, nl);
+        if (nl > d.x) dm.raise_lb(v, nl, quiet && m != ~0ull);
       }
     }
     {
@@ -428,7 +444,7 @@ __device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, C
       if (off < 64u) {
         const unsigned long long m = Hm | ((1ull << off) - 1ull);
         const int nu = w.ub0 - (m == ~0ull ? 64 : (int)__builtin_ctzll(~m));
-        if (nu < d.y) dm.lower_ub(v, nu);
+        if (nu < d.y) dm.lower_ub(v, nu, quiet && m != ~0ull);
       }
     }
   }
@@ -740,10 +756,18 @@ __device__ __forceinline__ uint32_t neq_walk_lists(const Tile& tl, const NeqArgs
         rec.y = is_y ? pc.v : other[u];
         rec.z = 0;
         rec.d = is_y ? t[u] : -t[u];
-        for (uint32_t m = pc.M; m; m &= m - 1) {
+        uint32_t k = 0;
+        for (uint32_t m = pc.M; m; m &= m - 1, ++k) {
           const uint32_t b = (uint32_t)__builtin_ctz(m);
           const int2 Vd = cell_bounds<PACKED>(dom[rv + b]), O = cell_bounds<PACKED>(dom[ro[u] + b]);
           if (Vd.x + t[u] != O.y && Vd.y + t[u] != O.x) continue;
+          // a node with a jump window: an ASSIGNED neighbour at a bound of the unassigned variable is a bit of the window — the jump behind
+          // the barrier removes it together with the values behind it, once, instead of one value here and the rest there
+          const uint32_t wi = k == 0 ? (pc.wsel & 0xffffu) : k == 1 ? (pc.wsel >> 16) : kNoWin;
+          if (wi != kNoWin && !(a.debug & 65536u) && O.x == O.y && Vd.x < Vd.y) {
+            const Win* wp = win + wi;
+            if ((uint32_t)(Vd.x - wp->lb0) < 64u && (uint32_t)(wp->ub0 - Vd.y) < 64u) continue;
+          }
           ++ctr.full;
           eval_record(rec, dom_of(b, &ctr));
         }
@@ -1423,7 +1447,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
     if (!narrowed && !nwin && misc[N_MORE] != round + 1) break;
     // (c) the jumps: each window's bound moves to the first value no assigned neighbour forbids
     if (nwin) {
-      neq_apply_jumps<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, nwin, ctr);
+      neq_apply_jumps<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, nwin, ctr, !(a.debug & 65536u));
       bar();
     }
   }
