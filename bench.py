@@ -471,7 +471,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: cells,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -684,7 +684,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
+            legs_req = "cells,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -723,6 +723,7 @@ def main():
                 flat[key] = float(f"{by[name][field]:.{digits}g}")
         put_ms("mix_ms", "MIX-nodes-along-the-dfs"); put_k("mix_nps", "MIX-nodes-along-the-dfs", "nodes_per_s"); put_k("mix_sps", "MIX-nodes-along-the-dfs", "evaluated_per_s")
         put_k("mix_frac", "MIX-nodes-along-the-dfs", "hbm_frac", 3)
+        put_ms("pk_ms", "C2-frontier-resident-as-packed-cells"); put_k("pk_nps", "C2-frontier-resident-as-packed-cells", "nodes_per_s"); put_k("pk_frac", "C2-frontier-resident-as-packed-cells", "hbm_frac", 3)
         put_ms("mixh_ms", "MIXH-children-with-dirty-var-hints"); put_ms("mixc_ms", "MIXC-children-no-hints"); put_k("mixh_nps", "MIXH-children-with-dirty-var-hints", "nodes_per_s")
         put_ms("d500_ms", "C2-deep-dive-500"); put_ms("d3000_ms", "C2-deep-dive-3000")
         put_ms("c3_ms", "C3-random-binary-csp-50k-vars-500k-props"); put_k("c3_sps", "C3-random-binary-csp-50k-vars-500k-props", "evaluated_per_s")
@@ -813,6 +814,39 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
         for k, v in {"force_path": 0, "nodes_per_block": 0, "team": 0, "global_dom": 0, "packed": 1, "word_level": 1}.items():
             ctx.set_option(k, v)
 
+    if "cells" in want and ctx.last_plan().get("path") == 1:
+        # the headline frontier RESIDENT AS PACKED CELLS (pcp_device_batch.cell_format PCP_CELLS_PACKED16): 4 B per variable in HBM instead of
+        # 8, the rows are the kernel's LDS format.  Same nodes as the headline, so same results: unpacked and compared with an int32 launch.
+        reset_opts()
+        ctx.set_option("nodes_per_block", args.nodes_per_block)
+        stream = torch.cuda.current_stream().cuda_stream
+        lb_h, ub_h = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+        cells0 = ctx.pack_rows(lb_h, ub_h, stream_ptr=stream)
+        nn = L.shape[0]
+        st_c = torch.zeros(nn, dtype=torch.uint8, device=dev)
+        copies = [cells0.clone() for _ in range(7)]
+        ctx.propagate_device(nn, copies[0], None, copies[0], None, None, None, st_c, stream, cells=True)
+        torch.cuda.synchronize()
+        ctx.stats_reset(stream)
+        ms = []
+        for cpy in copies[1:]:
+            ctx.propagate_device(nn, cpy, None, cpy, None, None, None, st_c, stream, cells=True)
+            ms.append(ctx.last_kernel_ms())
+        stc = ctx.stats_read(stream)
+        st_i = torch.zeros(nn, dtype=torch.uint8, device=dev)
+        ctx.propagate_device(nn, lb_h, ub_h, lb_h, ub_h, None, None, st_i, stream)
+        ul, uu = ctx.unpack_rows(copies[-1], stream_ptr=stream)
+        torch.cuda.synchronize()
+        okc = st_i != 0
+        if not (torch.equal(st_c, st_i) and torch.equal(ul[okc], lb_h[okc]) and torch.equal(uu[okc], ub_h[okc])):
+            raise SystemExit("PARITY FAILURE (cells leg): the packed-cell launch differs from the int32 launch")
+        med = float(np.median(ms))
+        nbytes = nn * 4 * V + 4 * V * min(nn, stc["narrowings"] / len(ms))
+        legs.append({"name": "C2-frontier-resident-as-packed-cells", "nodes": nn, "launches": len(ms), "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
+                     "nodes_per_s": nn / (med * 1e-3), "compulsory_bytes_per_launch": nbytes, "hbm_frac": nbytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "identical_to_int32_launch": True,
+                     "note": "the headline frontier kept in HBM as rows of 32-bit cells (-lb & 0xffff | ub << 16): half the bytes per node; hbm_frac is of THESE bytes"})
+        del copies, cells0, lb_h, ub_h, ul, uu
     if "explicit" in want:  # the same frontier with explicit `active` rows (round 1's node format and headline)
         reset_opts()
         ctx.set_option("nodes_per_block", args.nodes_per_block)

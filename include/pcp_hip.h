@@ -229,7 +229,20 @@ typedef struct {
    * work differs.  Used by the all-XNeqY kernel (interval mode, implicit nodes); every other path ignores it.  A hint that breaks the
    * promise gives an unspecified (sound but possibly not fully propagated) result. */
   const uint32_t* dirty_var;
+  /* ABI v7: the format of the bounds rows.  0 (PCP_CELLS_I32, the default): lb / ub are two int32 rows per node.  1 (PCP_CELLS_PACKED16): ONE
+   * row of n_vars 32-bit CELLS per node, cell = (-lb & 0xffff) | ub << 16 — the format the all-XNeqY kernel keeps in LDS — in lb_in / lb_out;
+   * ub_in / ub_out are ignored.  4 n_vars bytes per node instead of 8: staging is a copy, open-node stacks and records halve.  Needs a
+   * declared hull within +-16383 (pcp_model_set_hull), an all-XNeqY model over implicit nodes (active_in == active_out == NULL), interval
+   * mode; anything else: PCP_ERR_UNSUPPORTED.  pcp_pack_rows / pcp_unpack_rows convert on the device. */
+  uint32_t cell_format;
+  uint32_t reserved;
 } pcp_device_batch;
+#define PCP_CELLS_I32 0u
+#define PCP_CELLS_PACKED16 1u
+/* int32 rows <-> packed cells, [n_nodes][n_vars] each, device pointers, enqueued on hip_stream.  A bound outside +-16383 cannot be packed:
+ * its cell is clamped and the context's sticky hull flag is raised (the next pcp_stats_read returns PCP_ERR_CONTRACT). */
+int32_t pcp_pack_rows(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, uint32_t* cells, void* hip_stream);
+int32_t pcp_unpack_rows(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, int32_t* lb, int32_t* ub, void* hip_stream);
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 
 /* ---- branching on the device (the caller side of the path) -------------------------------------

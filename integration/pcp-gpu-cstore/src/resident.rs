@@ -123,6 +123,7 @@ where
             active_in: if words > 0 { self.rows.act[cur] } else { ptr::null() },
             active_out: if words > 0 { self.rows.act[other] } else { ptr::null_mut() },
             status: self.rows.status, bits_in: ptr::null(), bits_out: ptr::null_mut(), dirty_var: ptr::null(),
+            cell_format: PCP_CELLS_I32, reserved: 0,
         };
         let rc = unsafe { pcp_propagate_device(g.dev.ctx, 1, &batch, ptr::null_mut()) };
         g.check(rc);

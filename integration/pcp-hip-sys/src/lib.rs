@@ -72,7 +72,13 @@ pub struct pcp_device_batch {
     /// ABI v7, nullable: [n_nodes] the ONE variable in which node i differs from a fixpoint of this model (a child of a propagated node:
     /// `pcp_branch_device_hint` writes it), or any value >= n_vars = no promise.  Same results, less work (include/pcp_hip.h).
     pub dirty_var: *const u32,
+    /// ABI v7: 0 = `PCP_CELLS_I32` (lb / ub int32 rows), 1 = `PCP_CELLS_PACKED16` (ONE row of 32-bit cells `(-lb & 0xffff) | ub << 16` per node in
+    /// lb_in / lb_out; all-XNeqY models with a declared hull within +-16383 only).
+    pub cell_format: u32,
+    pub reserved: u32,
 }
+pub const PCP_CELLS_I32: u32 = 0;
+pub const PCP_CELLS_PACKED16: u32 = 1;
 
 /// One node of a formula unit (logic/conjunction.rs, logic/disjunction.rs): type 0 leaf (first = index into the leaves), 1 Conjunction,
 /// 2 Disjunction (first = index of the first child, children consecutive).
@@ -170,6 +176,8 @@ extern "C" {
     pub fn pcp_branch_device_hint(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
                                   child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, child_dirty: *mut u32, counts: *mut u32,
                                   hip_stream: *mut c_void) -> i32; // the same, and every child's pcp_device_batch.dirty_var entry
+    pub fn pcp_pack_rows(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, cells: *mut u32, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_unpack_rows(ctx: *mut pcp_ctx, n_nodes: u32, cells: *const u32, lb: *mut i32, ub: *mut i32, hip_stream: *mut c_void) -> i32;
     pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
                                  status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
                                  hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains

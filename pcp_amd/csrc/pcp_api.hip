@@ -599,6 +599,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     if (need && need <= c->lds_max) { B = t; break; }
   }
   if (!B) return 1;
+  if (bt->cell_format && !packed) return fail(c, PCP_ERR_UNSUPPORTED, "cell_format PCP_CELLS_PACKED16 needs a declared hull (and constants) within +-16383");
   LaunchPlan plan;
   plan.grid = (n_nodes + B - 1) / B;
   plan.lds_bytes = lds_bytes_neq(S, V, B, packed, (uint32_t)c->opt_neq_wgs);
@@ -626,6 +627,8 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
   a.status = bt->status;
   a.stats = c->d_stats;
+  a.cell_rows = bt->cell_format;
+  if (a.cell_rows) { a.ub_in = nullptr; a.ub_out = nullptr; }  // (rows of cells: one row per node)
   a.dirty = (c->opt_neq_hint && !c->dfs_sp) ? bt->dirty_var : nullptr;  // (pcp_device_batch.dirty_var: round 0 = that variable's lists only)
   c->dfs_team_words = 0;
   c->last_plan = pcp_plan{B, 1u, packed ? 1u : 0u, 0u, 0u, 0u, 1u, 0u, plan.grid, plan.block, (uint32_t)plan.lds_bytes, S, 1u};
@@ -947,6 +950,16 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   c->ev_valid = false;
   if (n_nodes == 0) return PCP_OK;
   if (!bt->status) return fail(c, PCP_ERR_ARG, "status must not be null");
+  if (bt->cell_format > PCP_CELLS_PACKED16 || bt->reserved) return fail(c, PCP_ERR_ARG, "unknown cell_format (or reserved != 0)");
+  if (bt->cell_format == PCP_CELLS_PACKED16) {
+    // rows of packed cells: the all-XNeqY kernel alone reads and writes them
+    if (c->set_words || c->has_formulas || bt->active_in || bt->active_out || !c->neq_model || !c->opt_neq_path || !c->opt_implicit || c->opt_force_path == 2 ||
+        c->opt_global_dom || c->dfs_sp)
+      return fail(c, PCP_ERR_UNSUPPORTED, "cell_format PCP_CELLS_PACKED16: an all-XNeqY model over implicit nodes in interval mode only");
+    if (!bt->lb_in || !bt->lb_out) return fail(c, PCP_ERR_ARG, "cell rows (lb_in / lb_out) must not be null");
+    const int32_t rcn = propagate_neq_device(c, n_nodes, bt, stream);
+    return rcn == 1 ? fail(c, PCP_ERR_UNSUPPORTED, "cell_format PCP_CELLS_PACKED16: the store does not fit LDS") : rcn;
+  }
   if (c->n_vars && !c->set_words && (!bt->lb_in || !bt->ub_in || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "domain pointers must not be null");
 
   if (c->set_words) return propagate_set_device(c, n_nodes, bt, stream);
@@ -1448,6 +1461,22 @@ int32_t pcp_dfs_device(pcp_ctx* c, const pcp_dfs_state* st, uint32_t n_steps, ui
   c->dfs_sp = nullptr; c->dfs_stop = nullptr; c->dfs_team_words = 0;
   c->opt_force_path = keep_path;
   return rc;
+}
+
+int32_t pcp_pack_rows(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, uint32_t* cells, void* hip_stream) {
+  if (!c) return PCP_ERR_ARG;
+  if (n_nodes && c->n_vars && (!lb || !ub || !cells)) return fail(c, PCP_ERR_ARG, "null pointer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_pack_rows(lb, ub, cells, (size_t)n_nodes * c->n_vars, c->d_retry + 1, reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
+}
+
+int32_t pcp_unpack_rows(pcp_ctx* c, uint32_t n_nodes, const uint32_t* cells, int32_t* lb, int32_t* ub, void* hip_stream) {
+  if (!c) return PCP_ERR_ARG;
+  if (n_nodes && c->n_vars && (!lb || !ub || !cells)) return fail(c, PCP_ERR_ARG, "null pointer");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, launch_unpack_rows(cells, lb, ub, (size_t)n_nodes * c->n_vars, reinterpret_cast<hipStream_t>(hip_stream)));
+  return PCP_OK;
 }
 
 int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,

@@ -33,6 +33,7 @@ struct NeqArgs {
     uint32_t stop_on_solution;
     unsigned long long node_limit;
   } dfs;
+  uint32_t cell_rows;           // 1 = pcp_device_batch.cell_format PCP_CELLS_PACKED16: lb_in / lb_out are rows of 32-bit cells (-lb & 0xffff | ub << 16), ub_* unused
   const uint32_t* dirty;        // pcp_device_batch.dirty_var: [n_nodes] the one variable in which node i differs from a fixpoint (>= n_vars: none), or null
   const int32_t* lb_in;
   const int32_t* ub_in;
@@ -43,6 +44,9 @@ struct NeqArgs {
 };
 size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block, bool packed, uint32_t wgs = 2);
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream);
+// int32 bounds rows <-> rows of packed cells (n = nodes x variables entries); a bound that does not fit sets *violation
+hipError_t launch_pack_rows(const int32_t* lb, const int32_t* ub, uint32_t* cells, size_t n, uint32_t* violation, hipStream_t stream);
+hipError_t launch_unpack_rows(const uint32_t* cells, int32_t* lb, int32_t* ub, size_t n, hipStream_t stream);
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
 // per workgroup (pcp_big.hip).

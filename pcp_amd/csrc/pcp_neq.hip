@@ -142,6 +142,13 @@ __device__ __forceinline__ unsigned long long wave_sum64(uint32_t x) {
 
 __device__ __forceinline__ bool zero_half(uint32_t u) { return (u & 0xffffu) == 0u || (u >> 16) == 0u; }
 
+// both 16-bit halves added separately (no carry from the low half into the high one)
+__device__ __forceinline__ uint32_t pk_add16(uint32_t x, uint32_t y) {
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
 // (cell(v) + swap(cell(o))) ^ (t, -t): a half is zero iff lb(v) + t == ub(o) (low) or ub(v) + t == lb(o) (high).  The constant is
 // compared by an exclusive-or, not added: v_pk_add_u16 issues at half the rate of a 32-bit VALU operation on gfx950 (4.6 against 2.5
 // cycles per wave instruction with four wavefronts per SIMD, tools/micro/box_probe.hip), v_xor_b32 at full rate.
@@ -381,8 +388,8 @@ const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB];
 // ---- write back: the rows of the nodes that changed (every node when the call is not in place).  A refused node's outputs are left
 // alone.  An empty cell found on the way out fails its node (misc[N_FAIL]).  Returns the mask of the nodes written (workgroup-uniform).
 template <bool PACKED, class Tile>
-__device__ __forceinline__ uint32_t neq_write_back(const Tile& tl, const int32_t* lb_in, const int32_t* ub_in, int32_t* lb_out, int32_t* ub_out) {
-const bool in_place = lb_in == lb_out && ub_in == ub_out;
+__device__ __forceinline__ uint32_t neq_write_back(const Tile& tl, const int32_t* lb_in, const int32_t* ub_in, int32_t* lb_out, int32_t* ub_out, const bool cells) {
+  const bool in_place = lb_in == lb_out && (cells || ub_in == ub_out);
   const uint32_t all_nodes = tl.nb >= 32 ? 0xFFFFFFFFu : ((1u << tl.nb) - 1u);
   const uint32_t dirty = __builtin_amdgcn_readfirstlane(tl.misc[N_DIRTY]), refused = __builtin_amdgcn_readfirstlane(tl.misc[N_OOB]);
   uint32_t badm = 0;
@@ -396,6 +403,22 @@ const bool in_place = lb_in == lb_out && ub_in == ub_out;
     int32_t* lbp = lb_out + (size_t)tl.misc[N_NID + b] * tl.V;
     int32_t* ubp = ub_out + (size_t)tl.misc[N_NID + b] * tl.V;
     bool bad = false;
+    if constexpr (PACKED) if (cells) {  // rows of cells (PCP_CELLS_PACKED16): the LDS column of the node, as it is
+      uint32_t* const cp = reinterpret_cast<uint32_t*>(lb_out) + (size_t)tl.misc[N_NID + b] * tl.V;
+      auto emp = [](uint32_t c) { return ((c + (c >> 16)) & 0x8000u) != 0u; };
+      if ((tl.V & 3u) == 0 && ((size_t)lb_out & 15u) == 0) {
+        for (uint32_t q = tl.tid; q < (tl.V >> 2); q += tl.nth) {
+          const uint32_t r0 = tl.rowof(4 * q) + b;  // (four slots of one quad: no padding between their rows)
+          const uint32_t c0 = tl.dom[r0], c1 = tl.dom[r0 + tl.B], c2 = tl.dom[r0 + 2 * tl.B], c3 = tl.dom[r0 + 3 * tl.B];
+          bad |= emp(c0) | emp(c1) | emp(c2) | emp(c3);
+          reinterpret_cast<uint4*>(cp)[q] = make_uint4(c0, c1, c2, c3);
+        }
+      } else {
+        for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) { const uint32_t c = tl.dom[tl.rowof(v) + b]; bad |= emp(c); cp[v] = c; }
+      }
+      if (bad) badm |= 1u << b;
+      continue;
+    }
     if (vec_out) {
       for (uint32_t q = tl.tid; q < (tl.V >> 2); q += tl.nth) {
         int l[4], u[4];
@@ -904,9 +927,11 @@ __device__ __forceinline__ void neq_build_list(const Tile& tl, uint32_t* const v
 // a wave-task's row offset is a scalar (buffer_load soffset), its LDS offset a scalar added to a per-lane constant.
 // Semantics of the kernel's `put` (fast path and its rare branch) exactly; returns bad | oob << 16 (bit b = node b).
 // A wave-task = FOUR nodes x SIXTEEN consecutive quads (see the kernel: the cells a wavefront writes per store fall on all LDS banks).
+// CELLS (pcp_device_batch.cell_format PCP_CELLS_PACKED16): the rows ARE cells — one 16-byte load per quad instead of two, no packing; a
+// singleton shows as a zero 16-bit sum of the two halves, an empty domain as a negative one, a field outside +-16384 refuses the node.
 struct StageTile16Args {
-  const int32_t* lb;            // the tile's rows: [16][V], 16-byte aligned
-  const int32_t* ub;
+  const int32_t* lb;            // the tile's rows: [16][V], 16-byte aligned (CELLS: the rows of cells)
+  const int32_t* ub;            // (CELLS: unused)
   const uint32_t* seed_always;  // or null
   uint32_t V, Wv;
   uint32_t dom_off, chg_off, vmk_off, list_off, misc_off;  // byte offsets into the workgroup's dynamic LDS
@@ -914,6 +939,7 @@ struct StageTile16Args {
   uint32_t r0_direct;           // round 0's list is built here (vmk masks, up to kR0Cap variables)
   uint32_t wv, nwv;
 };
+template <bool CELLS>
 __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -929,7 +955,7 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
   uint4* const list = reinterpret_cast<uint4*>(smem_ + g.list_off);
   uint32_t* const misc = reinterpret_cast<uint32_t*>(smem_ + g.misc_off);
   const __amdgpu_buffer_rsrc_t rs_lb = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(g.lb), 0, (int)(16u * V * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(g.ub), 0, (int)(16u * V * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ub = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(CELLS ? g.lb : g.ub), 0, (int)(16u * V * 4u), 0x00020000);
   const uint32_t dqc = g.nwv % QC, dng = g.nwv / QC;
   uint32_t ng = g.wv / QC, qc = g.wv - ng * QC;  // (wave-uniform: scalar registers)
   uint32_t badm = 0, oobm = 0;
@@ -942,7 +968,7 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
       if (w0 + j * g.nwv < WT) {  // (uniform)
         const uint32_t so = ng * (16u * V) + qc * 256u, vo = qc == QC - 1u ? vo_last : vo_full;
         L[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)vo, (int)so, 0);
-        U[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)vo, (int)so, 0);
+        if constexpr (!CELLS) U[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)vo, (int)so, 0);
       }
       qc += dqc; ng += dng;
       if (qc >= QC) { qc -= QC; ++ng; }
@@ -951,6 +977,33 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
     for (int j = 0; j < UF; ++j) {
       if (w0 + j * g.nwv >= WT) break;  // (uniform)
       const bool lastc = qcj[j] == QC - 1u;
+      if constexpr (CELLS) {
+        const uint32_t c0 = L[j].x, c1 = L[j].y, c2 = L[j].z, c3 = L[j].w;
+        uint32_t* const p0 = reinterpret_cast<uint32_t*>(smem_ + ((lastc ? do_last : do_full) + qcj[j] * (16u * 272u) + ngj[j] * 16u));
+        p0[0] = c0; p0[16] = c1; p0[32] = c2; p0[48] = c3;
+        const uint32_t s0 = (c0 + (c0 >> 16)) & 0xffffu, s1 = (c1 + (c1 >> 16)) & 0xffffu, s2 = (c2 + (c2 >> 16)) & 0xffffu, s3 = (c3 + (c3 >> 16)) & 0xffffu;  // ub - lb, 16 bits
+        const uint32_t rng = (pk_add16(c0, 0x40004000u) | pk_add16(c1, 0x40004000u) | pk_add16(c2, 0x40004000u) | pk_add16(c3, 0x40004000u)) & 0x80008000u;
+        if ((min(min(s0, s1), min(s2, s3)) == 0u) | (((s0 | s1 | s2 | s3) & 0x8000u) != 0u) | (rng != 0u) || g.seed_always) {
+          const uint32_t b = 4u * ngj[j] + lb4, v0 = 4u * (16u * qcj[j] + (lastc ? lq_last : lq));
+          uint32_t nib = (s0 == 0u ? 1u : 0u) | (s1 == 0u ? 2u : 0u) | (s2 == 0u ? 4u : 0u) | (s3 == 0u ? 8u : 0u);
+          if (g.seed_always) nib |= (g.seed_always[v0 >> 5] >> (v0 & 31u)) & 15u;
+          if ((g.hintm >> b) & 1u) nib = 0;
+          if (nib) atomicOr(&chg[b * g.Wv + (v0 >> 5)], nib << (v0 & 31u));
+          if (g.r0_direct && misc[N_R0OVF] == 0u) {
+            for (uint32_t m = nib; m; m &= m - 1u) {
+              const uint32_t v = v0 + (uint32_t)__builtin_ctz(m), hs = 16u * (v & 1u);
+              const uint32_t old = atomicOr(&vmk[v >> 1], (1u << b) << hs);
+              if (((old >> hs) & 0xffffu) == 0u) {
+                const uint32_t pos = atomicAdd(&misc[N_COUNT0], 1u);
+                if (pos < kR0Cap) list[pos].x = v; else misc[N_R0OVF] = 1u;
+              }
+            }
+          }
+          if (rng) oobm |= 1u << b;
+          else if ((s0 | s1 | s2 | s3) & 0x8000u) badm |= 1u << b;
+        }
+        continue;
+      }
       const int l0 = (int)L[j].x, l1 = (int)L[j].y, l2 = (int)L[j].z, l3 = (int)L[j].w, u0 = (int)U[j].x, u1 = (int)U[j].y, u2 = (int)U[j].z, u3 = (int)U[j].w;
       const int mn = min(min(min(l0, l1), min(l2, l3)), min(min(u0, u1), min(u2, u3)));
       const int mx = max(max(max(l0, l1), max(l2, l3)), max(max(u0, u1), max(u2, u3)));
@@ -990,7 +1043,7 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
 // are marked for round 0, or listed directly (`r0_direct`: vmk masks + the list's first kR0Cap entries) —, fail nodes with an empty
 // domain, refuse nodes with a bound outside the cells' range, and mark the ONE changed variable of hinted nodes instead of their assigned
 // ones.  The first tile of a workgroup also stores the list offsets it requested before (adj_pre) behind its row loads.
-template <bool PACKED, bool DFS, int BT, class Tile>
+template <bool PACKED, bool DFS, int BT, bool CELLS, class Tile>
 __device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a, uint32_t* const vmk, const NeqCarve& cv, unsigned char* const smem, const uint32_t S,
                                                 const uint32_t node0, const bool r0_direct, const bool vec, const uint32_t dfs_hint, uint32_t (&adj_pre)[4], bool& adj_stored) {
   using Cell = typename NeqCell<PACKED>::type;
@@ -1068,7 +1121,44 @@ __device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a,
   };
   auto note = [&](uint32_t f, uint32_t b) { if (f) { badm |= (f & 1u) << b; oobm |= (f >> 1) << b; } };
   const uint32_t SQ = (V + 3) >> 2, tasks = nb * SQ;
-  if (vec) {
+  if (CELLS) {
+    // the rows are cells already (PCP_CELLS_PACKED16): a copy into the node-minor layout plus the checks
+    if constexpr (CELLS) {
+      const uint32_t* const rows = reinterpret_cast<const uint32_t*>(a.lb_in);
+      if (!adj_stored) {
+        adj_stored = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
+      }
+      if (BT == 16 && nb == 16u && (V & 3u) == 0 && ((size_t)rows & 15u) == 0) {
+        const uint32_t r = stage_tile16<true>(StageTile16Args{a.lb_in + (size_t)node0 * V, nullptr, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
+                                                              (uint32_t)cv.vmk, (uint32_t)cv.list, (uint32_t)(reinterpret_cast<unsigned char*>(misc) - smem), hintm,
+                                                              r0_direct ? 1u : 0u, (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), nth >> 6});
+        badm |= r & 0xffffu; oobm |= r >> 16;
+      } else {
+        if (r0_direct && tid == 0) misc[N_R0OVF] = 1u;  // (a ragged tile: round 0's list comes from the scan of the marks)
+        for (uint32_t t = tid; t < tasks; t += nth) {
+          const uint32_t b = t / SQ, q = t - b * SQ, v0 = 4 * q, cnt = min(4u, V - v0);
+          const uint32_t* const rp = rows + (size_t)misc[N_NID + b] * V + v0;
+          uint32_t nib = 0;
+          bool bad = false, oob = false;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if ((uint32_t)i < cnt) {
+              const uint32_t c = rp[i], s = (c + (c >> 16)) & 0xffffu;
+              dom[rowof(v0 + i) + b] = c;
+              nib |= s == 0u ? 1u << i : 0u;
+              bad |= (s & 0x8000u) != 0u;
+              oob |= (pk_add16(c, 0x40004000u) & 0x80008000u) != 0u;
+            }
+          if (a.seed_always) nib |= (a.seed_always[v0 >> 5] >> (v0 & 31u)) & ((1u << cnt) - 1u);
+          if ((hintm >> b) & 1u) nib = 0;
+          if (nib) atomicOr(&chg[b * Wv + (v0 >> 5)], nib << (v0 & 31u));
+          if (oob) oobm |= 1u << b; else if (bad) badm |= 1u << b;
+        }
+      }
+    }
+  } else if (vec) {
     // ALL of a tile's row loads in flight at once where the registers allow (16 nodes of 1000 variables on 512 threads: eight
     // 16-byte pairs per lane = 64 VGPRs): one memory round trip per tile instead of two in a row
     constexpr int UF = PACKED ? 8 : 6;  // (the int2-cell instantiations have fewer registers to spare)
@@ -1135,7 +1225,7 @@ __device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a,
       if (PACKED && BT == 16 && nb == 16u && !(a.debug & 32768u)) {
         // a full tile: the lean loop (stage_tile16), out of line
         store_adj();
-        const uint32_t r = stage_tile16(StageTile16Args{a.lb_in + (size_t)node0 * V, a.ub_in + (size_t)node0 * V, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
+        const uint32_t r = stage_tile16<false>(StageTile16Args{a.lb_in + (size_t)node0 * V, a.ub_in + (size_t)node0 * V, a.seed_always, V, Wv, (uint32_t)cv.dom, (uint32_t)cv.chg,
                                                         (uint32_t)cv.vmk, (uint32_t)cv.list, (uint32_t)(reinterpret_cast<unsigned char*>(misc) - smem), hintm,
                                                         r0_direct ? 1u : 0u, wv_s, nwv_s});
         badm |= r & 0xffffu; oobm |= r >> 16;
@@ -1219,7 +1309,8 @@ __device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a,
 // BT = the tile size as a compile-time constant — 16 (the batch default), 1 (the search loop) — or 0: taken from the launch.  With it the
 // cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
 // kernel does not have (it spills scalars into VGPR lanes as it is).
-template <bool PACKED, bool PAY4, bool DFS, int BT>
+// CELLS: the bounds rows in HBM are rows of packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16; PACKED batch launches only).
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false>
 __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(4))) neqfix_kernel(const NeqArgs a_in) {  // (four wavefronts per SIMD: the forest runs 16 per CU)
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
@@ -1370,7 +1461,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   if (resume) {
     if (tid == 0) chg[dfs.resume_var >> 5] = 1u << (dfs.resume_var & 31u);  // the left child: only the variable branched on has changed
   } else {
-    neq_stage_tile<PACKED, DFS, BT>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, vmk, cv, smem, S, node0, r0_direct, vec, dfs.hint,
+    neq_stage_tile<PACKED, DFS, BT, CELLS>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, vmk, cv, smem, S, node0, r0_direct, vec, dfs.hint,
                                     adj_pre, adj_stored);
   }
   if (!adj_stored) {
@@ -1470,7 +1561,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   bar();
   PCP_TR(11);
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
-  wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out);
+  wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out, CELLS);
   // the counters: wave sums by DPP (VALU only), then one lane adds them to the tile's LDS words.  (The wave reductions that used to
   // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
   // address were tried instead and cost 8 800.)
@@ -1585,19 +1676,58 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4, bool DFS, int BT>
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false>
 static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
 }
 template <bool DFS, int BT>
 static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if constexpr (!DFS)
+    if (a.cell_rows) {
+      if (!a.packed) return hipErrorInvalidValue;
+      return a.adjp4 ? launch_neq_k<true, true, false, BT, true>(a, p, stream) : launch_neq_k<true, false, false, BT, true>(a, p, stream);
+    }
   if (a.adjp4) return a.packed ? launch_neq_k<true, true, DFS, BT>(a, p, stream) : launch_neq_k<false, true, DFS, BT>(a, p, stream);
   return a.packed ? launch_neq_k<true, false, DFS, BT>(a, p, stream) : launch_neq_k<false, false, DFS, BT>(a, p, stream);
+}
+
+// ---- int32 bounds rows <-> rows of packed cells (pcp_pack_rows / pcp_unpack_rows): element-wise, four per thread where the rows allow
+__global__ void __launch_bounds__(256) pack_rows_kernel(const int32_t* __restrict__ lb, const int32_t* __restrict__ ub, uint32_t* __restrict__ cells, size_t n, uint32_t* violation) {
+  bool oob = false;
+  auto one = [&](int l, int u) {
+    oob |= (l < -kPackedMax) | (l > kPackedMax) | (u < -kPackedMax) | (u > kPackedMax);
+    return pack16(max(-kPackedMax, min(kPackedMax, l)), max(-kPackedMax, min(kPackedMax, u)));
+  };
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((size_t)lb | (size_t)ub | (size_t)cells) & 15u) == 0) {
+    for (size_t q = i0; q < (n >> 2); q += stride) {
+      const int4 l = reinterpret_cast<const int4*>(lb)[q], u = reinterpret_cast<const int4*>(ub)[q];
+      reinterpret_cast<uint4*>(cells)[q] = make_uint4(one(l.x, u.x), one(l.y, u.y), one(l.z, u.z), one(l.w, u.w));
+    }
+    for (size_t i = (n & ~(size_t)3) + i0; i < n; i += stride) cells[i] = one(lb[i], ub[i]);
+  } else {
+    for (size_t i = i0; i < n; i += stride) cells[i] = one(lb[i], ub[i]);
+  }
+  if (oob) atomicMax(violation, 1u);
+}
+__global__ void __launch_bounds__(256) unpack_rows_kernel(const uint32_t* __restrict__ cells, int32_t* __restrict__ lb, int32_t* __restrict__ ub, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((size_t)lb | (size_t)ub | (size_t)cells) & 15u) == 0) {
+    for (size_t q = i0; q < (n >> 2); q += stride) {
+      const uint4 c = reinterpret_cast<const uint4*>(cells)[q];
+      const int2 a = unpack16(c.x), b = unpack16(c.y), d = unpack16(c.z), e = unpack16(c.w);
+      reinterpret_cast<int4*>(lb)[q] = make_int4(a.x, b.x, d.x, e.x);
+      reinterpret_cast<int4*>(ub)[q] = make_int4(a.y, b.y, d.y, e.y);
+    }
+    for (size_t i = (n & ~(size_t)3) + i0; i < n; i += stride) { const int2 d = unpack16(cells[i]); lb[i] = d.x; ub[i] = d.y; }
+  } else {
+    for (size_t i = i0; i < n; i += stride) { const int2 d = unpack16(cells[i]); lb[i] = d.x; ub[i] = d.y; }
+  }
 }
 
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
@@ -1607,6 +1737,19 @@ hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stre
     return launch_neq_d<true, 1>(a, p, stream);
   }
   return a.nodes_per_block == 16 ? launch_neq_d<false, 16>(a, p, stream) : launch_neq_d<false, 0>(a, p, stream);
+}
+
+hipError_t launch_pack_rows(const int32_t* lb, const int32_t* ub, uint32_t* cells, size_t n, uint32_t* violation, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<size_t>((n / 4 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(grid), dim3(256), 0, stream, lb, ub, cells, n, violation);
+  return hipGetLastError();
+}
+hipError_t launch_unpack_rows(const uint32_t* cells, int32_t* lb, int32_t* ub, size_t n, hipStream_t stream) {
+  if (!n) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<size_t>((n / 4 + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(grid), dim3(256), 0, stream, cells, lb, ub, n);
+  return hipGetLastError();
 }
 
 }  // namespace pcp

@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -47,7 +47,7 @@ class PcpPlan(C.Structure):
 class DeviceBatch(C.Structure):
     _fields_ = [("lb_in", C.c_void_p), ("ub_in", C.c_void_p), ("lb_out", C.c_void_p), ("ub_out", C.c_void_p),
                 ("active_in", C.c_void_p), ("active_out", C.c_void_p), ("status", C.c_void_p), ("bits_in", C.c_void_p), ("bits_out", C.c_void_p),
-                ("dirty_var", C.c_void_p)]
+                ("dirty_var", C.c_void_p), ("cell_format", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DfsState(C.Structure):
@@ -116,6 +116,8 @@ def load_library():
     L.pcp_propagate_device.argtypes = [vp, u32, C.POINTER(DeviceBatch), vp]
     L.pcp_branch_device.argtypes = [vp, u32] + [vp] * 9
     L.pcp_branch_device_hint.argtypes = [vp, u32] + [vp] * 10
+    L.pcp_pack_rows.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.pcp_unpack_rows.argtypes = [vp, u32, vp, vp, vp, vp]
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
@@ -128,7 +130,7 @@ def load_library():
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -284,15 +286,33 @@ class Context:
 
     # ---- propagation, device-resident (pcp_propagate_device) ------------------------------------------------
     def propagate_device(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream_ptr: int = 0,
-                         bits_in=None, bits_out=None, dirty=None):
+                         bits_in=None, bits_out=None, dirty=None, cells=False):
         """All arguments are torch tensors on this context's device (or None for the optional masks); nothing is
         synchronised.  Tensors: lb/ub int32 [n,V]; active int64/uint64 [n,words]; status uint8 [n]; set mode: bits int64
         [n,V,set_words] (lb_in/ub_in ignored); dirty int32 [n]: per node the one variable in which it differs from a fixpoint of this
-        model, -1 / >= n_vars = none (pcp_device_batch.dirty_var)."""
+        model, -1 / >= n_vars = none (pcp_device_batch.dirty_var).  cells=True (pcp_device_batch.cell_format PCP_CELLS_PACKED16): lb_in / lb_out
+        are int32 [n,V] tensors of packed CELLS (pack_rows), ub_* ignored."""
         def p(t):
             return None if t is None else C.c_void_p(t.data_ptr())
-        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out), p(dirty))
+        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out), p(dirty),
+                         1 if cells else 0, 0)
         self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
+
+    def pack_rows(self, lb, ub, cells=None, stream_ptr: int = 0):
+        """pcp_pack_rows: int32 bounds rows [n,V] -> rows of packed cells (an int32 [n,V] tensor whose bits are the cells)."""
+        import torch
+        if cells is None:
+            cells = torch.empty_like(lb)
+        self._check(self._L.pcp_pack_rows(self._h, lb.shape[0], C.c_void_p(lb.data_ptr()), C.c_void_p(ub.data_ptr()), C.c_void_p(cells.data_ptr()), C.c_void_p(stream_ptr)))
+        return cells
+
+    def unpack_rows(self, cells, lb=None, ub=None, stream_ptr: int = 0):
+        """pcp_unpack_rows: rows of packed cells -> (lb, ub) int32 rows."""
+        import torch
+        lb = torch.empty_like(cells) if lb is None else lb
+        ub = torch.empty_like(cells) if ub is None else ub
+        self._check(self._L.pcp_unpack_rows(self._h, cells.shape[0], C.c_void_p(cells.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_void_p(ub.data_ptr()), C.c_void_p(stream_ptr)))
+        return lb, ub
 
     def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0, child_dirty=None):
         """pcp_branch_device(_hint) on torch tensors of this context's device (counts: int32[5]; child_dirty: int32 [2 n] capacity, receives

@@ -34,7 +34,7 @@ def test_prop_struct_layout_matches_header():
     from pcp_amd.model import PROP_DTYPE
     assert PROP_DTYPE.itemsize == 32
     assert PROP_DTYPE.fields["var"][1] == 8 and PROP_DTYPE.fields["off"][1] == 20 and PROP_DTYPE.fields["group"][1] == 4
-    assert ctypes.sizeof(E.PcpStats) == 64 and ctypes.sizeof(E.DeviceBatch) == 80 and ctypes.sizeof(E.PcpPlan) == 52
+    assert ctypes.sizeof(E.PcpStats) == 64 and ctypes.sizeof(E.DeviceBatch) == 88 and ctypes.sizeof(E.PcpPlan) == 52
 
 
 def test_fails_loudly_without_gpu():
