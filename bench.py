@@ -214,7 +214,7 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
     if set_mode or args.engine == "forest":
         return run_forest_mode(args, torch, dist, world, rank, dev, ctx, lb0, ub0, set_mode)
-    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True)
+    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, args.node_budget + 4 * batch), implicit=True, cells=args.cells)
     if world == 1 and not dist.is_initialized():
         # a single GPU still goes through the process group (RCCL with one rank): same driver, same exchange steps
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -253,7 +253,8 @@ def run_search_mode(args, torch, dist, world, rank, dev):
                 "steps_reference_equivalent_per_s": steps / dt,
                 "nodes": nodes, "nodes_per_s": nodes / dt, "solutions": sols, "failed_nodes": fails, "moved_records": moved,
                 "exchange_seconds_rank0": info.get("exchange_s"), "exchange_share_rank0": (info.get("exchange_s") or 0) / dt, "exchanges": info.get("exchanges"),
-                "record_bytes": 8 * n + (8 * n * ((n + 63) // 64) if set_mode else 0), "domains": args.domains,
+                "record_bytes": (4 * n if args.cells else 8 * n) + (8 * n * ((n + 63) // 64) if set_mode else 0), "domains": args.domains,
+                "node_format": "packed cells (PCP_CELLS_PACKED16)" if args.cells else "int32 rows",
                 "parallelism": f"worklist sharded over {world} GPU(s)",
             },
         })
@@ -286,17 +287,33 @@ def c5_legs(args, torch, dist, world, rank, dev, n):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return r, float(t.item())
 
-    ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, budget + 4 * batch), implicit=True)
-    D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=min(budget, 8 * batch * world), rounds_per_exchange=args.rounds_per_exchange, base=1)
-    info = {}
-    (nodes, sols, fails, steps, moved), dt = timed(lambda: D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=budget,
-                                                                                  rounds_per_exchange=args.rounds_per_exchange, info=info, base=1))
-    x = torch.tensor([info.get("exchange_s", 0.0)], dtype=torch.float64, device=dev)
-    dist.all_reduce(x, op=dist.ReduceOp.MAX)
-    out.update(c5_nps=float(f"{nodes / dt:.4g}"), c5_xchg_share=round(float(x.item()) / dt, 4), c5_moved=int(moved),
-               c5_moved_mb=round(moved * info.get("record_bytes", 8 * n) / 1e6, 2), c5_nodes=int(nodes), c5_ms=round(dt * 1e3, 2), c5_exchanges=int(info.get("exchanges", 0)))
-    del ds
-    torch.cuda.empty_cache()
+    # the worklist engine twice: open nodes as int32 rows (c5_i32_*), then as rows of packed cells (c5_*: pcp_device_batch.cell_format
+    # PCP_CELLS_PACKED16, pcp_branch_device_cells — half the bytes per open node and per record moved between ranks).  Same budget, same batch,
+    # same exchanges: the two must count the same tree.
+    totals = {}
+    for fmt, cells in (("i32", False), ("cells", True)):
+        if cells and args.no_cells:
+            continue
+        ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, budget + 4 * batch), implicit=True, cells=cells)
+        D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=min(budget, 8 * batch * world), rounds_per_exchange=args.rounds_per_exchange, base=1)
+        info = {}
+        (nodes, sols, fails, steps, moved), dt = timed(lambda: D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=budget,
+                                                                                      rounds_per_exchange=args.rounds_per_exchange, info=info, base=1))
+        x = torch.tensor([info.get("exchange_s", 0.0)], dtype=torch.float64, device=dev)
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        totals[fmt] = (int(nodes), int(sols), int(fails))
+        if cells or args.no_cells:
+            out.update(c5_nps=float(f"{nodes / dt:.4g}"), c5_xchg_share=round(float(x.item()) / dt, 4), c5_moved=int(moved),
+                       c5_moved_mb=round(moved * info.get("record_bytes", 8 * n) / 1e6, 2), c5_nodes=int(nodes), c5_ms=round(dt * 1e3, 2), c5_exchanges=int(info.get("exchanges", 0)),
+                       c5_fmt="cells" if cells else "i32", c5_rec_bytes=int(info.get("record_bytes", 0)))
+        else:
+            out.update(c5_i32_nps=float(f"{nodes / dt:.4g}"), c5_i32_ms=round(dt * 1e3, 2))
+        del ds
+        torch.cuda.empty_cache()
+    if len(totals) == 2:
+        if totals["i32"] != totals["cells"]:
+            raise RuntimeError(f"PARITY FAILURE (c5 worklist): packed cells {totals['cells']} != int32 rows {totals['i32']} (nodes, solutions, failures)")
+        out["c5_same_tree"] = 1
     trees = args.trees if args.trees else 4096
     spl = args.steps_per_launch if args.steps_per_launch else 1024
     forest_search(ctx, lb0, ub0, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world, dist=dist)
@@ -483,6 +500,8 @@ def main():
     ap.add_argument("--c5-single", action="store_true", help="run the config-5 legs of --gpus N > 1 on one GPU too (one-rank process group)")
     ap.add_argument("--c5-budget", type=int, default=2097152,
                     help="--gpus N > 1: nodes of the short config-5 leg appended to the headline run (worklist engine; the forest leg runs 8x as many); 0 = skip")
+    ap.add_argument("--cells", action="store_true", help="--mode search --engine worklist: keep the open nodes as rows of packed cells (cell_format PCP_CELLS_PACKED16)")
+    ap.add_argument("--no-cells", action="store_true", help="config-5 worklist leg (--gpus N > 1, --c5-single): int32 rows only (default: both formats, c5_* = packed cells)")
     ap.add_argument("--engine", choices=["forest", "worklist"], default="forest",
                     help="--mode search: forest = one in-kernel DFS per open node of a frontier, no exchange (default; the only engine for --domains set); "
                          "worklist = batched rounds with the open-node stacks balanced GPU-to-GPU over RCCL")

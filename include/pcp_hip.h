@@ -243,6 +243,10 @@ typedef struct {
  * its cell is clamped and the context's sticky hull flag is raised (the next pcp_stats_read returns PCP_ERR_CONTRACT). */
 int32_t pcp_pack_rows(pcp_ctx* ctx, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, uint32_t* cells, void* hip_stream);
 int32_t pcp_unpack_rows(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, int32_t* lb, int32_t* ub, void* hip_stream);
+/* pcp_branch_device_hint over rows of packed cells (implicit nodes): the same brancher, the same child order (option branch_reverse), the same
+ * counts and hints; child_cells has room for 2 n_nodes rows.  A search whose open nodes stay cells between launches needs nothing else. */
+int32_t pcp_branch_device_cells(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, const uint8_t* status, uint32_t* child_cells,
+                                uint32_t* child_dirty, uint32_t* counts, void* hip_stream);
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 
 /* ---- branching on the device (the caller side of the path) -------------------------------------

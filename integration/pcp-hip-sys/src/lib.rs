@@ -178,6 +178,8 @@ extern "C" {
                                   hip_stream: *mut c_void) -> i32; // the same, and every child's pcp_device_batch.dirty_var entry
     pub fn pcp_pack_rows(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, cells: *mut u32, hip_stream: *mut c_void) -> i32;
     pub fn pcp_unpack_rows(ctx: *mut pcp_ctx, n_nodes: u32, cells: *const u32, lb: *mut i32, ub: *mut i32, hip_stream: *mut c_void) -> i32;
+    pub fn pcp_branch_device_cells(ctx: *mut pcp_ctx, n_nodes: u32, cells: *const u32, status: *const u8, child_cells: *mut u32, child_dirty: *mut u32,
+                                   counts: *mut u32, hip_stream: *mut c_void) -> i32;
     pub fn pcp_branch_device_set(ctx: *mut pcp_ctx, n_nodes: u32, bits: *const u64, lb: *const i32, ub: *const i32, active: *const u64,
                                  status: *const u8, child_bits: *mut u64, child_active: *mut u64, counts: *mut u32,
                                  hip_stream: *mut c_void) -> i32; // the same brancher over IntervalSet domains

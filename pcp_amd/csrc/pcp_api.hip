@@ -1502,6 +1502,21 @@ int32_t pcp_branch_device_hint(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, 
   return PCP_OK;
 }
 
+int32_t pcp_branch_device_cells(pcp_ctx* c, uint32_t n_nodes, const uint32_t* cells, const uint8_t* status, uint32_t* child_cells, uint32_t* child_dirty,
+                                uint32_t* counts, void* hip_stream) {
+  if (!c || !counts) return PCP_ERR_ARG;
+  if (c->set_words) return fail(c, PCP_ERR_UNSUPPORTED, "pcp_branch_device_cells: interval mode only");
+  hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_nodes && (!status || (c->n_vars && (!cells || !child_cells)))) return fail(c, PCP_ERR_ARG, "null buffer");
+  int32_t rc = ensure(c, c->d_child_base, c->cap_child_base, std::max<uint32_t>(n_nodes, 1));
+  if (rc) return rc;
+  if (n_nodes == 0) { HIP_TRY(c, hipMemsetAsync(counts, 0, 20, stream)); return PCP_OK; }
+  HIP_TRY(c, launch_branch_scan(n_nodes, status, c->d_child_base, counts, stream));
+  HIP_TRY(c, launch_branch_cells(n_nodes, c->n_vars, cells, c->d_child_base, child_cells, child_dirty, counts, (uint32_t)c->opt_branch_reverse, stream));
+  return PCP_OK;
+}
+
 int32_t pcp_branch_device_set(pcp_ctx* c, uint32_t n_nodes, const uint64_t* bits, const int32_t* lb, const int32_t* ub, const uint64_t* active,
                               const uint8_t* status, uint64_t* child_bits, uint64_t* child_active, uint32_t* counts, void* hip_stream) {
   if (!c || !counts) return PCP_ERR_ARG;

@@ -47,6 +47,9 @@ hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stre
 // int32 bounds rows <-> rows of packed cells (n = nodes x variables entries); a bound that does not fit sets *violation
 hipError_t launch_pack_rows(const int32_t* lb, const int32_t* ub, uint32_t* cells, size_t n, uint32_t* violation, hipStream_t stream);
 hipError_t launch_unpack_rows(const uint32_t* cells, int32_t* lb, int32_t* ub, size_t n, hipStream_t stream);
+// the brancher over rows of cells; child_base from launch_branch_scan (pcp_kernels.hip), which also fills counts
+hipError_t launch_branch_cells(uint32_t n_nodes, uint32_t n_vars, const uint32_t* cells, const uint32_t* child_base, uint32_t* child_cells, uint32_t* child_dirty,
+                               const uint32_t* counts, uint32_t reverse, hipStream_t stream);
 
 // Binary models whose store fits LDS only as 10-bit cells (declared hull of at most 1024 values), implicit-active nodes, one node
 // per workgroup (pcp_big.hip).

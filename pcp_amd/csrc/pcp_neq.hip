@@ -1730,6 +1730,51 @@ __global__ void __launch_bounds__(256) unpack_rows_kernel(const uint32_t* __rest
   }
 }
 
+// ---- Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (search/branching/brancher.rs:52-71) on a row of cells: branch_kernel
+// (pcp_kernels.hip) with the bounds read from and written as cells.  One block per node; child_base[node] = the node's first child slot
+// (branch_scan_kernel), 0xFFFFFFFF = not Unknown.
+__global__ void __launch_bounds__(256) branch_cells_kernel(uint32_t n_vars, const uint32_t* __restrict__ cells, const uint32_t* __restrict__ child_base,
+                                                           uint32_t* __restrict__ child_cells, uint32_t* __restrict__ child_dirty, const uint32_t* __restrict__ counts,
+                                                           uint32_t reverse) {
+  const uint32_t node = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const uint32_t slot = child_base[node];
+  if (slot == 0xFFFFFFFFu) return;
+  const uint32_t rowL = reverse ? counts[0] - 1 - slot : slot;
+  const uint32_t rowR = reverse ? rowL - 1 : slot + 1;
+  __shared__ unsigned long long best[4];
+  const uint32_t* const p = cells + (size_t)node * n_vars;
+  unsigned long long key = ~0ull;  // FirstSmallestVar: minimum of (size << 32 | index) over the variables of size > 1
+  for (uint32_t v = tid; v < n_vars; v += nth) {
+    const int2 d = unpack16(p[v]);
+    const unsigned long long size = (unsigned long long)((long long)d.y - (long long)d.x + 1);
+    if (d.y > d.x) key = min(key, (size << 32) | v);
+  }
+  for (int o = 32; o > 0; o >>= 1) key = min(key, (unsigned long long)__shfl_down(key, o));
+  if ((tid & 63) == 0) best[tid >> 6] = key;
+  __syncthreads();
+  key = best[0];
+  for (uint32_t w = 1; w < (nth >> 6); ++w) key = min(key, best[w]);
+  const uint32_t var = key == ~0ull ? 0xFFFFFFFFu : (uint32_t)key;
+  int32_t val = 0;
+  if (var != 0xFFFFFFFFu) { const int2 d = unpack16(p[var]); val = (d.x + d.y) / 2; }  // MiddleVal: `/` truncates toward zero like Rust's
+  if (child_dirty && tid == 0) { child_dirty[rowL] = var; child_dirty[rowR] = var; }
+  uint32_t* const c0 = child_cells + (size_t)rowL * n_vars;
+  uint32_t* const c1 = child_cells + (size_t)rowR * n_vars;
+  for (uint32_t v = tid; v < n_vars; v += nth) {
+    const uint32_t c = p[v];
+    uint32_t l = c, r = c;
+    if (v == var) { const int2 d = unpack16(c); l = pack16(d.x, min(d.y, val)); r = pack16(max(d.x, val + 1), d.y); }  // x <= val | x > val
+    c0[v] = l; c1[v] = r;
+  }
+}
+
+hipError_t launch_branch_cells(uint32_t n_nodes, uint32_t n_vars, const uint32_t* cells, const uint32_t* child_base, uint32_t* child_cells, uint32_t* child_dirty,
+                               const uint32_t* counts, uint32_t reverse, hipStream_t stream) {
+  if (!n_nodes) return hipSuccess;
+  hipLaunchKernelGGL(branch_cells_kernel, dim3(n_nodes), dim3(256), 0, stream, n_vars, cells, child_base, child_cells, child_dirty, counts, reverse);
+  return hipGetLastError();
+}
+
 hipError_t launch_neqfix(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (a.nodes_per_block == 0 || a.nodes_per_block > 16 || a.m.n_slots >= 65536u || !a.m.adjp) return hipErrorInvalidValue;
   if (a.dfs.n_steps) {

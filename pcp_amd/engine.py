@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library():
     L.pcp_branch_device_hint.argtypes = [vp, u32] + [vp] * 10
     L.pcp_pack_rows.argtypes = [vp, u32, vp, vp, vp, vp]
     L.pcp_unpack_rows.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.pcp_branch_device_cells.argtypes = [vp, u32, vp, vp, vp, vp, vp, vp]
     L.pcp_branch_device_set.argtypes = [vp, u32] + [vp] * 9
     L.pcp_dfs_device.argtypes = [vp, C.POINTER(DfsState), u32, u32, C.c_uint64, vp]
     L.pcp_dfs_forest_device_set.argtypes = [vp, C.POINTER(ForestState), u32, u32, C.c_uint64, vp]
@@ -130,7 +131,7 @@ def load_library():
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -313,6 +314,12 @@ class Context:
         ub = torch.empty_like(cells) if ub is None else ub
         self._check(self._L.pcp_unpack_rows(self._h, cells.shape[0], C.c_void_p(cells.data_ptr()), C.c_void_p(lb.data_ptr()), C.c_void_p(ub.data_ptr()), C.c_void_p(stream_ptr)))
         return lb, ub
+
+    def branch_device_cells(self, n_nodes: int, cells, status, child_cells, counts, stream_ptr: int = 0, child_dirty=None):
+        """pcp_branch_device_cells: branch_device over rows of packed cells (implicit nodes)."""
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self._L.pcp_branch_device_cells(self._h, n_nodes, p(cells), p(status), p(child_cells), p(child_dirty), p(counts), C.c_void_p(stream_ptr)))
 
     def branch_device(self, n_nodes: int, lb, ub, active, status, child_lb, child_ub, child_active, counts, stream_ptr: int = 0, child_dirty=None):
         """pcp_branch_device(_hint) on torch tensors of this context's device (counts: int32[5]; child_dirty: int32 [2 n] capacity, receives

@@ -35,7 +35,7 @@ class DeviceSearch:
     the children straight above them, in reverse order, as a new segment: nothing is copied or reordered.  The popped
     parents leave a hole below the new segment; it is reclaimed when that segment is used up (LIFO)."""
 
-    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None, implicit: bool = False, hints=None):
+    def __init__(self, ctx, batch: int = 1024, capacity: int = 0, device=None, implicit: bool = False, hints=None, cells: bool = False):
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -45,8 +45,13 @@ class DeviceSearch:
         self.V, self.W = V, W
         self.cap = int(capacity) if capacity else 8 * self.batch + 64
         i32, i64, u8 = torch.int32, torch.int64, torch.uint8
+        # cells: the open nodes are rows of packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16; all-XNeqY models with a declared hull
+        # within +-16383, implicit nodes): `lb` holds the cells, there is no `ub` — half the bytes per open node, same search node for node
+        self.cells = bool(cells)
+        if self.cells and (not implicit or getattr(ctx, "set_words", 0)):
+            raise ValueError("cells=True needs implicit nodes in interval mode")
         self.lb = torch.empty((self.cap, V), dtype=i32, device=self.dev)
-        self.ub = torch.empty((self.cap, V), dtype=i32, device=self.dev)
+        self.ub = None if self.cells else torch.empty((self.cap, V), dtype=i32, device=self.dev)
         # implicit: a node record is its domains only — no `active` rows are kept, the engine derives liveness from the
         # domains (a node that descends from an all-active root has active = not entailed)
         self.implicit = bool(implicit) or not ctx.words
@@ -86,6 +91,8 @@ class DeviceSearch:
 
     def _rows(self):
         rows = (self.lb, self.ub) if self.act is None else (self.lb, self.ub, self.act)
+        if self.cells:
+            rows = (self.lb,)
         if self.dirty is not None:
             rows = rows + (self.dirty,)
         return rows if self.bits is None else rows + (self.bits,)
@@ -123,8 +130,13 @@ class DeviceSearch:
             from .model import interval_bits
             self.base = int(base)
             self.bits[0] = torch.from_numpy(interval_bits(np.asarray(lb0), np.asarray(ub0), self.set_words, self.base).view(np.int64)).to(self.dev)
-        self.lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev)
-        self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
+        if self.cells:
+            l0 = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev).reshape(1, -1)
+            u0 = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev).reshape(1, -1)
+            ctx.pack_rows(l0, u0, self.lb[0:1], self._stream())
+        else:
+            self.lb[0] = torch.from_numpy(np.ascontiguousarray(lb0, np.int32)).to(self.dev)
+            self.ub[0] = torch.from_numpy(np.ascontiguousarray(ub0, np.int32)).to(self.dev)
         if self.act is not None:
             self.act[0] = torch.from_numpy(full_active(1, ctx.n_units).view(np.int64)[0]).to(self.dev)
         if self.dirty is not None:
@@ -167,10 +179,14 @@ class DeviceSearch:
             if n <= 0:
                 break
             lo = top - n
-            lb, ub = self.lb[lo:top], self.ub[lo:top]
+            lb, ub = self.lb[lo:top], (None if self.cells else self.ub[lo:top])
             act = None if self.act is None else self.act[lo:top]
             status = self.status[:n]
-            if self.bits is None and self.dirty is not None:
+            if self.cells:
+                dirty = None if self.dirty is None else self.dirty[lo:top]
+                ctx.propagate_device(n, lb, None, lb, None, None, None, status, stream, dirty=dirty, cells=True)
+                ctx.branch_device_cells(n, lb, status, self.lb[top:], self.counts, stream, child_dirty=None if self.dirty is None else self.dirty[top:])
+            elif self.bits is None and self.dirty is not None:
                 ctx.propagate_device(n, lb, ub, lb, ub, act, act, status, stream, dirty=self.dirty[lo:top])
                 ctx.branch_device(n, lb, ub, act, status, self.lb[top:], self.ub[top:], None if self.act is None else self.act[top:],
                                   self.counts, stream, child_dirty=self.dirty[top:])
@@ -203,7 +219,8 @@ class DeviceSearch:
                 if limit_row_true:
                     rows = rows[rows != 0]  # (not counted: not kept either)
                 rows = rows[: keep_solutions - len(st.solutions)]
-                for r in lb[rows].cpu().numpy():
+                sol = ctx.unpack_rows(lb[rows].contiguous(), stream_ptr=stream)[0] if self.cells else lb[rows]
+                for r in sol.cpu().numpy():
                     st.solutions.append(r)
             # pop the parents; the children, already in left-first order (branch_reverse), become the new top segment
             self.segs[-1][1] = length - n
@@ -231,7 +248,7 @@ class DeviceSearch:
         if self.segs and self.segs[-1][1] < min(k, self.size):
             self.compact()
         if not self.segs:
-            return self.lb[0:0], self.ub[0:0], (None if self.act is None else self.act[0:0])
+            return self.lb[0:0], (None if self.cells else self.ub[0:0]), (None if self.act is None else self.act[0:0])
         s, l = self.segs[-1]
         lo = max(s, s + l - k)
-        return self.lb[lo:s + l], self.ub[lo:s + l], (None if self.act is None else self.act[lo:s + l])
+        return self.lb[lo:s + l], (None if self.cells else self.ub[lo:s + l]), (None if self.act is None else self.act[lo:s + l])

@@ -41,7 +41,52 @@ class OracleDeviceCtx(OracleCtx):
     def stats_read(self, stream=0):
         return dict(self._stats)
 
-    def propagate_device(self, n, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream=0, bits_in=None, bits_out=None, dirty=None):
+    # ---- rows of packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16): cell = (-lb & 0xffff) | ub << 16, as int32 tensors
+    @staticmethod
+    def _pack(L, U):
+        assert (np.abs(L) <= 16383).all() and (np.abs(U) <= 16383).all()
+        return (((-L.astype(np.int64)) & 0xffff) | ((U.astype(np.int64) & 0xffff) << 16)).astype(np.uint32).view(np.int32)
+
+    @staticmethod
+    def _unpack(cells):
+        c = np.ascontiguousarray(cells).view(np.uint32)
+        return (-(c & 0xffff).astype(np.uint16).view(np.int16).astype(np.int32)), (c >> 16).astype(np.uint16).view(np.int16).astype(np.int32)
+
+    def pack_rows(self, lb, ub, cells=None, stream_ptr=0):
+        import torch
+        out = torch.from_numpy(self._pack(lb.numpy(), ub.numpy()))
+        if cells is None:
+            return out
+        cells[:] = out
+        return cells
+
+    def unpack_rows(self, cells, lb=None, ub=None, stream_ptr=0):
+        import torch
+        L, U = self._unpack(cells.numpy())
+        return torch.from_numpy(L), torch.from_numpy(U)
+
+    def branch_device_cells(self, n, cells, status, child_cells, counts, stream=0, child_dirty=None):
+        import torch
+        L, U = self._unpack(cells[:n].numpy())
+        cl, cu = torch.zeros((2 * n, self.n_vars), dtype=torch.int32), torch.zeros((2 * n, self.n_vars), dtype=torch.int32)
+        self.branch_device(n, torch.from_numpy(L), torch.from_numpy(U), None, status, cl, cu, None, counts, stream, child_dirty=child_dirty)
+        k = int(counts[0])
+        if k:
+            child_cells[:k] = torch.from_numpy(self._pack(cl[:k].numpy(), cu[:k].numpy()))
+
+    def propagate_device(self, n, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, stream=0, bits_in=None, bits_out=None, dirty=None, cells=False):
+        if cells:
+            import torch
+            assert ub_in is None and ub_out is None and active_in is None and active_out is None
+            L, U = self._unpack(lb_in[:n].numpy())
+            lo, uo = torch.from_numpy(L.copy()), torch.from_numpy(U.copy())
+            self.propagate_device(n, lo, uo, lo, uo, None, None, status, stream, dirty=dirty)
+            ok = status[:n].numpy() != 0  # (a failed node's domains are unspecified — and may be empty, which no cell need carry)
+            out = lb_in[:n].numpy().copy()
+            out[ok] = self._pack(lo.numpy()[ok], uo.numpy()[ok])
+            lb_out[:n] = torch.from_numpy(out)
+            self.cell_launches = getattr(self, "cell_launches", 0) + 1
+            return
         if dirty is not None:
             # a hint must name a variable of the node (or none: -1) and — the promise — giving that variable back its parent's bound must
             # leave a fixpoint; the oracle ignores hints (same results by definition), the stand-in only checks their form

@@ -183,3 +183,101 @@ def test_cells_refusals(ctx):
     ctx.set_option("small_path", 0)
     with pytest.raises(E.PcpError):
         ctx.propagate_device(64, cells, None, cells, None, None, None, st, cells=True)
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_branch_on_cells_equals_branch_on_rows(ctx, reverse):
+    """pcp_branch_device_cells = pcp_branch_device_hint through pack / unpack: same children in the same rows, same hints, same counts —
+    including nodes that are not Unknown (skipped) and negative bounds (MiddleVal truncates toward zero)."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    V, dom = 33, (-7, 9)
+    props = neq_model(21, V, 90, dom)
+    ctx.set_model(V, props)
+    ctx.set_hull(dom[0], dom[1])
+    ctx.set_option("small_path", 0)
+    n = 200
+    L, U = nodes_with_assignments(77, V, n, dom, p_assign=0.25)
+    lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.propagate_device(n, lb, ub, lb, ub, None, None, st)
+    assert len(set(st.cpu().tolist())) >= 2
+    ctx.set_option("branch_reverse", reverse)
+    cl = torch.zeros((2 * n, V), dtype=torch.int32, device=dev); cu = torch.zeros_like(cl)
+    cd = torch.full((2 * n,), -5, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(5, dtype=torch.int32, device=dev)
+    ctx.branch_device(n, lb, ub, None, st, cl, cu, None, cnt, child_dirty=cd)
+    cells = ctx.pack_rows(lb, ub)
+    cc = torch.zeros((2 * n, V), dtype=torch.int32, device=dev)
+    cd2 = torch.full((2 * n,), -5, dtype=torch.int32, device=dev)
+    cnt2 = torch.zeros(5, dtype=torch.int32, device=dev)
+    ctx.branch_device_cells(n, cells, st, cc, cnt2, child_dirty=cd2)
+    ctx.set_option("branch_reverse", 0)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt, cnt2)
+    k = int(cnt[0].item())
+    assert k == 2 * int((st == 2).sum().item()) and k > 0
+    l2, u2 = ctx.unpack_rows(cc[:k].contiguous())
+    assert torch.equal(l2, cl[:k]) and torch.equal(u2, cu[:k]) and torch.equal(cd[:k], cd2[:k])
+    assert (cd2[k:] == -5).all() and (cc[k:] == 0).all()
+
+
+@pytest.mark.parametrize("n", [8, 10])
+def test_device_search_on_cells_is_the_same_tree(ctx, n):
+    """DeviceSearch(cells=True): the open nodes stay packed cells from the root to the leaves (pcp_propagate_device with cell_format,
+    pcp_branch_device_cells).  Node for node the oracle's tree, and the same solutions in the same order as the search over int32 rows."""
+    from pcp_amd.search_device import DeviceSearch
+    props = M.nqueens_props(n)
+    ctx.set_model(n, props)
+    ctx.set_hull(1, n)
+    ctx.set_option("small_path", 0)
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    ss = orc.OracleModel(n, props).search(lb0, ub0, all_solutions=True)[0]
+    want = (ss["num_nodes"], ss["num_solution"], ss["num_failed_node"])
+    for batch in (1, 7, 64):
+        base = DeviceSearch(ctx, batch=batch, capacity=4096, implicit=True).run(lb0, ub0, all_solutions=True, keep_solutions=50)
+        for hints in (True, False):
+            ds = DeviceSearch(ctx, batch=batch, capacity=4096, implicit=True, hints=hints, cells=True)
+            assert ds.ub is None
+            st = ds.run(lb0, ub0, all_solutions=True, keep_solutions=50)
+            assert (st.num_nodes, st.num_solution, st.num_failed_node) == want, (batch, hints)
+            assert len(st.solutions) == len(base.solutions) and all(np.array_equal(a, b) for a, b in zip(st.solutions, base.solutions))
+    lim = DeviceSearch(ctx, batch=7, capacity=4096, implicit=True, cells=True).run(lb0, ub0, all_solutions=True, node_limit=40)
+    ref = DeviceSearch(ctx, batch=7, capacity=4096, implicit=True).run(lb0, ub0, all_solutions=True, node_limit=40)
+    assert (lim.num_nodes, lim.num_solution, lim.num_failed_node) == (ref.num_nodes, ref.num_solution, ref.num_failed_node)
+    ctx.set_option("small_path", 1)
+
+
+@pytest.mark.parametrize("n", [64, 7])
+def test_cell_outside_the_format_refuses_its_node(ctx, n):
+    """A cell that pcp_pack_rows could not have written (a half outside +-16384) refuses its node — status PCP_STATUS_HULL, the row untouched,
+    the sticky flag raised — in the full-tile and the ragged staging loop; the other nodes of the tile are propagated as usual."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    V, dom = 24, (0, 6)
+    props = neq_model(9, V, 60, dom)
+    ctx.set_model(V, props)
+    ctx.set_hull(*dom)
+    ctx.set_option("small_path", 0)
+    L, U = nodes_with_assignments(9, V, n, dom, p_assign=0.1)
+    ref = orc.OracleModel(V, props).consistency(L.copy(), U.copy(), None)
+    lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+    cells = ctx.pack_rows(lb, ub)
+    cells[5, 3] = 0x7fff0000          # ub = 32767
+    before = cells[5].clone()
+    st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ctx.stats_reset()
+    ctx.propagate_device(n, cells, None, cells, None, None, None, st, cells=True)
+    l2, u2 = ctx.unpack_rows(cells)
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    assert st[5] == 0xFE and torch.equal(cells[5], before)
+    keep = np.arange(n) != 5
+    assert np.array_equal(st[keep], ref[3][keep])
+    ok = keep & (st != 0)
+    assert np.array_equal(l2.cpu().numpy()[ok], ref[0][ok]) and np.array_equal(u2.cpu().numpy()[ok], ref[1][ok])
+    with pytest.raises(E.PcpError):
+        ctx.stats_read()
+    ctx.stats_reset()
+    ctx.stats_read()
+    ctx.set_option("small_path", 1)

@@ -145,7 +145,7 @@ def test_two_rank_worklist_gloo(batch):
     assert len(res[0][5]) > 0 and len(res[1][5]) > 0  # both ranks did real work
 
 
-def _device_worker(rank, world, port, n, batch, implicit, q, node_limit=0):
+def _device_worker(rank, world, port, n, batch, implicit, q, node_limit=0, cells=False):
     """parallel_search_device end to end over gloo: DeviceSearch on CPU tensors with the oracle-backed stand-in context."""
     import torch
     import torch.distributed as dist
@@ -156,7 +156,7 @@ def _device_worker(rank, world, port, n, batch, implicit, q, node_limit=0):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         ctx = OracleDeviceCtx(n, M.nqueens_props(n))
-        ds = DeviceSearch(ctx, batch=batch, capacity=4096, device=torch.device("cpu"), implicit=implicit)
+        ds = DeviceSearch(ctx, batch=batch, capacity=4096, device=torch.device("cpu"), implicit=implicit, cells=cells)
         info = {}
         tot = D.parallel_search_device(ds, np.ones(n, np.int32), np.full(n, n, np.int32), dist, all_solutions=True, rounds_per_exchange=2, info=info,
                                        node_limit=node_limit)
@@ -203,6 +203,45 @@ def test_two_rank_device_search_gloo(implicit):
     assert tot0 == tot1 and tot0[:3] == (779, 92, 298)   # nodes, solutions, failures of the reference's tree (all_solution.rs:70)
     assert tot0[4] > 0 and n0 > 0 and n1 > 0 and n0 + n1 == 779 and x0 == x1 > 1
     assert rb0 == rb1 == 8 * 8 + (4 if implicit else 8 * ((3 * 28 + 63) // 64)) and mb0 + mb1 == tot0[4] * rb0  # only whole records moved (implicit nodes: the bounds + the 4-byte dirty-variable hint)
+
+
+def test_two_rank_device_search_on_cells_gloo():
+    """The same driver with the open nodes kept as rows of packed cells (DeviceSearch(cells=True): pcp_device_batch.cell_format,
+    pcp_branch_device_cells): the stack has ONE row tensor per node, so a record that moves between ranks is 4 bytes per variable plus the
+    hint; the tree is the reference's."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_device_worker, args=(r, 2, port, 8, 8, True, q, 0, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, tot0, n0, x0, mb0, rb0, _), (r1, tot1, n1, x1, mb1, rb1, _) = res
+    assert tot0 == tot1 and tot0[:3] == (779, 92, 298)
+    assert tot0[4] > 0 and n0 > 0 and n1 > 0 and n0 + n1 == 779
+    assert rb0 == rb1 == 4 * 8 + 4 and mb0 + mb1 == tot0[4] * rb0
+
+
+def test_device_search_on_cells_stand_in():
+    """DeviceSearch(cells=True) on the oracle-backed stand-in: every launch goes through the cell entry points, solutions come back unpacked."""
+    import torch
+    from oracle_ctx import OracleDeviceCtx
+    from pcp_amd.search_device import DeviceSearch
+    n = 8
+    ctx = OracleDeviceCtx(n, M.nqueens_props(n))
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    base = DeviceSearch(ctx, batch=5, capacity=4096, device=torch.device("cpu"), implicit=True).run(lb0, ub0, all_solutions=True, keep_solutions=92)
+    ds = DeviceSearch(ctx, batch=5, capacity=4096, device=torch.device("cpu"), implicit=True, cells=True)
+    st = ds.run(lb0, ub0, all_solutions=True, keep_solutions=92)
+    assert ds.ub is None and ctx.cell_launches == st.rounds
+    assert (st.num_nodes, st.num_solution, st.num_failed_node) == (779, 92, 298)
+    assert len(st.solutions) == 92 and all(np.array_equal(a, b) for a, b in zip(st.solutions, base.solutions))
+    with pytest.raises(ValueError):
+        DeviceSearch(ctx, batch=5, device=torch.device("cpu"), implicit=False, cells=True)
 
 
 @pytest.mark.parametrize("n,batch", [(8, 4), (9, 8)])

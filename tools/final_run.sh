@@ -10,6 +10,8 @@ fi
 timeout 600 python bench.py > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
 cp gpurun_out/bench_legs.json gpurun_out/$T/bench_legs.json 2>/dev/null
 timeout 200 python bench.py --mode search > gpurun_out/$T/search_interval.json 2> gpurun_out/$T/search_interval.err
+timeout 200 python bench.py --mode search --engine worklist > gpurun_out/$T/search_worklist.json 2> gpurun_out/$T/search_worklist.err
+timeout 200 python bench.py --mode search --engine worklist --cells > gpurun_out/$T/search_worklist_cells.json 2> gpurun_out/$T/search_worklist_cells.err
 timeout 200 python bench.py --mode search --domains set > gpurun_out/$T/search_set.json 2> gpurun_out/$T/search_set.err
 timeout 300 python bench.py --legs none --cpu-budget 0 --c5-single > gpurun_out/$T/bench_c5_single.json 2> gpurun_out/$T/bench_c5_single.err
 timeout 400 bash tools/profile_cmd.sh $T/benchcmd python bench.py --legs none --cpu-budget 0 > gpurun_out/$T/prof_benchcmd.log 2>&1

@@ -16,6 +16,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = E.Context(0)
 t0, it, checked = time.time(), 0, 0
 paths = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0}
+cells_checked = 0
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed0 + it)
     n = int(rng.integers(20, 110))
@@ -104,6 +105,26 @@ while time.time() - t0 < budget:
         checked += 1
     paths[path] += 1
     checked += 1
+    if kinds == [M.NEQ]:
+        # the same nodes resident as packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16): any tile size, in or out of place
+        import torch
+        for k, v in {"neq_path": 1, "small_path": 1, "global_dom": 0, "nodes_per_block": int(rng.choice([0, 1, 2, 4, 8, 16]))}.items():
+            ctx.set_option(k, v)
+        dev = torch.device("cuda", ctx.device)
+        tl, tu = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+        cells = ctx.pack_rows(tl, tu)
+        out = cells if rng.random() < 0.5 else torch.zeros_like(cells)
+        st = torch.zeros(N, dtype=torch.uint8, device=dev)
+        ctx.propagate_device(N, cells, None, out, None, None, None, st, cells=True)
+        assert ctx.last_plan()["path"] == 1
+        gl, gu = ctx.unpack_rows(out)
+        torch.cuda.synchronize()
+        st = st.cpu().numpy(); ok = st != 0
+        assert np.array_equal(st, ref_i[3]) and np.array_equal(gl.cpu().numpy()[ok], ref_i[0][ok]) and np.array_equal(gu.cpu().numpy()[ok], ref_i[1][ok]), \
+            f"soak it={it} n={n} P={P} N={N} [cells]"
+        ctx.set_option("nodes_per_block", 0)
+        cells_checked += 1
+        checked += 1
     for k, v in {"global_dom": 0, "neq_path": 1, "big_path": 1, "big_round": 0, "small_path": 1}.items():
         ctx.set_option(k, v)
     if rng.random() < 0.3:  # path 3: a random store of formula units (the reified layer), explicit rows and implicit nodes
@@ -120,4 +141,4 @@ while time.time() - t0 < budget:
         assert_parity(reff[:4], got[:4], f"soak it={it} formula store [implicit]")
         paths[3] += has_formula; checked += 2
     it += 1
-print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s; implicit launches by asserted path {paths}")
+print(f"soak ok: {it} models, {checked} launches checked in {time.time() - t0:.0f} s; implicit launches by asserted path {paths}; {cells_checked} launches on packed cells")
