@@ -388,8 +388,9 @@ const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB];
 // ---- write back: the rows of the nodes that changed (every node when the call is not in place).  A refused node's outputs are left
 // alone.  An empty cell found on the way out fails its node (misc[N_FAIL]).  Returns the mask of the nodes written (workgroup-uniform).
 template <bool PACKED, class Tile>
-__device__ __forceinline__ uint32_t neq_write_back(const Tile& tl, const int32_t* lb_in, const int32_t* ub_in, int32_t* lb_out, int32_t* ub_out, const bool cells) {
-  const bool in_place = lb_in == lb_out && (cells || ub_in == ub_out);
+__device__ __forceinline__ uint32_t neq_write_back(const Tile& tl, const int32_t* lb_in, const int32_t* ub_in, int32_t* lb_out, int32_t* ub_out, const bool cells,
+                                                   const bool force_all = false) {
+  const bool in_place = !force_all && lb_in == lb_out && (cells || ub_in == ub_out);
   const uint32_t all_nodes = tl.nb >= 32 ? 0xFFFFFFFFu : ((1u << tl.nb) - 1u);
   const uint32_t dirty = __builtin_amdgcn_readfirstlane(tl.misc[N_DIRTY]), refused = __builtin_amdgcn_readfirstlane(tl.misc[N_OOB]);
   uint32_t badm = 0;
@@ -477,6 +478,7 @@ __device__ __forceinline__ void neq_apply_jumps(const Tile& tl, uint32_t nwin, C
 struct NeqDfsRegs {
   uint32_t sp, stop, resume_var, hint, err;
   unsigned long long nodes, sols, fail;
+  uint32_t stale;  // the node on top of the stack is in LDS only (a left child whose row was not pushed): its write-back writes the whole row
 };
 
 // ---- the search step on the node the tile has just propagated: OneSolution / AllSolution over Propagation<Brancher<FirstSmallestVar,
@@ -484,7 +486,7 @@ struct NeqDfsRegs {
 // row (lb_out / ub_out: row sp - 1 of the tree's stack).  Count it; failed / solution: pop; Unknown: the right child x > v over the
 // parent's row, the left child x <= v on top and — its domains being in LDS already — marked as the node to continue with.
 template <bool PACKED, class Tile>
-__device__ __forceinline__ void neq_dfs_step(const Tile& tl, const NeqArgs& a, NeqDfsRegs& r) {
+__device__ __forceinline__ void neq_dfs_step(const Tile& tl, const NeqArgs& a, NeqDfsRegs& r, const bool last_step) {
   const bool failed = (tl.misc[N_FAIL] & 1u) != 0, refused = (tl.misc[N_OOB] & 1u) != 0, open = (tl.misc[N_UNK] & 1u) != 0;
   r.resume_var = 0xFFFFFFFFu;
   uint32_t new_sp = r.sp - 1;
@@ -539,9 +541,17 @@ __device__ __forceinline__ void neq_dfs_step(const Tile& tl, const NeqArgs& a, N
         if constexpr (PACKED) tl.dom[tl.rowof(var)] = pack16(d.x, min(d.y, val)); else tl.dom[tl.rowof(var)] = make_int2(-d.x, min(d.y, val));
       }
       __syncthreads();
-      int32_t* l0 = a.lb_out + tl.V;
-      int32_t* u0 = a.ub_out + tl.V;
-      for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) { const int2 c = cell_bounds<PACKED>(tl.dom[tl.rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
+      // The left child is the next node of this very loop and is propagated from LDS; the write-back of ITS fixpoint puts its row on the
+      // stack (in full: r.stale).  Its unpropagated row is written here only when the loop ends with it on top — the launch's last step,
+      // or the node limit reached —, so that the stack in HBM is complete whenever anyone else can look at it (between launches: the
+      // steal, the refill across ranks, the host).  Saves one 8 n_vars-byte row of scalar stores per node.
+      if (last_step || (a.dfs.node_limit && r.nodes >= a.dfs.node_limit)) {
+        int32_t* l0 = a.lb_out + tl.V;
+        int32_t* u0 = a.ub_out + tl.V;
+        for (uint32_t v = tl.tid; v < tl.V; v += tl.nth) { const int2 c = cell_bounds<PACKED>(tl.dom[tl.rowof(v)]); l0[v] = c.x; u0[v] = c.y; }
+      } else {
+        r.stale = 1u;
+      }
       new_sp = r.sp + 1;
       r.resume_var = var;
     }
@@ -1380,7 +1390,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
   bool adj_loaded = false, adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
-  NeqDfsRegs dfs{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0ull, 0ull, 0ull};
+  NeqDfsRegs dfs{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0ull, 0ull, 0ull, 0u};
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
   // the forest of one tree; pcp_dfs_forest_device launches many, each an independent instance of the same loop)
   const size_t tree_row0 = DFS ? (size_t)blockIdx.x * a_in.dfs.capacity : 0;
@@ -1561,7 +1571,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   bar();
   PCP_TR(11);
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
-  wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out, CELLS);
+  wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out, CELLS, DFS && dfs.stale != 0u);
+  if constexpr (DFS) dfs.stale = 0u;
   // the counters: wave sums by DPP (VALU only), then one lane adds them to the tile's LDS words.  (The wave reductions that used to
   // stand here were 24 dependent ds_bpermute round trips, 4 000 cycles of a frontier tile's 45 000; 64-lane LDS atomics on one
   // address were tried instead and cost 8 800.)
@@ -1639,7 +1650,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   } else {
     // ---- the search step on the node just propagated (what dfs_step_kernel does for the generic kernels) ---------------------
     bar();
-    neq_dfs_step<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, dfs);
+    neq_dfs_step<PACKED>(NeqTile<PACKED>{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth}, a, dfs, dfs_it + 1u >= a.dfs.n_steps);
     bar();
   }
   }  // the DFS loop / the tile loop

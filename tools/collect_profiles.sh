@@ -3,7 +3,7 @@
 # reads:   bash tools/collect_profiles.sh <tag> <rNN>        (run here, after the gpurun call has merged its output)
 set -u
 T=gpurun_out/$1; R=$2
-for L in frontier deep500 deep3000 mix mixh search neqforest c3 c4 f4 explicit setforest; do
+for L in frontier cells deep500 deep3000 mix mixh search neqforest c3 c4 f4 explicit setforest; do
   [ -f $T/${L}_summary.txt ] && cp $T/${L}_summary.txt profiles/${R}_${L}_rocprofv3_summary.txt
 done
 [ -f $T/forest8k/neqforest_summary.txt ] && cp $T/forest8k/neqforest_summary.txt profiles/${R}_neqforest8k_rocprofv3_summary.txt

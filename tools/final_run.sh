@@ -16,7 +16,7 @@ timeout 200 python bench.py --mode search --domains set > gpurun_out/$T/search_s
 timeout 300 python bench.py --legs none --cpu-budget 0 --c5-single > gpurun_out/$T/bench_c5_single.json 2> gpurun_out/$T/bench_c5_single.err
 timeout 400 bash tools/profile_cmd.sh $T/benchcmd python bench.py --legs none --cpu-budget 0 > gpurun_out/$T/prof_benchcmd.log 2>&1
 timeout 300 python tools/replay_leg.py save deep500 deep3000 > gpurun_out/$T/save.log 2>&1
-for L in frontier deep500 deep3000 mix mixh search neqforest; do timeout 600 bash tools/profile_leg.sh $T $L neqfix > gpurun_out/$T/prof_$L.log 2>&1; done
+for L in frontier cells deep500 deep3000 mix mixh search neqforest; do timeout 600 bash tools/profile_leg.sh $T $L neqfix > gpurun_out/$T/prof_$L.log 2>&1; done
 PCP_FOREST_8K=1 timeout 600 bash tools/profile_leg.sh $T/forest8k neqforest neqfix > gpurun_out/$T/prof_neqforest8k.log 2>&1
 timeout 300 bash tools/pmc_phases.sh $T/phases > gpurun_out/$T/prof_phases.log 2>&1
 timeout 120 python tools/box_probe.py > gpurun_out/$T/box_probe.json 2> /dev/null

@@ -2,7 +2,7 @@
 batches are built by thousands of one-node launches, which made the PMC passes of round 2 abort):
    python tools/replay_leg.py save deep500 deep3000     # build the batches once, un-profiled, into /tmp on the GPU box
    python tools/replay_leg.py run deep500 [launches]    # load and launch: in place on fresh copies, HIP-event time per launch
-   python tools/replay_leg.py run c3 | c4 | f4 | mix | explicit | frontier | search | setforest   # these build their input with a handful of launches"""
+   python tools/replay_leg.py run c3 | c4 | f4 | mix | explicit | frontier | cells | search | setforest   # these build their input with a handful of launches"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,10 +23,22 @@ def nq():
 
 
 HINT = None
+CELLS = False
 
 
 def launches(lb, ub, act, k):
     N = lb.shape[0]
+    if CELLS:  # the nodes resident as packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16)
+        st = torch.zeros(N, dtype=torch.uint8, device=dev)
+        cells0 = ctx.pack_rows(lb, ub)
+        ms = []
+        for i in range(k + 1):
+            c = cells0.clone()
+            torch.cuda.synchronize()
+            ctx.propagate_device(N, c, None, c, None, None, None, st, dirty=HINT, cells=True)
+            if i:
+                ms.append(ctx.last_kernel_ms())
+        return ms, ctx.last_plan()
     st = torch.zeros(N, dtype=torch.uint8, device=dev)
     ms = []
     for i in range(k + 1):
@@ -53,7 +65,8 @@ else:
     if nm.startswith("deep"):
         nq()
         lb, ub = (t.to(dev) for t in torch.load(f"/tmp/{nm}.pt"))
-    elif nm == "frontier":
+    elif nm in ("frontier", "cells"):
+        CELLS = nm == "cells"
         nq()
         L, U, _ = W.nqueens_frontier(ctx, n, 16384, share=0, shares=8, implicit=True)
         lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
