@@ -488,7 +488,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (rank 0, N=1 only; 0 = skip)")
     ap.add_argument("--active", choices=["implicit", "explicit"], default="implicit",
                     help="node format of the headline leg: domains only (liveness derived) or domains + `active` rows")
-    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: cells,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4")
+    ap.add_argument("--legs", default="auto", help="'auto' = all side legs at N=1, 'none', or a comma list of: cells,wide,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4")
     ap.add_argument("--share", type=int, default=-1, help="which share of the frontier this process runs (default: its rank)")
     ap.add_argument("--nodes-per-block", type=int, default=0)
     ap.add_argument("--block-threads", type=int, default=1024)
@@ -703,7 +703,7 @@ def main():
         }
         legs_req = args.legs
         if legs_req == "auto":
-            legs_req = "cells,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
+            legs_req = "cells,wide,mix,explicit,c2,forest,deep500,deep3000,set,setsearch,c3,c4,f4" if world == 1 else "none"
         legs = []
         if world == 1 and args.cpu_budget > 0:
             out["cpu_baseline"], ref = cpu_baseline(n, props, L, U, A, args.cpu_budget)
@@ -743,6 +743,7 @@ def main():
         put_ms("mix_ms", "MIX-nodes-along-the-dfs"); put_k("mix_nps", "MIX-nodes-along-the-dfs", "nodes_per_s"); put_k("mix_sps", "MIX-nodes-along-the-dfs", "evaluated_per_s")
         put_k("mix_frac", "MIX-nodes-along-the-dfs", "hbm_frac", 3)
         put_ms("pk_ms", "C2-frontier-resident-as-packed-cells"); put_k("pk_nps", "C2-frontier-resident-as-packed-cells", "nodes_per_s"); put_k("pk_frac", "C2-frontier-resident-as-packed-cells", "hbm_frac", 3)
+        put_ms("w8_ms", "C2-frontier-eight-shares-one-launch"); put_k("w8_nps", "C2-frontier-eight-shares-one-launch", "nodes_per_s"); put_k("w8_frac", "C2-frontier-eight-shares-one-launch", "hbm_frac", 3)
         put_ms("mixh_ms", "MIXH-children-with-dirty-var-hints"); put_ms("mixc_ms", "MIXC-children-no-hints"); put_k("mixh_nps", "MIXH-children-with-dirty-var-hints", "nodes_per_s")
         put_ms("d500_ms", "C2-deep-dive-500"); put_ms("d3000_ms", "C2-deep-dive-3000")
         put_ms("c3_ms", "C3-random-binary-csp-50k-vars-500k-props"); put_k("c3_sps", "C3-random-binary-csp-50k-vars-500k-props", "evaluated_per_s")
@@ -866,6 +867,44 @@ def side_legs(ctx, torch, dev, n, props, args, want, L, U):
                      "identical_to_int32_launch": True,
                      "note": "the headline frontier kept in HBM as rows of 32-bit cells (-lb & 0xffff | ub << 16): half the bytes per node; hbm_frac is of THESE bytes"})
         del copies, cells0, lb_h, ub_h, ul, uu
+    if "wide" in want and ctx.last_plan().get("path") == 1:
+        # the headline launch at EIGHT times its width: the 8 shares of the frontier (8 x args.nodes open nodes of one depth, ~1 GB of rows) in one
+        # launch — 16 tiles per persistent workgroup instead of 2.  Separates what a launch pays once (start-up, the first generation of tiles
+        # staged by every CU at the same moment, the late tiles of the few nodes that narrow) from the kernel's steady state.
+        reset_opts()
+        ctx.set_option("nodes_per_block", args.nodes_per_block)
+        stream = torch.cuda.current_stream().cuda_stream
+        parts = [W.nqueens_frontier(ctx, n, args.nodes, share=s_, shares=8, implicit=True)[:2] for s_ in range(8)]
+        Lw = torch.from_numpy(np.concatenate([p_[0] for p_ in parts])).to(dev)
+        Uw = torch.from_numpy(np.concatenate([p_[1] for p_ in parts])).to(dev)
+        nw = Lw.shape[0]
+        st_w = torch.zeros(nw, dtype=torch.uint8, device=dev)
+        copies = [(Lw.clone(), Uw.clone()) for _ in range(6)]
+        ctx.propagate_device(nw, *copies[0], *copies[0], None, None, st_w, stream)
+        torch.cuda.synchronize()
+        ctx.stats_reset(stream)
+        ms = []
+        for l_, u_ in copies[1:]:
+            ctx.propagate_device(nw, l_, u_, l_, u_, None, None, st_w, stream)
+            ms.append(ctx.last_kernel_ms())
+        stw = ctx.stats_read(stream)
+        # the same nodes one share per launch: identical rows and statuses
+        k0 = args.nodes
+        l1, u1 = Lw[:k0].clone(), Uw[:k0].clone()
+        st_1 = torch.zeros(k0, dtype=torch.uint8, device=dev)
+        ctx.propagate_device(k0, l1, u1, l1, u1, None, None, st_1, stream)
+        torch.cuda.synchronize()
+        if not (torch.equal(st_1, st_w[:k0]) and torch.equal(l1, copies[-1][0][:k0]) and torch.equal(u1, copies[-1][1][:k0])):
+            raise SystemExit("PARITY FAILURE (wide leg): a share of the wide launch differs from the same share launched alone")
+        med = float(np.median(ms))
+        nbytes = nw * node_bytes(V, words, False) + 8 * V * min(nw, stw["narrowings"] / len(ms))
+        legs.append({"name": "C2-frontier-eight-shares-one-launch", "nodes": nw, "launches": len(ms), "kernel_ms": {"min": float(min(ms)), "median": med, "max": float(max(ms))},
+                     "nodes_per_s": nw / (med * 1e-3), "evaluated_per_s": stw["evaluated"] / len(ms) / (med * 1e-3), "compulsory_bytes_per_launch": nbytes,
+                     "hbm_frac": nbytes / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, "us_per_headline_batch": med * 1e3 * args.nodes / nw, "share0_identical_to_its_own_launch": True,
+                     "plan": {k: v for k, v in ctx.last_plan().items() if k in ("nodes_per_block", "packed", "implicit_active", "grid")},
+                     "note": "the 8 shares of the frontier (what 8 ranks would each take one of) in ONE launch on one GPU: 16 tiles per persistent workgroup; "
+                             "us_per_headline_batch = this launch's time per 16384 nodes, to be read against the headline's kernel_ms"})
+        del copies, Lw, Uw, parts, l1, u1
     if "explicit" in want:  # the same frontier with explicit `active` rows (round 1's node format and headline)
         reset_opts()
         ctx.set_option("nodes_per_block", args.nodes_per_block)
