@@ -9,7 +9,7 @@ done
 [ -f $T/forest8k/neqforest_summary.txt ] && cp $T/forest8k/neqforest_summary.txt profiles/${R}_neqforest8k_rocprofv3_summary.txt
 [ -f $T/benchcmd/summary.txt ] && cp $T/benchcmd/summary.txt profiles/${R}_benchcmd_rocprofv3_summary.txt
 [ -f $T/phases/phases_summary.txt ] && cp $T/phases/phases_summary.txt profiles/${R}_phases_summary.txt
-{
+[ -f $T/neq_probe.txt ] && {
   echo "# the box's ceilings and the round's stand-alone probes, same gpurun call as the profiles (tools/final_run.sh)"
   echo "## tools/box_probe.py (tools/micro/box_probe.hip)"; cat $T/box_probe.json 2>/dev/null
   echo; echo "## tools/micro/stream_probe (D = 0, 10000, 20000 cycles of synthetic compute per tile) and tools/micro/stage_probe (D = 20000)"; cat $T/stream_probe.txt 2>/dev/null
