@@ -210,6 +210,8 @@ def run_search_mode(args, torch, dist, world, rank, dev):
     set_mode = args.domains == "set"
     ctx.set_model(n, M.nqueens_props(n), set_words=(n + 63) // 64 if set_mode else 0)
     ctx.set_hull(1, n)
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     batch = args.search_batch
     lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
     if set_mode or args.engine == "forest":
@@ -509,6 +511,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0, help="--mode search, forest: nodes per tree and launch (0 = 1024 for intervals, 2048 for sets)")
     ap.add_argument("--domains", choices=["interval", "set"], default="interval",
                     help="--mode search: Interval<i32> domains, or IntervalSet<i32> (the reference's FDSpace: what example/src/nqueens.rs runs)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="(experiments) pcp_set_option on the context after the model is set, e.g. --opt neq_persist=0; repeatable")
     ap.add_argument("--spawn-dry-run", action="store_true",
                     help="(tests) the self-spawned ranks only bring up a gloo group on CPU, all_reduce their ranks and rank 0 prints a small JSON line: checks the launcher without a GPU")
     args = ap.parse_args()

@@ -248,6 +248,9 @@ int32_t pcp_unpack_rows(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, i
 int32_t pcp_branch_device_cells(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, const uint8_t* status, uint32_t* child_cells,
                                 uint32_t* child_dirty, uint32_t* counts, void* hip_stream);
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
+/* One context = one queue of launches: the device-side scratch behind a launch (counters, team words, `active` scratch, the tile tickets of the
+ * persistent kernels) belongs to the context, so the launches of one context must not overlap on the device — enqueue them on one stream, or order
+ * the streams; concurrent launches take one context each (the model is uploaded per context). */
 
 /* ---- branching on the device (the caller side of the path) -------------------------------------
  * ≡ Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (search/branching/brancher.rs:52-71) applied to every

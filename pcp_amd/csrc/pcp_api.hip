@@ -71,6 +71,7 @@ struct pcp_ctx {
   // scratch
   pcp_stats* d_stats = nullptr;
   unsigned long long* d_dbg = nullptr;  // [PCP_DBG_COUNT] diagnostic counters (pcp_debug_counters)
+  uint32_t* d_tile_ctr = nullptr; // pcp_neq.hip's tile tickets (NeqArgs::tile_ctr): zero between launches
   uint32_t* d_retry = nullptr;   // packed launches: stamped with `epoch` by a tile that has to be re-run with 32-bit cells
   uint32_t epoch = 0;
   bool hull_set = false; int32_t hull_lo = 0, hull_hi = 0;  // pcp_model_set_hull
@@ -108,6 +109,7 @@ struct pcp_ctx {
   int64_t opt_neq_persist = 1;      // 1 = the tile kernel's workgroups are persistent (at most what the chip holds at once; each runs several tiles)
   int64_t opt_neq_debug = 0;        // profiling only: NeqArgs::debug
   int64_t opt_neq_trace = 0;        // profiling only: device pointer of NeqArgs::trace
+  int64_t opt_neq_dynamic = 2;      // pcp_neq.hip: tiles a persistent workgroup takes by the fixed stride before it draws its tiles from a ticket (0 = never draws)
   int64_t opt_neq_wgs = 2;          // workgroups of that kernel meant to share a CU (sizes the jump-window area in LDS)
   int64_t opt_neq_dfs_block = 0;    // threads per tree of the in-kernel search loop: 256 or 512; 0 = 512 for one tree (pcp_dfs_device: latency per node),
                                     // 256 for a forest (four independent chains per CU instead of two: 20 % more nodes/s measured)
@@ -622,6 +624,10 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   a.violation = c->d_retry + 1; a.dbg = c->d_dbg;
   a.debug = (uint32_t)c->opt_neq_debug; a.trace = reinterpret_cast<unsigned long long*>(c->opt_neq_trace);
   a.lds_wgs = lds_wgs;
+  // persistent workgroups with more tiles than workgroups draw their second and later tiles from a ticket (the first is blockIdx.x): tiles of
+  // unequal cost — deep nodes next to shallow ones — then spread over the workgroups as they come free instead of by a fixed stride
+  a.tile_static = (uint32_t)std::max<int64_t>(1, c->opt_neq_dynamic);
+  a.tile_ctr = (c->opt_neq_persist && c->opt_neq_dynamic && !c->dfs_sp && (uint64_t)a.tile_static * plan.grid < (n_nodes + B - 1) / B) ? c->d_tile_ctr : nullptr;
   a.stagger = (c->opt_neq_persist && plan.grid > (uint32_t)c->num_cu && !c->dfs_sp) ? (uint32_t)c->opt_neq_stagger : 0u;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
@@ -692,6 +698,7 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
   if (hipMalloc(reinterpret_cast<void**>(&c->d_stats), kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
       hipMemset(c->d_stats, 0, kStatSlots * sizeof(pcp_stats)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->d_retry), 8) != hipSuccess || hipMemset(c->d_retry, 0, 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), 9 * 128) != hipSuccess || hipMemset(c->d_tile_ctr, 0, 9 * 128) != hipSuccess ||  // (pcp_neq.hip: eight tile tickets and the count of finished workgroups, a cache line each)
       hipMalloc(reinterpret_cast<void**>(&c->d_dbg), kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess || hipMemset(c->d_dbg, 0, kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess ||
       hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
     delete c;
@@ -705,7 +712,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
   if (!c) return;
   hipError_t e = hipSetDevice(c->device);
   (void)e;
-  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_ad_tab, c->d_ad_vars, c->d_ad_mask, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_dbg, c->d_wdesc, c->d_adjp};
+  void* ptrs[] = {c->d_fnodes, c->d_unit_root, c->d_ad_tab, c->d_ad_vars, c->d_ad_mask, c->d_brec, c->d_badj, c->d_adjp4, c->d_seed_always, c->d_mul_off, c->d_gdesc, c->d_sum_off, c->d_sum_mem, c->d_recs, c->d_adj_off, c->d_adj, c->d_const, c->d_stats, c->d_live, c->d_team, c->d_stage, c->d_rec_unit, c->d_unit_first, c->d_recs8, c->d_child_base, c->d_retry, c->d_tile_ctr, c->d_dbg, c->d_wdesc, c->d_adjp};
   for (void* p : ptrs)
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
@@ -904,6 +911,9 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "big_round") {
     if (value < 0 || value > 2) return fail(c, PCP_ERR_ARG, "big_round must be 0 (auto), 1 (dense rounds only) or 2 (sparse rounds only)");
     c->opt_big_round = value;
+  } else if (k == "neq_dynamic") {
+    if (value < 0 || value > 1024) return fail(c, PCP_ERR_ARG, "neq_dynamic must be in [0,1024]");
+    c->opt_neq_dynamic = value;
   } else if (k == "neq_wgs") {
     if (value < 1 || value > 8) return fail(c, PCP_ERR_ARG, "neq_wgs must be in [1,8]");
     c->opt_neq_wgs = value;

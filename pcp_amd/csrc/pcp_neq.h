@@ -15,6 +15,8 @@ struct NeqArgs {
   uint32_t nodes_per_block;     // B <= 16 nodes per workgroup, domains in LDS node-major
   uint32_t packed;              // 1 = 16-bit (-lb, ub) cells (declared hull within +-kPackedMax), 0 = int2 cells
   uint32_t lds_wgs;             // workgroups meant to share a CU's LDS (sizes the jump-window area; must match lds_bytes_neq's argument)
+  uint32_t* tile_ctr;           // or null: nine words 128 bytes apart, zero between launches — [32 r] the next ticket of residue r = blockIdx.x & 7 (tile = tile_static * gridDim.x + 8 * ticket + r), [256] workgroups that finished (the last one zeroes all nine)
+  uint32_t tile_static;         // tiles a workgroup takes by the fixed stride before it draws tickets (>= 1)
   uint32_t stagger;             // option "neq_stagger": shader cycles by which the workgroup in a CU's second pair of wave slots delays its start (0 = none)
   uint32_t debug;               // profiling only ("neq_debug"; results are WRONG when non-zero): 1 = no rounds, 2 = no status scan, 4 = round 0 only
   uint32_t* violation;          // sticky device word: a node was refused with PCP_STATUS_HULL

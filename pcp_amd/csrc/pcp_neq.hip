@@ -79,6 +79,7 @@ constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
 
 constexpr uint32_t kR0Cap = 32;      // assigned variables of a tile that staging lists by itself (round 0's list built in passing); more: the marks are scanned
+constexpr uint32_t kNextTileWord = 2 * 48 + 14;  // word of the status area (behind its two copies and the seven u64 sums) that holds a persistent workgroup's next tile
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
 constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
 constexpr uint32_t kNoWin = 0xFFFFu;
@@ -126,6 +127,15 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
 // Sum over the 64 lanes of a wavefront, in every lane's... lane 63, handed out wave-uniform: six DPP adds (row_shr 1, 2, 4, 8 inside the rows
 // of 16 lanes, row_bcast 15 and 31 across them) and one readlane — VALU only.  __shfl_down is a ds_bpermute, i.e. an LDS-pipeline
 // round trip per step, and this kernel's LDS pipeline is where a frontier tile's serial steps queue up.
+// A kernel argument read from the kernel-argument segment at the point of use (the kernel's one parameter, NeqArgs, starts the segment).
+template <class T>
+__device__ __forceinline__ T neq_karg(size_t off) {
+  typedef __attribute__((address_space(4))) const char* KP;
+  typedef __attribute__((address_space(4))) const volatile T* TP;
+  KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(TP)(kp + off);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
@@ -1485,6 +1495,18 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   if (ptime) pt1 = __builtin_amdgcn_s_memtime();
   if (misc[N_OOB] && tid == 0) atomicMax(a.violation, 1u);  // sticky: reported by pcp_stats_read
 
+  uint32_t ticket = 0;
+  // Tiles of unequal cost on persistent workgroups: a workgroup's first `tile_static` tiles are blockIdx.x + k gridDim.x, the later ones come
+  // from a ticket — one of eight (blockIdx.x & 7: the tiles behind the static ones are dealt to the eight residues, so that 512 workgroups
+  // do not queue on one address: same-address device atomics serialise, and when every workgroup drew from one word in the launch's
+  // lockstep first generation the last of them waited ~8 us).  The ticket of the tile after next is drawn behind this tile's staging by the last
+  // wavefront's first lane (of a frontier tile's twelve pieces that wavefront walks one, not two) and published behind the status scan; the
+  // barrier there makes it visible, and the word's last reader (the end of the previous tile) is three barriers back.  (Drawn in front of the row
+  // loads and kept across the staging it cost the headline instantiation 16 B of scratch.)
+  // (the two arguments are read from the kernel-argument segment where they are used — volatile scalar loads, three per tile — instead of being
+  // held for the whole kernel in scalar registers it does not have: held, they cost the headline instantiation 16 B of scratch per lane)
+  auto draws = [&]() { return !DFS && neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr)) != nullptr && dfs_it + 1u >= neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)); };
+  if constexpr (!DFS) { if (tid == nth - 64u && draws()) ticket = atomicAdd(neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr)) + 32u * (blockIdx.x & 7u), 1u); }
   // ---- rounds: round 0 = the lists of the assigned variables (the sweep), round r = the lists of the changed variables ------
   Ctr ctr;
   uint32_t ev0 = 0;  // item tests of round 0 (they stand for the sweep: counted as evaluated, not as extra steps)
@@ -1564,6 +1586,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
   // chains one after the other in every wavefront.
   neq_status_scan<PACKED, DFS>(tl, pay, (a.debug & 2u) != 0);
+  if constexpr (!DFS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   uint32_t wb_need = 0;
@@ -1642,7 +1665,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
     if (tr_on && lane < 16) a.trace[((size_t)tile * 16 + wv) * 16 + lane] = lane == 15 ? (unsigned long long)__builtin_amdgcn_s_memrealtime() : trbuf[wv * 16 + lane];
     // the next tile of this workgroup.  No barrier here: the next tile clears the OTHER copy of the status words, its cells are not
     // written before its own first barrier, and every wavefront left the last tile's cells behind the barrier above.
-    tile += gridDim.x;
+    tile = draws() ? (uint32_t)__builtin_amdgcn_readfirstlane(misc_base[kNextTileWord]) : tile + gridDim.x;
     if (tile >= n_tiles) break;
     node0 = tile * B; nb = min(B, n_eff - node0);
     if (ptime) { pt0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); pta = ptb = ptc = 0; }
@@ -1677,6 +1700,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
       *a.dfs.sp = dfs.sp; *a.dfs.stop = dfs.stop;
       a.dfs.counters[0] = dfs.nodes; a.dfs.counters[1] = dfs.sols; a.dfs.counters[2] = dfs.fail;
       if (dfs.err) a.dfs.counters[3] = dfs.err;
+    }
+    if constexpr (!DFS) {
+      uint32_t* const tile_ctr = neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr));
+      if (tile_ctr) {  // every workgroup drew the ticket that ended it before it comes here: the last one to arrive leaves the words zero for the next launch
+        __threadfence();
+        if (atomicAdd(tile_ctr + 32u * 8u, 1u) == gridDim.x - 1u) { for (uint32_t i = 0; i <= 8u; ++i) atomicExch(tile_ctr + 32u * i, 0u); }
+      }
     }
     if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : (n_tiles - 1 - blockIdx.x) / gridDim.x + 1));
   }
