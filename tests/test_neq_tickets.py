@@ -28,7 +28,7 @@ def batch():
     props = neq_model(4242, V, P, dom)
     L0, U0 = nodes_with_assignments(4343, V, 1500, dom)
     rng = np.random.default_rng(7)
-    pick = rng.integers(0, L0.shape[0], size=9001)  # (9001: the last tile is ragged for every tile size)
+    pick = rng.integers(0, L0.shape[0], size=13001)  # (13001: the last tile is ragged for every tile size; more than 3 x 1024 tiles of four nodes)
     L, U = np.ascontiguousarray(L0[pick]), np.ascontiguousarray(U0[pick])
     om = orc.OracleModel(V, props)
     ref0 = om.consistency(L0, U0, None)
