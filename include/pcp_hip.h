@@ -250,7 +250,9 @@ int32_t pcp_branch_device_cells(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* 
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
 /* One context = one queue of launches: the device-side scratch behind a launch (counters, team words, `active` scratch, the tile tickets of the
  * persistent kernels) belongs to the context, so the launches of one context must not overlap on the device — enqueue them on one stream, or order
- * the streams; concurrent launches take one context each (the model is uploaded per context). */
+ * the streams; concurrent launches take one context each (the model is uploaded per context).  The tile tickets are guarded at run time as well:
+ * a ticketed launch enqueued on another stream than the context's last ticketed launch waits for that one (hipStreamWaitEvent), and after any HIP
+ * error reported by this context the tickets are zeroed in front of the next launch that uses them. */
 
 /* ---- branching on the device (the caller side of the path) -------------------------------------
  * ≡ Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter (search/branching/brancher.rs:52-71) applied to every

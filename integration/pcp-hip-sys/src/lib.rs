@@ -122,6 +122,7 @@ pub struct pcp_dfs_state {
     pub status: *mut u8,
     pub counters: *mut u64, // nodes, solutions, failed, error, internal
     pub first_solution: *mut i32,
+    pub dirty: *mut u32, // ABI v7, nullable: [capacity] per stack row, the variable the row was branched on (>= n_vars: none)
 }
 
 /// `pcp_dfs_forest_device_set` (ABI v5): the search loop over FDSpace on the device, one tree per workgroup, an undo trail per tree.

@@ -72,6 +72,10 @@ struct pcp_ctx {
   pcp_stats* d_stats = nullptr;
   unsigned long long* d_dbg = nullptr;  // [PCP_DBG_COUNT] diagnostic counters (pcp_debug_counters)
   uint32_t* d_tile_ctr = nullptr; // pcp_neq.hip's tile tickets (NeqArgs::tile_ctr): zero between launches
+  bool tickets_suspect = false;   // a HIP error was seen on this context since the tickets were last known to be zero: the next ticketed launch zeroes them first
+  hipStream_t tickets_stream = nullptr;  // the stream of the last ticketed launch, and the event recorded behind it: a ticketed launch on ANOTHER stream waits
+  hipEvent_t ev_tickets = nullptr;       // for that event, so that two launches of one context can never draw from the words at the same time
+  bool tickets_used = false;
   uint32_t* d_retry = nullptr;   // packed launches: stamped with `epoch` by a tile that has to be re-run with 32-bit cells
   uint32_t epoch = 0;
   bool hull_set = false; int32_t hull_lo = 0, hull_hi = 0;  // pcp_model_set_hull
@@ -129,6 +133,8 @@ namespace {
 
 int32_t fail(pcp_ctx* c, int32_t code, const std::string& msg) {
   if (c) c->err = msg;
+  // (a launch that died may have left pcp_neq.hip's tile tickets non-zero — only the last workgroup of a launch that ends cleanly zeroes them)
+  if (c && code == PCP_ERR_HIP) c->tickets_suspect = true;
   return code;
 }
 int32_t hip_fail(pcp_ctx* c, hipError_t e, const char* what) {
@@ -627,7 +633,15 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   // persistent workgroups with more tiles than workgroups draw their second and later tiles from a ticket (the first is blockIdx.x): tiles of
   // unequal cost — deep nodes next to shallow ones — then spread over the workgroups as they come free instead of by a fixed stride
   a.tile_static = (uint32_t)std::max<int64_t>(1, c->opt_neq_dynamic);
-  a.tile_ctr = (c->opt_neq_persist && c->opt_neq_dynamic && !c->dfs_sp && (uint64_t)a.tile_static * plan.grid < (n_nodes + B - 1) / B) ? c->d_tile_ctr : nullptr;
+  // (the tiles behind the static ones are dealt to EIGHT residues of blockIdx.x: a grid of fewer than eight workgroups — a device or an option
+  // that leaves fewer than eight resident — would never draw some of them: fixed stride there)
+  a.tile_ctr = (c->opt_neq_persist && c->opt_neq_dynamic && !c->dfs_sp && plan.grid >= 8u && (uint64_t)a.tile_static * plan.grid < (n_nodes + B - 1) / B) ? c->d_tile_ctr : nullptr;
+  if (a.tile_ctr) {
+    // The tickets belong to the context and must be zero when a launch starts.  A launch that ended cleanly left them zero; after a HIP error on
+    // this context they are zeroed here; and a launch on a different stream than the last ticketed one first waits for that one to end.
+    if (c->tickets_suspect) { HIP_TRY(c, hipMemsetAsync(c->d_tile_ctr, 0, 9 * 128, stream)); c->tickets_suspect = false; }
+    if (c->tickets_used && c->tickets_stream != stream) HIP_TRY(c, hipStreamWaitEvent(stream, c->ev_tickets, 0));
+  }
   a.stagger = (c->opt_neq_persist && plan.grid > (uint32_t)c->num_cu && !c->dfs_sp) ? (uint32_t)c->opt_neq_stagger : 0u;
   a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
   a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
@@ -641,6 +655,7 @@ int32_t propagate_neq_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_start, stream));
   HIP_TRY(c, launch_neqfix(a, plan, stream));
   if (!c->dfs_sp && c->opt_time_kernels) HIP_TRY(c, hipEventRecord(c->ev_stop, stream));
+  if (a.tile_ctr) { HIP_TRY(c, hipEventRecord(c->ev_tickets, stream)); c->tickets_stream = stream; c->tickets_used = true; }
   if (bt->active_out && P) {
     // the `active` rows on request: record r is live iff it is not entailed under the final domains
     ModelDev m = a.m;
@@ -700,7 +715,8 @@ int32_t pcp_ctx_create(int32_t hip_device, pcp_ctx** out) {
       hipMalloc(reinterpret_cast<void**>(&c->d_retry), 8) != hipSuccess || hipMemset(c->d_retry, 0, 8) != hipSuccess ||
       hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), 9 * 128) != hipSuccess || hipMemset(c->d_tile_ctr, 0, 9 * 128) != hipSuccess ||  // (pcp_neq.hip: eight tile tickets and the count of finished workgroups, a cache line each)
       hipMalloc(reinterpret_cast<void**>(&c->d_dbg), kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess || hipMemset(c->d_dbg, 0, kStatSlots * PCP_DBG_COUNT * 8) != hipSuccess ||
-      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess) {
+      hipEventCreate(&c->ev_start) != hipSuccess || hipEventCreate(&c->ev_stop) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_tickets, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return PCP_ERR_HIP;
   }
@@ -717,6 +733,7 @@ void pcp_ctx_destroy(pcp_ctx* c) {
     if (p) { e = hipFree(p); (void)e; }
   if (c->ev_start) { e = hipEventDestroy(c->ev_start); (void)e; }
   if (c->ev_stop) { e = hipEventDestroy(c->ev_stop); (void)e; }
+  if (c->ev_tickets) { e = hipEventDestroy(c->ev_tickets); (void)e; }
   delete c;
 }
 

@@ -1330,7 +1330,9 @@ __device__ __forceinline__ void neq_stage_tile(const Tile& tl, const NeqArgs& a,
 // cell index of (slot, node) is shifts and immediates; a run-time tile size costs a multiplication per access and a handful of SGPRs the
 // kernel does not have (it spills scalars into VGPR lanes as it is).
 // CELLS: the bounds rows in HBM are rows of packed cells (pcp_device_batch.cell_format PCP_CELLS_PACKED16; PACKED batch launches only).
-template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false>
+// TICKETS: the launch has more tiles than `tile_static` per workgroup and deals the rest by tickets (NeqArgs::tile_ctr != null).  A template flag,
+// not a run-time test: the ticket's registers cost the 16 384-node headline launch — which never draws — 16 B of scratch per lane in round 5.
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false, bool TICKETS = false>
 __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_per_eu(4))) neqfix_kernel(const NeqArgs a_in) {  // (four wavefronts per SIMD: the forest runs 16 per CU)
   NeqArgs a = a_in;
   a.stats += blockIdx.x & (kStatSlots - 1);
@@ -1428,7 +1430,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
     const unsigned long long lo = wave_sum(x & 0xffffu);
     return __ballot((x >> 16) != 0u) ? lo + ((unsigned long long)wave_sum(x >> 16) << 16) : lo;
   };
-  for (uint32_t dfs_it = 0;; ++dfs_it) {  // DFS: the search loop's nodes; otherwise this workgroup's tiles
+  uint32_t dfs_it = 0;
+  for (;; ++dfs_it) {  // DFS: the search loop's nodes; otherwise this workgroup's tiles
   bool resume = false;
   if constexpr (!DFS) {
     misc = misc_base + (dfs_it & 1u) * 48u;
@@ -1505,8 +1508,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   // loads and kept across the staging it cost the headline instantiation 16 B of scratch.)
   // (the two arguments are read from the kernel-argument segment where they are used — volatile scalar loads, three per tile — instead of being
   // held for the whole kernel in scalar registers it does not have: held, they cost the headline instantiation 16 B of scratch per lane)
-  auto draws = [&]() { return !DFS && neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr)) != nullptr && dfs_it + 1u >= neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)); };
-  if constexpr (!DFS) { if (tid == nth - 64u && draws()) ticket = atomicAdd(neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr)) + 32u * (blockIdx.x & 7u), 1u); }
+  auto draws = [&]() { if constexpr (DFS || !TICKETS) return false; else return dfs_it + 1u >= neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)); };
+  if constexpr (!DFS && TICKETS) { if (tid == nth - 64u && draws()) ticket = atomicAdd(neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr)) + 32u * (blockIdx.x & 7u), 1u); }
   // ---- rounds: round 0 = the lists of the assigned variables (the sweep), round r = the lists of the changed variables ------
   Ctr ctr;
   uint32_t ev0 = 0;  // item tests of round 0 (they stand for the sweep: counted as evaluated, not as extra steps)
@@ -1586,7 +1589,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
   // chains one after the other in every wavefront.
   neq_status_scan<PACKED, DFS>(tl, pay, (a.debug & 2u) != 0);
-  if constexpr (!DFS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
+  if constexpr (!DFS && TICKETS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   uint32_t wb_need = 0;
@@ -1701,14 +1704,13 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
       a.dfs.counters[0] = dfs.nodes; a.dfs.counters[1] = dfs.sols; a.dfs.counters[2] = dfs.fail;
       if (dfs.err) a.dfs.counters[3] = dfs.err;
     }
-    if constexpr (!DFS) {
+    if constexpr (!DFS && TICKETS) {
       uint32_t* const tile_ctr = neq_karg<uint32_t*>(offsetof(NeqArgs, tile_ctr));
-      if (tile_ctr) {  // every workgroup drew the ticket that ended it before it comes here: the last one to arrive leaves the words zero for the next launch
-        __threadfence();
-        if (atomicAdd(tile_ctr + 32u * 8u, 1u) == gridDim.x - 1u) { for (uint32_t i = 0; i <= 8u; ++i) atomicExch(tile_ctr + 32u * i, 0u); }
-      }
+      // every workgroup drew the ticket that ended it before it comes here: the last one to arrive leaves the words zero for the next launch
+      __threadfence();
+      if (atomicAdd(tile_ctr + 32u * 8u, 1u) == gridDim.x - 1u) { for (uint32_t i = 0; i <= 8u; ++i) atomicExch(tile_ctr + 32u * i, 0u); }
     }
-    if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : (n_tiles - 1 - blockIdx.x) / gridDim.x + 1));
+    if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : dfs_it + 1u));  // the tiles this workgroup ran (by stride or by ticket)
   }
 }
 
@@ -1717,14 +1719,20 @@ size_t lds_bytes_neq(uint32_t n_slots, uint32_t n_vars, uint32_t nodes_per_block
   return c.total <= 160 * 1024 ? c.total : 0;
 }
 
-template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false>
-static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS, bool TICKETS>
+static hipError_t launch_neq_t(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
   if (p.lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS, TICKETS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
+  hipLaunchKernelGGL((neqfix_kernel<PACKED, PAY4, DFS, BT, CELLS, TICKETS>), dim3(p.grid), dim3(p.block), p.lds_bytes, stream, a);
   return hipGetLastError();
+}
+template <bool PACKED, bool PAY4, bool DFS, int BT, bool CELLS = false>
+static hipError_t launch_neq_k(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
+  if constexpr (!DFS)
+    if (a.tile_ctr) return launch_neq_t<PACKED, PAY4, DFS, BT, CELLS, true>(a, p, stream);
+  return launch_neq_t<PACKED, PAY4, DFS, BT, CELLS, false>(a, p, stream);
 }
 template <bool DFS, int BT>
 static hipError_t launch_neq_d(const NeqArgs& a, const LaunchPlan& p, hipStream_t stream) {
