@@ -296,7 +296,13 @@ def c5_legs(args, torch, dist, world, rank, dev, n):
     for fmt, cells in (("i32", False), ("cells", True)):
         if cells and args.no_cells:
             continue
-        ds = DeviceSearch(ctx, batch=batch, capacity=max(32 * batch, budget + 4 * batch), implicit=True, cells=cells)
+        # an Unknown node adds one open node net, so the stack can hold up to `budget` rows before the search ends — but never ask for more than
+        # a quarter of the free HBM (17 GB of int32 rows at the defaults; a smaller or shared GPU gets a smaller stack, and a stack
+        # that does fill up is reported as c5_error, not as a lost headline line)
+        rec = (4 if cells else 8) * n + 4
+        free_b = torch.cuda.mem_get_info(dev)[0]
+        capacity = int(min(max(32 * batch, budget + 4 * batch), max(8 * batch, free_b // 4 // rec)))
+        ds = DeviceSearch(ctx, batch=batch, capacity=capacity, implicit=True, cells=cells)
         D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=min(budget, 8 * batch * world), rounds_per_exchange=args.rounds_per_exchange, base=1)
         info = {}
         (nodes, sols, fails, steps, moved), dt = timed(lambda: D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=budget,
@@ -313,9 +319,11 @@ def c5_legs(args, torch, dist, world, rank, dev, n):
         del ds
         torch.cuda.empty_cache()
     if len(totals) == 2:
-        if totals["i32"] != totals["cells"]:
-            raise RuntimeError(f"PARITY FAILURE (c5 worklist): packed cells {totals['cells']} != int32 rows {totals['i32']} (nodes, solutions, failures)")
-        out["c5_same_tree"] = 1
+        # (reported, not raised: the headline record is complete by now and must not be lost to a side leg — ADVICE r5; 0 is a parity failure)
+        out["c5_same_tree"] = int(totals["i32"] == totals["cells"])
+        if not out["c5_same_tree"]:
+            out["c5_error"] = f"PARITY FAILURE (c5 worklist): packed cells {totals['cells']} != int32 rows {totals['i32']} (nodes, solutions, failures)"
+            print(out["c5_error"], file=sys.stderr, flush=True)
     trees = args.trees if args.trees else 4096
     spl = args.steps_per_launch if args.steps_per_launch else 1024
     forest_search(ctx, lb0, ub0, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world, dist=dist)
@@ -499,7 +507,9 @@ def main():
     ap.add_argument("--search-batch", type=int, default=16384, help="worklist engine: open nodes per round and GPU (4096: 2.0e7 nodes/s on one MI355X, 16384: 3.4e7, 65536: 5.1e7 — a round is two launches and one 20-byte read-back)")
     ap.add_argument("--rounds-per-exchange", type=int, default=4)
     ap.add_argument("--c5-timeout", type=float, default=240.0, help="seconds after which the config-5 legs are given up and the headline line is printed without them")
-    ap.add_argument("--c5-single", action="store_true", help="run the config-5 legs of --gpus N > 1 on one GPU too (one-rank process group)")
+    ap.add_argument("--c5-single", action="store_true", help="(default since round 6; kept so that old command lines still parse) run the config-5 legs on one GPU too")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 legs (worklist engine through RCCL, interval forest with cross-rank refill); by default they run "
+                                                         "behind the headline at every --gpus N, on one GPU through a one-rank RCCL group")
     ap.add_argument("--c5-budget", type=int, default=2097152,
                     help="--gpus N > 1: nodes of the short config-5 leg appended to the headline run (worklist engine; the forest leg runs 8x as many); 0 = skip")
     ap.add_argument("--cells", action="store_true", help="--mode search --engine worklist: keep the open nodes as rows of packed cells (cell_format PCP_CELLS_PACKED16)")
@@ -779,12 +789,12 @@ def main():
     # collective hangs (this path cannot be run on more than one GPU where it was written), rank 0 still prints the headline line, with
     # `c5_error` in place of the c5 keys, and every rank leaves.
     c5 = {}
-    if args.c5_budget > 0 and (world > 1 or args.c5_single):
+    if args.c5_budget > 0 and not args.no_c5 and (world > 1 or args.c5_single or args.legs == "auto"):
         import threading
 
         def finish(extra):
             if rank == 0:
-                out["config"] = {**flat, **extra, **out["config"]}
+                out["config"] = {**front_keys({**flat, **extra}), **out["config"]}
                 emit_json(out)
             _flush_c_stdio()
             os._exit(0)
@@ -807,7 +817,7 @@ def main():
         dog.cancel()
     if rank == 0:
         flat.update(c5)
-        out["config"] = {**flat, **out["config"]}
+        out["config"] = {**front_keys(flat), **out["config"]}
         if legs:
             full = json.dumps({"legs": legs})
             print(full, file=sys.stderr, flush=True)
@@ -822,6 +832,17 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     _flush_c_stdio()
+
+
+# The flat keys in the order of what a reader of the ONE line needs first — the driver's parser keeps only the first two dozen keys of `config`
+# (BENCH_r05.json: everything behind `forest_nps` was cut): config 5's worklist engine (VERDICT r5 #1c), the search-node and wide-batch legs, then
+# one figure per BASELINE configuration, then the rest.
+FRONT_KEYS = ("c5_nps", "c5_i32_nps", "c5_same_tree", "c5_xchg_share", "c5f_nps", "c5_error", "mix_ms", "mixh_ms", "w8_frac", "w8_ms", "pk_ms", "pk_frac",
+              "c3_ms", "d500_ms", "d3000_ms", "c4_ms", "f4_ms", "set_ms", "set_frac", "expl_ms", "expl_frac", "forest_nps", "setforest_nps", "forest8k_nps")
+
+
+def front_keys(flat):
+    return {**{k: flat[k] for k in FRONT_KEYS if k in flat}, **{k: v for k, v in flat.items() if k not in FRONT_KEYS}}
 
 
 def side_legs(ctx, torch, dev, n, props, args, want, L, U):

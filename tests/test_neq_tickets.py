@@ -61,3 +61,58 @@ def test_tickets_do_not_show_in_the_result(ctx, batch, static, tile):
     finally:
         for k, v in {"nodes_per_block": 0, "neq_dynamic": 2, "small_path": 1}.items():
             ctx.set_option(k, v)
+
+
+def test_tickets_on_16_node_tiles_at_n1000():
+    """The shape the tickets were built for: 16-node tiles of N-queens-1000, 512 persistent workgroups, two static tiles each
+    and the rest drawn — 32 768 frontier nodes = 2048 tiles, 1024 of them dealt by ticket, 128 per residue of blockIdx.x & 7.  64 nodes against
+    the oracle: from static tiles and from ticketed tiles of EVERY residue (so a residue that is never drawn, or drawn twice, shows), the rest of
+    the batch against the same launch with the fixed stride (neq_dynamic 0), and a second launch on the same context (the words came back to zero)."""
+    import torch
+    from pcp_amd import model as M
+    from pcp_amd import workloads as W
+    n = 1000
+    c = E.Context(0)
+    try:
+        props = M.nqueens_props(n)
+        c.set_model(n, props)
+        c.set_hull(1, n)
+        nodes = 32768
+        L, U, _ = W.nqueens_frontier(c, n, nodes, share=0, shares=8, implicit=True)
+        L, U = np.ascontiguousarray(L[:nodes]), np.ascontiguousarray(U[:nodes])
+        dev = torch.device("cuda", 0)
+
+        def launch(dynamic):
+            c.set_option("neq_dynamic", dynamic)
+            lb, ub = torch.from_numpy(L).to(dev), torch.from_numpy(U).to(dev)
+            st = torch.full((nodes,), 255, dtype=torch.uint8, device=dev)
+            c.propagate_device(nodes, lb, ub, lb, ub, None, None, st)
+            pl = c.last_plan()
+            torch.cuda.synchronize()
+            return lb.cpu().numpy(), ub.cpu().numpy(), st.cpu().numpy(), pl
+
+        c.stats_reset()
+        l2, u2, s2, pl = launch(2)
+        assert pl["path"] == 1 and pl["nodes_per_block"] == 16 and pl["packed"] == 1, pl
+        tiles, grid = nodes // 16, pl["grid"]
+        assert tiles >= 3 * grid, pl  # persistent, >= 3 tiles per workgroup (MI355X: grid 512, four each): the third and later ones are drawn
+        assert c.stats_read()["nodes"] == nodes  # every tile ran exactly once (a tile drawn twice would count its nodes twice)
+        l0, u0, s0, _ = launch(0)
+        assert np.array_equal(s2, s0) and np.array_equal(l2, l0) and np.array_equal(u2, u0)
+        assert (s2 != 255).all()
+        l2b, u2b, s2b, _ = launch(2)  # the tickets were left zero
+        assert np.array_equal(s2b, s0) and np.array_equal(l2b, l0) and np.array_equal(u2b, u0)
+        # 64 nodes against the oracle: 16 from static tiles, 6 from ticketed tiles of each residue (tile = 2 grid + 8 ticket + residue)
+        rng = np.random.default_rng(11)
+        pick = list(rng.integers(0, 2 * grid * 16, size=16))
+        for r in range(8):
+            cand = np.arange(2 * grid + r, tiles, 8)
+            for t in rng.choice(cand, size=6, replace=False):
+                pick.append(int(t) * 16 + int(rng.integers(0, 16)))
+        pick = np.array(pick[:64])
+        om = orc.OracleModel(n, props)
+        ref = om.consistency(L[pick], U[pick], None, check_dup=False)
+        assert_parity((ref[0], ref[1], None, ref[3]), (l2[pick], u2[pick], None, s2[pick]), "ticketed 16-node tiles at n = 1000")
+    finally:
+        c.set_option("neq_dynamic", 2)
+        c.close()
