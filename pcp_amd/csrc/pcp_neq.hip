@@ -53,6 +53,11 @@
 #ifndef PCP_PUT_FAST
 #define PCP_PUT_FAST 1
 #endif
+// cache policy of a full tile's row loads (raw_buffer_load aux: 1 = sc0, 2 = nt, 16 = sc1): the rows are read once — streaming them past the
+// L1 leaves it to the list payloads every tile reads again
+#ifndef PCP_STAGE_AUX
+#define PCP_STAGE_AUX 0
+#endif
 // A/B switches of two round-5 experiments (tools/build_neq_variant.py): the constant compared by exclusive-or instead of a second packed
 // add, and pieces shorter than 256 entries when a round walks few lists.
 #ifndef PCP_NEQ_XOR
@@ -73,7 +78,9 @@ enum { N_FAIL = 0, N_OOB = 1, N_COUNT0 = 2, N_COUNT1 = 3, N_RMASK0 = 4, N_RMASK1
        N_EV = 10, N_FULL = 12, N_STEPS = 14, N_WIN0 = 16, N_WIN1 = 17, N_MORE = 18, N_WORDS = 19,
        N_NID = 19 /* .. 34: the global node index of the tile's node b */,
        N_R0OVF = 38 /* round 0's direct list overflowed: the marks are scanned instead */,
-       N_HINT = 35 /* bit b: node b came with a dirty-variable hint (pcp_device_batch.dirty_var): round 0 walks that variable's lists only */ };
+       N_HINT = 35 /* bit b: node b came with a dirty-variable hint (pcp_device_batch.dirty_var): round 0 walks that variable's lists only */,
+       N_VOTE = 39 /* .. 41: the votes of the lean round 0's passes, word (pass mod 3): 1 = a lane narrowed something, 2 = it assigned or emptied a variable,
+                      4 = it left a flagged entry untested */ };
 constexpr uint32_t kMaxRounds = 1u << 22;  // a round that runs narrows something, so a fixpoint has far fewer; the cap only makes a runaway impossible
 constexpr uint32_t kCascadeThreads = 8;  // threads that narrowed something in a round before the next round's cover is priced at all
 constexpr uint32_t kResweepMin = 32;  // marked variables of a node before the assigned-lists alternative is priced
@@ -83,6 +90,8 @@ constexpr uint32_t kNextTileWord = 2 * 48 + 14;  // word of the status area (beh
 constexpr uint32_t kListCap = 256;   // entries of a round's list; more changed variables than that wait for the next round
 constexpr uint32_t kWinCap = 1024;   // jump windows per round (fewer when LDS is short: NeqCarve::wcap)
 constexpr uint32_t kNoWin = 0xFFFFu;
+constexpr uint32_t kFastLists = 4;   // assigned variables of a full tile up to which round 0 takes the lean form (neq_fast_walk)
+constexpr uint32_t kFastPer = 6;     // list entries per lane of that form (512 threads: lists of up to 3072 entries)
 
 // A jump window: the values of variable v (node b) that assigned neighbours forbid, as bits above lb0 / below ub0.
 struct __attribute__((aligned(16))) Win {
@@ -290,6 +299,33 @@ struct TileDom32 {
     }
   }
 };
+// TileDom16 for the lean round 0 (neq_fast_walk): a narrowing wakes its variable — marks it, raises *woke — only when it assigned or emptied it.
+// (Why the others need no wake-up: see neq_fast_walk.)
+struct TileDom16Q : TileDom16 {
+  bool* woke;
+  __device__ __forceinline__ void raise_lb(uint32_t v, int nlb) const {
+    uint32_t* p = cell(v);
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nlb <= d.x) return;
+      const uint32_t prev = atomicCAS(p, old, pack16(min(nlb, d.y + 1), d.y));
+      if (prev == old) { ++c->narrow; const bool wake = nlb >= d.y; touch(v, wake); *woke |= wake; if (nlb > d.y) set_fail(); return; }
+      old = prev;
+    }
+  }
+  __device__ __forceinline__ void lower_ub(uint32_t v, int nub) const {
+    uint32_t* p = cell(v);
+    uint32_t old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const int2 d = unpack16(old);
+      if (nub >= d.y) return;
+      const uint32_t prev = atomicCAS(p, old, pack16(d.x, max(nub, d.x - 1)));
+      if (prev == old) { ++c->narrow; const bool wake = nub <= d.x; touch(v, wake); *woke |= wake; if (nub < d.x) set_fail(); return; }
+      old = prev;
+    }
+  }
+};
 template <bool PACKED> struct TileDomOf { using type = TileDom32; };
 template <> struct TileDomOf<true> { using type = TileDom16; };
 
@@ -351,8 +387,8 @@ struct NeqTile {
 // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
 // chains one after the other in every wavefront.  Sets bit b of misc[N_UNK] for a node with an open record.
 template <bool PACKED, bool DFS, class Tile, class Pay>
-__device__ __forceinline__ void neq_status_scan(const Tile& tl, const Pay* pay, bool skip) {
-const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB];
+__device__ __forceinline__ void neq_status_scan(const Tile& tl, const Pay* pay, bool skip, const uint32_t only = 0xFFFFFFFFu) {
+const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB] | ~only;  // (`only`: the nodes to scan — the others keep the bit they have)
   for (uint32_t b0 = tl.wv; b0 < tl.nb; b0 += 2 * tl.nwv) {
     // (a wavefront with one node left gives it all 64 lanes: the search loop's single node, the odd node of a ragged tile)
     const bool pair = !DFS && b0 + tl.nwv < tl.nb;                            // wave-uniform (the search loop has one node: folded away)
@@ -393,6 +429,50 @@ const uint32_t inert = tl.misc[N_FAIL] | tl.misc[N_OOB];
     }
     if (open && hl == 0) atomicOr(&tl.misc[N_UNK], 1u << b);
   }
+}
+
+// The usual outcome of the status scan, split in two so that its one memory round trip is in flight while the tile's list walk runs (the lean
+// round 0, neq_fast_walk).  Full tiles on eight wavefronts only: node wv in a wavefront's lanes 0-31, node wv + 8 in its lanes 32-63.
+// issue: the node's first unassigned variable u among its first 32, u's cell and the first 32 entries of u's list (one load per lane);
+// finish: is one of those records open — not entailed: the intervals meet (x_neq_y.rs:71-73 via x_eq_y.rs:87-93)?  Then the node is Unknown
+// (store.rs:250-256) and its bit of misc[N_UNK] is set.  Anything else — no unassigned variable among the first 32, no open record among the
+// first 32 — is left to the full scan (neq_status_scan), which finish() asks for by returning true (wave-uniform).
+struct StatusPre { uint32_t q; int lbu, ubu; uint32_t flags; };  // flags: 1 = q holds an entry, 4 = the node is inert (failed or refused); bits 8..: the variable u
+template <class Tile>
+__device__ __forceinline__ StatusPre neq_status_issue(const Tile& tl, const uint32_t* __restrict__ pay) {
+  const uint32_t hb = tl.lane >> 5, hl = tl.lane & 31u, b = tl.wv + hb * tl.nwv;
+  const bool live = !(((tl.misc[N_FAIL] | tl.misc[N_OOB]) >> b) & 1u);
+  StatusPre r{0u, 0, 0, live ? 0u : 4u};
+  bool wide = false;
+  if (live && hl < tl.V) { const int2 d = unpack16(tl.dom[tl.rowof(hl) + b]); wide = d.x < d.y; }
+  const uint32_t cand = (uint32_t)(__ballot(wide) >> (32u * hb));
+  if (cand) {
+    const uint32_t u = (uint32_t)__builtin_ctz(cand);
+    const int2 Ud = unpack16(tl.dom[tl.rowof(u) + b]);
+    const uint32_t o0 = tl.adjo[u], deg = tl.adjo[u + 1] - o0;
+    r.lbu = Ud.x; r.ubu = Ud.y;
+    r.flags |= u << 8;
+    if (hl < deg) { r.q = pay[o0 + hl]; r.flags |= 1u; }
+  }
+  return r;
+}
+template <class Tile>
+// `refresh`: u's cell is read again (a later pass of the lean round 0: the node narrowed since issue(); u is still its first unassigned variable —
+// those passes assign nothing — and the entries are u's, whatever its bounds).
+__device__ __forceinline__ bool neq_status_finish(const Tile& tl, const StatusPre& r, const uint32_t only = 0xFFFFFFFFu, const bool refresh = false) {
+  const uint32_t hb = tl.lane >> 5, b = tl.wv + hb * tl.nwv;
+  if (!__ballot((only >> b) & 1u)) return false;  // (none of this wavefront's two nodes is asked for)
+  bool op = false;
+  if (r.flags & 1u) {
+    int lbu = r.lbu, ubu = r.ubu;
+    if (refresh) { const int2 Ud = unpack16(tl.dom[tl.rowof(r.flags >> 8) + b]); lbu = Ud.x; ubu = Ud.y; }
+    const int t = pay_t(r.q);
+    const int2 O = unpack16(tl.dom[tl.rowof(pay_other(r.q)) + b]);
+    op = !((lbu + t > O.y) || (ubu + t < O.x));  // not disjoint
+  }
+  const bool open = (uint32_t)(__ballot(op) >> (32u * hb)) != 0u, mine = ((only >> b) & 1u) != 0u;
+  if (open && mine && (tl.lane & 31u) == 0u) atomicOr(&tl.misc[N_UNK], 1u << b);
+  return __ballot(mine && !(r.flags & 4u) && !open) != 0ull;
 }
 
 // ---- write back: the rows of the nodes that changed (every node when the call is not in place).  A refused node's outputs are left
@@ -840,6 +920,124 @@ __device__ __forceinline__ uint32_t neq_walk_lists(const Tile& tl, const NeqArgs
   return my_ev;
 }
 
+// ---- round 0 of a FRONTIER tile, lean (round 6).  A full tile of sixteen nodes in 16-bit cells whose nodes have at most kFastLists assigned
+// variables between them — the tiles of a breadth-first frontier, the headline batch — used to go through the general round: complete the list's
+// entries, barrier, pieces of 4 x 64 entries dealt to the wavefronts (twelve pieces on eight wavefronts: two rounds of pieces, the second half
+// empty), barrier with a vote, status scan, barrier: 19 000 of a tile's 31 000 ticks (tools/neq_trace.py), most of them waiting.  Here every
+// wavefront reads the (few) list heads by itself — no barrier —, a list's entries are dealt EVENLY, entry j * threads + tid to thread tid (2997
+// entries on 512 threads: six loads per lane, all in flight at once), every entry is tested against all sixteen nodes (nodes outside the variable's
+// mask ride along: they can only raise a flag that the full filter, which walks the mask, ignores), and the status scan runs BEFORE the round's one
+// barrier, so that its memory round trip overlaps the other wavefronts' walks.
+// A flagged entry runs the full filter (eval_record: XNeqY::propagate, x_neq_y.rs:82-93) on a QUIET store (TileDom16Q): the narrowed variable is not
+// woken unless it was assigned or emptied.  Instead, when a pass narrowed something and woke nothing, the SAME lists are walked again, until a pass
+// narrows nothing.  Same fixpoint: a propagator x != y + c acts only when one side is assigned, so every propagator that can act on a narrowed,
+// still unassigned variable sits in the list of an assigned variable — and the lists walked here are those of ALL assigned variables of every node
+// of the tile (staging listed them: vmk), none of which changed.  (The general rounds make the same choice when it is cheaper: resweep_marks.)
+// A pass that assigned or emptied a variable hands the tile to the general rounds (the new variable's own list must run).
+// The payload of the tile's FIRST list is requested once per tile and kept in registers (neq_fast_load): a later pass — and there is one only in
+// the few tiles that narrow anything — tests the same entries again without another memory round trip (in the launch's first generation of tiles,
+// when every CU of the chip is streaming rows, a round trip was 3-5 thousand ticks, and a tile that narrowed paid four of them in a row).  Further
+// lists (a frontier tile has one, seldom two) are loaded where they are tested.
+template <class Tile>
+__device__ __forceinline__ void neq_fast_load(const Tile& tl, const uint32_t* __restrict__ pay, const uint32_t e, uint32_t (&q)[kFastPer]) {
+  const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane(tl.list[e].x) & 0xffffu;
+  const uint32_t o0 = (uint32_t)__builtin_amdgcn_readfirstlane(tl.adjo[v]), dg = (uint32_t)__builtin_amdgcn_readfirstlane(tl.adjo[v + 1]) - o0;
+  // (all kFastPer loads, unconditionally — a shorter list reads its last entry again, masked off by the test —: a conditional load into a register
+  // array makes the compiler thread the whole array through memory)
+  const uint32_t last = o0 + (dg ? dg - 1u : 0u);
+#pragma unroll
+  for (uint32_t j = 0; j < kFastPer; ++j) q[j] = pay[min(o0 + j * tl.nth + tl.tid, last)];
+}
+// One pass over the tile's lists for the nodes `only`; q0 = list 0's payload (neq_fast_load).  Returns: this lane narrowed something; `more`: it left
+// a flagged entry untested.
+template <class Tile>
+__device__ __forceinline__ bool neq_fast_test(const Tile& tl, const uint32_t* __restrict__ pay, const uint32_t* vmk, const uint32_t cnt, const uint32_t only,
+                                               const uint32_t (&q0)[kFastPer], Ctr& ctr, uint32_t& my_ev, bool& woke, bool& more) {
+  const uint32_t narrow0 = ctr.narrow;
+  auto* const dom = tl.dom;
+  auto one_list = [&](const uint32_t v, const uint32_t M, const uint32_t dg, const uint32_t (&q)[kFastPer]) {
+    const uint32_t qm = ((M & 0xFu) ? 1u : 0u) | ((M & 0xF0u) ? 2u : 0u) | ((M & 0xF00u) ? 4u : 0u) | ((M & 0xF000u) ? 8u : 0u);  // quads of nodes with a node of the mask
+    const uint32_t per = (dg + tl.nth - 1u) / tl.nth;
+    const uint32_t rv = tl.rowof(v);
+    uint4 c[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c[g] = *reinterpret_cast<const uint4*>(dom + rv + 4 * g);  // the walked variable's cells in the sixteen nodes
+    const bool all4 = qm == 15u;  // (uniform) the first pass of a frontier tile: every quad; a later pass: the quads of the nodes that narrowed
+    const uint32_t nm = (uint32_t)__popc(M);
+    // a lane's flagged entry (one is kept; a second one in the same lane and list — entries 512 apart both at a bound — sets `more`: the caller
+    // runs another pass over every node, which finds it)
+    bool have = false;
+    uint32_t hq = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kFastPer; ++j) {
+      if (j >= per) break;  // (uniform)
+      const bool valid = j * tl.nth + tl.tid < dg;
+      const uint32_t ro = tl.rowof(pay_other(q[j])), K = pack_mt(pay_t(q[j]));
+      uint32_t acc = 0xffffffffu;
+      if (all4) {
+        uint4 o[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[g] = *reinterpret_cast<const uint4*>(dom + ro + 4 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc = pk_min_u16(acc, pk_min_u16(pk_min_u16(neq_terms16(c[g].x, o[g].x, K), neq_terms16(c[g].y, o[g].y, K)),
+                                           pk_min_u16(neq_terms16(c[g].z, o[g].z, K), neq_terms16(c[g].w, o[g].w, K))));
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (!((qm >> g) & 1u)) continue;  // (uniform)
+          const uint4 og = *reinterpret_cast<const uint4*>(dom + ro + 4 * g);
+          acc = pk_min_u16(acc, pk_min_u16(pk_min_u16(neq_terms16(c[g].x, og.x, K), neq_terms16(c[g].y, og.y, K)),
+                                           pk_min_u16(neq_terms16(c[g].z, og.z, K), neq_terms16(c[g].w, og.w, K))));
+        }
+      }
+      const bool hit = valid && zero_half(acc);
+      more |= hit && have;
+      hq = (hit && !have) ? q[j] : hq;
+      have |= hit;
+      my_ev += valid ? nm : 0u;
+    }
+    if (have) {  // the flagged entry: the full filter, in the nodes of the mask whose domains meet the condition
+      const uint32_t other = pay_other(hq);
+      const int t = pay_t(hq);
+      const bool is_y = pay_is_y(hq);
+      Rec rec;
+      rec.xk = (is_y ? other : v) | ((uint32_t)PCP_NEQ << 28);
+      rec.y = is_y ? v : other;
+      rec.z = 0;
+      rec.d = is_y ? t : -t;
+      const uint32_t ro = tl.rowof(other);
+      for (uint32_t m = M; m; m &= m - 1u) {
+        const uint32_t b = (uint32_t)__builtin_ctz(m);
+        const int2 Vd = unpack16(dom[rv + b]), O = unpack16(dom[ro + b]);
+        if (Vd.x + t != O.y && Vd.y + t != O.x) continue;
+        ++ctr.full;
+        const TileDom16 base = tl.dom_of(b, &ctr);
+        TileDom16Q dq;
+        static_cast<TileDom16&>(dq) = base;
+        dq.woke = &woke;
+        eval_record(rec, dq);
+      }
+    }
+  };
+  auto head = [&](const uint32_t e, uint32_t& v, uint32_t& M, uint32_t& dg) {
+    v = (uint32_t)__builtin_amdgcn_readfirstlane(tl.list[e].x) & 0xffffu;
+    M = ((uint32_t)__builtin_amdgcn_readfirstlane(vmk[v >> 1]) >> (16u * (v & 1u))) & 0xffffu & only;  // (`only`: the nodes this pass is about)
+    dg = (uint32_t)__builtin_amdgcn_readfirstlane(tl.adjo[v + 1]) - (uint32_t)__builtin_amdgcn_readfirstlane(tl.adjo[v]);
+  };
+  uint32_t q[kFastPer];
+#pragma unroll
+  for (uint32_t j = 0; j < kFastPer; ++j) q[j] = q0[j];
+  for (uint32_t e = 0; e < cnt; ++e) {
+    uint32_t v, M, dg;
+    head(e, v, M, dg);
+    if (!M || !dg) continue;
+    if (e) neq_fast_load(tl, pay, e, q);
+    one_list(v, M, dg, q);
+  }
+  return ctr.narrow != narrow0;
+}
+
 // ---- (a) of a round: one list for the tile, (variable, mask of the nodes in which it changed).  The marks of the listed variables are
 // consumed here (the narrowings of this round set them again behind the barrier); variables beyond the list's capacity keep their
 // marks and are listed by the next round.
@@ -959,11 +1157,12 @@ struct StageTile16Args {
   uint32_t r0_direct;           // round 0's list is built here (vmk masks, up to kR0Cap variables)
   uint32_t wv, nwv;
 };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kStage16UF = 8;
 template <bool CELLS>
 __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  constexpr int UF = 8;
+  constexpr int UF = kStage16UF;
   constexpr int lim = kPackedMax;
   const uint32_t lane = threadIdx.x & 63u, lb4 = lane >> 4, lq = lane & 15u;
   const uint32_t V = g.V, SQ = V >> 2, QC = (SQ + 15u) >> 4, WT = 4u * QC;
@@ -987,8 +1186,8 @@ __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
       ngj[j] = ng; qcj[j] = qc;
       if (w0 + j * g.nwv < WT) {  // (uniform)
         const uint32_t so = ng * (16u * V) + qc * 256u, vo = qc == QC - 1u ? vo_last : vo_full;
-        L[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)vo, (int)so, 0);
-        if constexpr (!CELLS) U[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)vo, (int)so, 0);
+        L[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_lb, (int)vo, (int)so, PCP_STAGE_AUX);
+        if constexpr (!CELLS) U[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_ub, (int)vo, (int)so, PCP_STAGE_AUX);
       }
       qc += dqc; ng += dng;
       if (qc >= QC) { qc -= QC; ++ng; }
@@ -1367,8 +1566,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   const uint32_t V = a.m.n_vars, S = a.m.n_slots, Wv = (S + 31) >> 5, B = BT ? (uint32_t)BT : a.nodes_per_block;
   auto bar = [&]() { __syncthreads(); };
   const NeqCarve cv = neq_carve(S, V, B, PACKED, a.lds_wgs);
-  const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 64u;  // profiling: per-wavefront event stamps in the last 2 KB of the window area
-  const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 64u : cv.wcap;
+  // profiling: per-wavefront event stamps behind the windows (16 stamps of 8 bytes per wavefront = four windows' worth each: with 512 threads the
+  // masks of round 0's direct list — they borrow the window area — still fit in front of them, so the traced launch runs what the product runs)
+  const bool tr_on = PCP_NEQ_PROFILE && !DFS && a.trace != nullptr && cv.wcap >= 4u * nwv;
+  const uint32_t sh = BT >= 16 ? 2u : BT == 1 ? 6u : cv.sh, wcap = tr_on ? cv.wcap - 4u * nwv : cv.wcap;
   unsigned long long* const trbuf = reinterpret_cast<unsigned long long*>(smem + cv.win + (size_t)wcap * sizeof(Win));
   PCP_TR(0);
   auto rowof = [&](uint32_t slot) { return neq_row(slot, B, sh); };  // index of node 0's cell of a slot
@@ -1398,9 +1599,12 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   uint64_t pt0 = ptime ? __builtin_amdgcn_s_memtime() : 0;
   uint64_t rt0 = ptime ? __builtin_amdgcn_s_memrealtime() : 0;  // (100 MHz: the launch's timeline across workgroups)
   uint64_t pt1 = 0, pt2 = 0, pt3 = 0, pta = 0, ptb = 0, ptc = 0;
-  // (loaded behind the first tile's zeroing barrier, together with its row loads — hipcc drains outstanding loads at a barrier)
-  uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
-  bool adj_loaded = false, adj_stored = false;
+  // (requested here, at the kernel's entry, and stored behind the first tile's zeroing barrier: the round trip runs while the workgroup pays its
+  // cold start.  Held in registers across the first tile's staging instead — one round trip for both — they cost the kernel a spilled register.)
+  uint32_t adj_pre[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) adj_pre[j] = a.m.adj_off[min(tid + j * nth, V)];
+  bool adj_stored = false;
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   NeqDfsRegs dfs{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0ull, 0ull, 0ull, 0u};
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
@@ -1450,7 +1654,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
     dfs.hint = (!resume && a.dfs.dirty) ? __hip_atomic_load(a.dfs.dirty + (dfs.sp - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
   }
   if (tid < (uint32_t)N_WORDS) misc[tid] = 0;
-  if (tid == (uint32_t)N_R0OVF) misc[tid] = 0;
+  if (tid == (uint32_t)N_R0OVF || (tid >= (uint32_t)N_VOTE && tid < (uint32_t)N_VOTE + 3u)) misc[tid] = 0;
   // Round 0's list — the assigned variables of the tile's nodes, each with the mask of the nodes it is assigned in — is built BY the staging
   // loop where it finds a singleton (rare branch of put): the mask in vmk, the first node to see a variable appends it.  The ballot scan over
   // the marks that used to build it was 3 000 of a frontier tile's 32 000 cycles, for one listed variable.
@@ -1473,10 +1677,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
   bar();
   PCP_TR(1);
-  if (!adj_loaded) {
-    adj_loaded = true;
+  if (!adj_stored) {
+    adj_stored = true;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; adj_pre[j] = a.m.adj_off[min(v, V)]; }
+    for (int j = 0; j < 4; ++j) { const uint32_t v = tid + j * nth; if (v <= V) adjo[v] = adj_pre[j]; }
     for (uint32_t v = tid + 4 * nth; v <= V; v += nth) adjo[v] = a.m.adj_off[v];
   }
   // DFS rows may have been written by this very workgroup a moment ago: they are read past the L1 (relaxed agent-scope loads)
@@ -1516,7 +1720,77 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   const uint32_t U4 = 4;
   const bool one_piece = a.m.max_deg <= 64u * U4;
   bool cascade = false;  // the round before narrowed in many threads at once (workgroup-uniform)
-  for (uint32_t round = 0;; ++round) {
+  // ---- round 0 of a frontier tile, lean (neq_fast_walk): a full tile whose nodes have few assigned variables between them -------------------
+  uint32_t fstate = 0;  // (workgroup-uniform) 0 / 1: the general rounds from round 0 / 1;  2: the rounds are done, the statuses are not;  3: both are
+  if constexpr (!DFS && BT == 16 && PACKED && PAY4) {
+    if (r0_direct && nb == 16u && a.seed_always == nullptr && !(a.debug & (131072u | 1u | 4u)) && a.m.max_deg <= kFastPer * nth) {
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_COUNT0]);
+      if (cnt <= kFastLists && (uint32_t)__builtin_amdgcn_readfirstlane(misc[N_R0OVF]) == 0u) {
+        const NeqTile<PACKED> tf{dom, chg, misc, adjo, list, win, V, Wv, B, sh, nb, tid, lane, wv, nwv, nth};
+        PCP_TR(4); PCP_TR(5); PCP_TR(6);
+        bool woke = false;
+        uint32_t my_ev = 0;
+        // the lists' payload first (one memory round trip, kept in registers for every pass); behind it the status scan's own round trip — the
+        // statuses are taken BEFORE the round's one barrier: valid iff the tile narrowed nothing at all (else the nodes that narrowed are
+        // scanned again below, on their final domains)
+        const bool no_status = (a.debug & 2u) != 0;
+        uint32_t q0[kFastPer] = {0u, 0u, 0u, 0u, 0u, 0u};
+        static_assert(kFastPer == 6, "q0's initialiser");
+        if (cnt) neq_fast_load(tf, pay, 0u, q0);
+        StatusPre sp{0u, 0, 0, 4u};
+        if (!no_status) sp = neq_status_issue(tf, pay);
+        // pass 0: every node; a later pass — there is one only when something narrowed, in a handful of tiles per frontier launch — tests the same
+        // lists again for the nodes that narrowed, until a pass narrows nothing; a pass that assigned or emptied a variable hands the tile to the
+        // general rounds (the variable's own list must run)
+        uint32_t only = 0xffffu & ~(misc[N_FAIL] | misc[N_OOB]);
+        for (uint32_t pass = 0;; ++pass) {
+          woke = false; my_ev = 0;
+          bool more = false;
+          const bool nar = neq_fast_test(tf, pay, vmk, cnt, only, q0, ctr, my_ev, woke, more);
+          ctr.ev += my_ev;
+          if (pass == 0) {
+            ev0 += my_ev;
+            PCP_TR(7);
+            if (!no_status && neq_status_finish(tf, sp)) neq_status_scan<PACKED, DFS>(tf, pay, false);
+            if constexpr (TICKETS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
+            PCP_TR(10);
+          }
+          // the pass's vote: one word, one barrier that waits for LDS only (__syncthreads_count is a reduction through LDS and two barriers)
+          const uint32_t vw = (uint32_t)N_VOTE + pass % 3u;
+          const uint32_t bits = (nar ? 1u : 0u) | (woke ? 2u : 0u) | (more ? 4u : 0u);
+          if (bits) atomicOr(&misc[vw], bits);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane(misc[vw]);
+          if (pass == 0) { PCP_TR(8); PCP_TR(9); PCP_TR(11); }
+          if (vote == 0u) {
+            if (pass == 0) { fstate = 3; break; }
+            // quiet again: the nodes that moved get their statuses from their final domains — from the entries requested for them before
+            // pass 0 where those still decide, else from the full scan
+            const uint32_t moved = misc[N_DIRTY];
+            if (tid == 0) atomicAnd(&misc[N_UNK], ~moved);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!no_status && neq_status_finish(tf, sp, moved, true)) neq_status_scan<PACKED, DFS>(tf, pay, false, moved);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            fstate = 3;
+            break;
+          }
+          if (tid == 0) misc[(uint32_t)N_VOTE + (pass + 2u) % 3u] = 0;  // (the word of the pass after next: last read before the barrier above)
+          if ((vote & 2u) || pass >= 64u) {
+            // the general rounds, from round 1: the marks of the narrowings are set; staging's marks of the assigned variables are still set
+            // too (their lists run once more: correct, and this is a tile in a thousand)
+            fstate = 1;
+            if (tid == 0) misc[N_UNK] = 0;
+            bar();
+            break;
+          }
+          // (only the nodes that narrowed can have anything left to do — unless a lane left a flagged entry untested: then every node again)
+          only = ((vote & 4u) ? 0xffffu : misc[N_DIRTY]) & ~(misc[N_FAIL] | misc[N_OOB]);
+        }
+      }
+    }
+  }
+  if (fstate < 2u)
+  for (uint32_t round = fstate;; ++round) {
     if (round >= kMaxRounds) { if (tid == 0) { atomicOr(&misc[N_OOB], nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u)); atomicMax(a.violation, 1u); } bar(); break; }  // (refused, not hung)
     const uint32_t m_count = (round & 1u) ? N_COUNT1 : N_COUNT0, m_rmask = (round & 1u) ? N_RMASK1 : N_RMASK0, m_win = (round & 1u) ? N_WIN1 : N_WIN0;
     const uint32_t inert = misc[N_FAIL] | misc[N_OOB];
@@ -1588,14 +1862,18 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   // Two nodes per wavefront at a time, one per 32-lane half: a node's scan is a chain of dependent LDS and memory reads (cells -> the
   // list's offsets -> its payload -> the other sides' cells), and a tile of sixteen nodes on eight wavefronts used to run two such
   // chains one after the other in every wavefront.
-  neq_status_scan<PACKED, DFS>(tl, pay, (a.debug & 2u) != 0);
-  if constexpr (!DFS && TICKETS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
+  if (fstate != 3u) {
+    neq_status_scan<PACKED, DFS>(tl, pay, (a.debug & 2u) != 0);
+    if constexpr (!DFS && TICKETS) { if (tid == nth - 64u && draws()) misc_base[kNextTileWord] = neq_karg<uint32_t>(offsetof(NeqArgs, tile_static)) * gridDim.x + 8u * ticket + (blockIdx.x & 7u); }
+  }
 
   // ---- write back: the rows of the nodes that changed (every node when the call is not in place) ----------------------------
   uint32_t wb_need = 0;
-  PCP_TR(10);
-  bar();
-  PCP_TR(11);
+  if (fstate != 3u) {
+    PCP_TR(10);
+    bar();
+    PCP_TR(11);
+  }
   if (ptime) pt3 = __builtin_amdgcn_s_memtime();
   wb_need = neq_write_back<PACKED>(tl, a.lb_in, a.ub_in, a.lb_out, a.ub_out, CELLS, DFS && dfs.stale != 0u);
   if constexpr (DFS) dfs.stale = 0u;
@@ -1616,7 +1894,8 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   PCP_TR(12);
   // (the write-back may fail a node — an empty cell found on the way out —: the statuses wait for it; a tile that wrote nothing back
   // has nothing to wait for, its words are final since the barrier behind the status scan)
-  if (!DEFER || wb_need) bar();
+  // (a barrier that waits for LDS only: the rows just written need not have landed — __syncthreads would wait for the stores)
+  if (!DEFER || wb_need) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   PCP_TR(13);
   if (tid < nb) {
     const bool failed = (misc[N_FAIL] >> tid) & 1u, refused = (misc[N_OOB] >> tid) & 1u;

@@ -42,7 +42,35 @@ for rep in range(3):
     print(f"kernel {ms * 1e3:.1f} us, grid {pl['grid']} x {pl['block']} threads")
     rt = t[:, 0, 15]
     print(f"realtime (100 MHz) end stamps: first {(rt.min() - rt.min()) / 100:.1f} us ... last {(rt.max() - rt.min()) / 100:.1f} us")
-    half = tiles // 2
+    # the launch's own clock: ticks from the first entry to the last end against the HIP-event time (s_memtime is one counter for the chip)
+    span = int(t[:, :, 14].max() - t[:, :, 0][t[:, :, 0] > 0].min())
+    print(f"ticks first entry -> last end: {span}  = {span / (ms * 1e3):.0f} ticks/us of kernel time")
+    ent = (t[:, 0, 0] - t[:, :, 0][t[:, :, 0] > 0].min())
+    g_ = pl["grid"]
+    for lo, hi, what in ((0, g_, "first tiles"), (g_, tiles, "second tiles")):
+        e0, e1 = ent[lo:hi], (t[lo:hi, :, 14].max(axis=1) - t[:, :, 0][t[:, :, 0] > 0].min())
+        print(f"  {what}: entry ticks min {e0.min()} median {int(np.median(e0))} max {e0.max()};  end ticks min {e1.min()} median {int(np.median(e1))} max {e1.max()}")
+    half = g_ if g_ < tiles else tiles // 2
+    # distributions: per tile, ticks from entry to end; the 100 MHz end stamp; by generation and by XCD (workgroup index mod 8)
+    dur = t[:, :, 14].max(axis=1) - t[:, 0, 0]
+    rte = (rt - rt.min()) / 100.0
+    pct = lambda a: " ".join(f"{np.percentile(a, q):9.1f}" for q in (0, 10, 50, 90, 99, 100))
+    for lo, hi, what in ((0, g_, "first tiles"), (g_, tiles, "second tiles")):
+        if hi <= lo:
+            continue
+        print(f"  {what}: tile ticks   p0/10/50/90/99/100: {pct(dur[lo:hi])}")
+        print(f"  {what}: end stamp us p0/10/50/90/99/100: {pct(rte[lo:hi])}")
+        for x in range(8):
+            sel = np.arange(lo, hi)[(np.arange(lo, hi) % g_) % 8 == x]
+            print(f"     xcd {x}: ticks median {np.median(dur[sel]):8.0f} max {dur[sel].max():8.0f}   end us median {np.median(rte[sel]):6.1f} max {rte[sel].max():6.1f}")
+    # per phase, per generation: distribution over tiles of (released k) - (released k-1) for the barrier-delimited phases
+    for lo, hi, what in ((0, g_, "first tiles"), (g_, tiles, "second tiles")):
+        if hi <= lo:
+            continue
+        w0 = t[lo:hi, 0, :15] - t[lo:hi, 0, :1]
+        for a, b, nm in ((0, 1, "entry->zeroed"), (1, 3, "staging"), (3, 5, "list build"), (5, 8, "walk+round end"), (8, 11, "status"), (11, 14, "write-back, counters, hand-over")):
+            d = w0[:, b] - w0[:, a]
+            print(f"  {what}: {nm:32s} ticks p0/10/50/90/99/100: {pct(d)}")
     for lo, hi, what in ((0, half, "first half of the grid"), (half, tiles, "second half")):
         r = rel[lo:hi]
         print(f"-- {what}: ticks since wavefront 0 entered, mean over tiles: [wavefront 0] [earliest wavefront] [latest wavefront] (latest - earliest)")
