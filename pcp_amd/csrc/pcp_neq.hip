@@ -1599,12 +1599,17 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   uint64_t pt0 = ptime ? __builtin_amdgcn_s_memtime() : 0;
   uint64_t rt0 = ptime ? __builtin_amdgcn_s_memrealtime() : 0;  // (100 MHz: the launch's timeline across workgroups)
   uint64_t pt1 = 0, pt2 = 0, pt3 = 0, pta = 0, ptb = 0, ptc = 0;
-  // (requested here, at the kernel's entry, and stored behind the first tile's zeroing barrier: the round trip runs while the workgroup pays its
-  // cold start.  Held in registers across the first tile's staging instead — one round trip for both — they cost the kernel a spilled register.)
-  uint32_t adj_pre[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) adj_pre[j] = a.m.adj_off[min(tid + j * nth, V)];
-  bool adj_stored = false;
+  // The copy goes straight into LDS (global_load_lds: LDS-DMA, no registers, nobody waits for it until the first tile's staging barrier, whose
+  // __syncthreads drains it): requested here, at the kernel's entry, its round trip — every workgroup of the launch asks for the same 4 KB at the
+  // same moment — runs under the cold start and the first tile's row loads.  (Through registers, stored behind the first zeroing barrier, the
+  // slowest workgroups waited 6 000 ticks for it there; held across the staging instead they cost the kernel a spilled register.)
+  for (uint32_t base = 0; base <= V; base += nth) {
+    const uint32_t v = base + tid;
+    auto* const dst = (__attribute__((address_space(3))) void*)(adjo + base + 64u * wv);  // (wave-uniform: lane i's dword lands at dst + 4 i)
+    if (v <= V) __builtin_amdgcn_global_load_lds(a.m.adj_off + v, dst, 4, 0, 0);
+  }
+  uint32_t adj_pre[4] = {0u, 0u, 0u, 0u};
+  bool adj_stored = true;  // (the register path of earlier rounds: its stores are dead code now)
   // DFS: the stack pointer and the stop flag live in registers for the launch (every thread keeps the same copy)
   NeqDfsRegs dfs{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0ull, 0ull, 0ull, 0u};
   // DFS: workgroup t searches tree t — its own stack rows, stack pointer, stop word, counters and first solution (pcp_dfs_device is
@@ -1675,7 +1680,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
     }
   }
   for (uint32_t i = tid; i < B * Wv; i += nth) chg[i] = 0;
-  bar();
+  // (only LDS words were written: a batch tile's barrier here waits for LDS alone, so that the offsets' DMA stays in flight; the search loop's
+  // rows may have been written by this very workgroup a moment ago: its barrier also waits for those stores)
+  if constexpr (!DFS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else bar();
   PCP_TR(1);
   if (!adj_stored) {
     adj_stored = true;
