@@ -125,6 +125,7 @@ struct pcp_ctx {
   int64_t opt_time_kernels = 1;     // 1 = a pair of HIP events brackets every fixpoint launch (pcp_last_kernel_ms); 0 = nothing but the kernel is enqueued
   int64_t opt_small_path = 1;       // 1 = small stores (<= 128 slots, <= 2048 records) run one wavefront per node (pcp_small.hip)
   int64_t opt_big_dense_k = 2;      // pcp_big.hip: dense iff k * list entries >= records
+  int64_t opt_big_bank = 1;         // pcp_big.hip: the kind-sorted table's records are ordered, within a kind, so that the 32 lanes of a half wavefront read 32 different LDS bank pairs (0 = the model's own order)
   int64_t opt_big_round = 0;        // tests: 1 = dense wake-up rounds only, 2 = sparse only (pcp_big.hip)
   int64_t opt_big_path = 1;         // 1 = binary models on 10-bit cells with implicit nodes run pcp_big.hip, 0 = the generic kernel's dom10 variant
 };
@@ -922,6 +923,10 @@ int32_t pcp_set_option(pcp_ctx* c, const char* key, int64_t value) {
   } else if (k == "small_path") {
     if (value < 0 || value > 1) return fail(c, PCP_ERR_ARG, "small_path must be 0 or 1");
     c->opt_small_path = value;
+  } else if (k == "big_bank") {
+    if (value != 0 && value != 1) return fail(c, PCP_ERR_ARG, "big_bank must be 0 or 1");
+    if (c->opt_big_bank != value) c->recs_by_kind_valid = false;  // (the table is rebuilt on its next use)
+    c->opt_big_bank = value;
   } else if (k == "big_dense_k") {
     if (value < 1 || value > 64) return fail(c, PCP_ERR_ARG, "big_dense_k must be in [1,64]");
     c->opt_big_dense_k = value;
@@ -1114,6 +1119,53 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
             badj[k] = make_uint2(coord(is_y ? x : y) | ((is_y ? 1u : 0u) << 17) | (kind << 18), (uint32_t)rec.d);
           }
         std::stable_sort(br.begin(), br.end(), [](const BR& p, const BR& q) { return p.key < q.key; });
+        // Bank-aware order within a kind (round 6; the order of the table is free — every fair schedule reaches the same fixpoint, DESIGN.md §2 —
+        // and the model is immutable).  A cell word is 8 bytes = one PAIR of LDS banks, and a wavefront's ds_read_b64 / 64-bit compare-and-swap is
+        // served one 32-lane half at a time: it is conflict-free iff the half's 32 word indices differ mod 32.  With the model's own (random) order a
+        // half hit ~12 distinct bank pairs out of 32 twice or more: SQ_LDS_BANK_CONFLICT was 0.44 of SQ_LDS_IDX_ACTIVE (profiles/r05_c3_*).  Greedy:
+        // the records of a kind are dealt from 32 buckets (x word mod 32), one per lane of a half, preferring among a bucket's next few records one
+        // whose y word falls on a bank pair the half has not used yet.  Neighbouring lanes then never compare-and-swap the same word either.
+        if (c->opt_big_bank) {
+          size_t s0 = 0;
+          while (s0 < P) {
+            size_t e0 = s0;
+            while (e0 < P && br[e0].key == br[s0].key) ++e0;
+            std::vector<uint32_t> bucket[32];
+            for (size_t r = s0; r < e0; ++r) bucket[br[r].r.x & 31u].push_back((uint32_t)r);
+            size_t head[32] = {0};
+            std::vector<BR> out;
+            out.reserve(e0 - s0);
+            const bool unary = br[s0].key == 3u;
+            size_t pos = s0;           // table position of the next record: halves are positions [32 h, 32 h + 32)
+            uint32_t usedx = 0, usedy = 0;
+            uint32_t rot = 0;
+            while (out.size() < e0 - s0) {
+              if ((pos & 31u) == 0) { usedx = 0; usedy = 0; }
+              // the fullest bucket whose bank pair this half has not used (ties: rotate), else the fullest bucket at all
+              int best = -1; size_t best_n = 0;
+              for (uint32_t i = 0; i < 32; ++i) {
+                const uint32_t b = (i + rot) & 31u;
+                const size_t n = bucket[b].size() - head[b];
+                if (n > best_n && !((usedx >> b) & 1u)) { best_n = n; best = (int)b; }
+              }
+              if (best < 0)
+                for (uint32_t b = 0; b < 32; ++b) { const size_t n = bucket[b].size() - head[b]; if (n > best_n) { best_n = n; best = (int)b; } }
+              std::vector<uint32_t>& bk = bucket[best];
+              size_t pick = head[best];
+              if (!unary)
+                for (size_t k2 = head[best]; k2 < std::min(bk.size(), head[best] + 16); ++k2)
+                  if (!((usedy >> (br[bk[k2]].r.y & 31u)) & 1u)) { pick = k2; break; }
+              std::swap(bk[pick], bk[head[best]]);
+              const BR& chosen = br[bk[head[best]++]];
+              usedx |= 1u << (chosen.r.x & 31u);
+              if (!unary) usedy |= 1u << (chosen.r.y & 31u);
+              out.push_back(chosen);
+              ++pos; ++rot;
+            }
+            std::copy(out.begin(), out.end(), br.begin() + s0);
+            s0 = e0;
+          }
+        }
         std::vector<uint2> brec(Ppad);
         for (size_t r = 0; r < Ppad; ++r) brec[r] = br[std::min<size_t>(r, P - 1)].r;
         if ((rc = ensure(c, c->d_brec, c->cap_brec, brec.size()))) return rc;
