@@ -206,7 +206,35 @@ def _gather_sizes(size: int, dist, dev) -> List[int]:
     return [int(x) for x in torch.cat(gathered).tolist()]
 
 
-def balance_stacks(stack, dist, info: Optional[dict] = None) -> int:
+class _Exchange:
+    """X1 and X3 in ONE collective (round 6): every rank contributes (open nodes, solutions, nodes) and gets everybody's — an all_gather of
+    3 x 8 bytes per rank into buffers that live as long as the search (device tensors plus pinned host mirrors on a GPU: no allocation, no
+    pageable copy), and ONE host wait.  Round 5 paid an all_gather with its device-to-host read, then an all_reduce with another, then two
+    small host-to-device copies, 36 times per 2 M nodes: 18 % of the worklist engine's time on one rank with nothing to move."""
+
+    def __init__(self, dist, dev):
+        import torch
+        self.dist, self.dev, self.world = dist, dev, dist.get_world_size()
+        cuda = dev.type == "cuda"
+        self.h_in = torch.zeros(3, dtype=torch.int64, pin_memory=cuda)
+        self.h_out = torch.zeros(3 * self.world, dtype=torch.int64, pin_memory=cuda)
+        self.d_in = torch.zeros(3, dtype=torch.int64, device=dev) if cuda else self.h_in
+        self.d_out = torch.zeros(3 * self.world, dtype=torch.int64, device=dev) if cuda else self.h_out
+
+    def gather(self, size: int, sols: int, nodes: int):
+        import torch
+        self.h_in[0], self.h_in[1], self.h_in[2] = int(size), int(sols), int(nodes)
+        if self.d_in is not self.h_in:
+            self.d_in.copy_(self.h_in, non_blocking=True)
+        self.dist.all_gather_into_tensor(self.d_out, self.d_in)
+        if self.d_out is not self.h_out:
+            self.h_out.copy_(self.d_out, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+        v = self.h_out.tolist()
+        return v[0::3], v[1::3], v[2::3]  # per rank: open nodes, solutions, nodes
+
+
+def balance_stacks(stack, dist, info: Optional[dict] = None, sizes: Optional[List[int]] = None) -> int:
     """X1 + X2 on a stack object with tensors ``lb [cap,V]``, ``ub [cap,V]``, ``act [cap,W]`` (and ``bits`` in set mode).  The open
     nodes are either rows [0, size) (a plain stack: ``size``) or DeviceSearch's segments ``segs`` = [start, length] bottom to top.
     Senders give away their OLDEST rows (bottom of the stack: closest to the root, the largest subtrees); receivers put them at the
@@ -220,7 +248,7 @@ def balance_stacks(stack, dist, info: Optional[dict] = None) -> int:
     segmented = hasattr(stack, "segs")
     segs = stack.segs if segmented else ([[0, int(stack.size)]] if stack.size else [])
     size = sum(l for _, l in segs)
-    moves = plan_moves(_gather_sizes(size, dist, dev))
+    moves = plan_moves(sizes if sizes is not None else _gather_sizes(size, dist, dev))  # (`sizes`: the caller has gathered them already)
     # implicit-active stacks carry no `active` rows; set-mode stacks carry the sets as well
     rows = tuple(stack._rows()) if hasattr(stack, "_rows") else tuple(t for t in (stack.lb, stack.ub, stack.act) if t is not None)
     cap = int(stack.lb.shape[0])
@@ -333,28 +361,41 @@ def parallel_search_device(search, lb0, ub0, dist, all_solutions: bool = True, n
     moved = 0
     exchange_s, exchanges = 0.0, 0
     xinfo = {}
+    xch = _Exchange(dist, dev)
+    # The exchange step is off the rounds' path where it has nothing to do: its interval starts at `rounds_per_exchange` and DOUBLES (up to 8 x)
+    # whenever an exchange found every rank with at least a round's worth of open nodes and moved nothing; it falls back as soon as a rank runs
+    # short or records move.  Every rank derives the interval from the same gathered numbers, so all of them enter the next collective together.
+    interval = max(1, int(rounds_per_exchange))
     while True:
         if search.size > 0 and (all_solutions or search.stats.num_solution == 0):
             # a rank's share of what is left of the node budget (the budget is global; it is checked at every exchange)
             # One rank: the budget IS the search's StopNode limit (its limit node is counted as a node and as nothing else, stop_node.rs:57-62).
-            # Several ranks: the limit is checked on the all-reduced total at every exchange, so there is no single "node that reaches it";
+            # Several ranks: the limit is checked on the gathered total at every exchange, so there is no single "node that reaches it";
             # a rank's share only ends its chunk (stop_at) and every node it explored counts with its status.
             if world == 1:
-                search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0, node_limit=node_limit)
+                search.advance(all_solutions=all_solutions, max_rounds=interval, keep_solutions=0, node_limit=node_limit)
             else:
                 left = max(1, (node_limit - search.stats.num_nodes * world) // world) if node_limit else 0
-                search.advance(all_solutions=all_solutions, max_rounds=rounds_per_exchange, keep_solutions=0,
+                search.advance(all_solutions=all_solutions, max_rounds=interval, keep_solutions=0,
                                stop_at=(search.stats.num_nodes + left) if node_limit else 0)
         t0 = time.perf_counter()
-        moved += max(balance_stacks(search, dist, xinfo), 0)
         st = search.stats
-        flags = torch.tensor([search.size, st.num_solution, st.num_nodes], dtype=torch.int64, device=dev)
-        dist.all_reduce(flags, op=dist.ReduceOp.SUM)
-        open_total, sol_total, nodes_total = (int(x) for x in flags.tolist())
+        sizes, sols, nodes = xch.gather(search.size, st.num_solution, st.num_nodes)  # X1 + X3: one collective, one host wait
+        open_total, sol_total, nodes_total = sum(sizes), sum(sols), sum(nodes)
+        over = open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit)
+        sent = 0
+        # X2, pairwise — only when some rank is about to run short (fewer than two rounds' worth of open nodes): while everybody has work for the
+        # rounds ahead, moving records buys nothing (records moved now are records the receiver would not have touched before the next exchange)
+        need = min(sizes) < 2 * search.batch
+        if not over and need:
+            sent = balance_stacks(search, dist, xinfo, sizes=sizes)
+            moved += max(sent, 0)
         exchange_s += time.perf_counter() - t0
         exchanges += 1
-        if open_total == 0 or (not all_solutions and sol_total > 0) or (node_limit and nodes_total >= node_limit):
+        if over:
             break
+        quiet = not need
+        interval = min(8 * max(1, int(rounds_per_exchange)), 2 * interval) if quiet else max(1, int(rounds_per_exchange))
     if info is not None:
         info.update(exchange_s=exchange_s, exchanges=exchanges, moved_bytes=xinfo.get("moved_bytes", 0), record_bytes=xinfo.get("record_bytes", 0))
     st = search.stats

@@ -168,7 +168,7 @@ def test_one_rank_rccl_worklist_equals_device_search_under_a_budget(env):
             info = {}
             nodes, sols, fails, steps, moved = D.parallel_search_device(ds, lb0, ub0, dist, all_solutions=True, node_limit=budget, rounds_per_exchange=4, info=info)
             assert (nodes, sols, fails) == (solo.num_nodes, solo.num_solution, solo.num_failed_node), (cells, nodes, sols, fails, solo)
-            assert nodes == budget and moved == 0 and info["exchanges"] >= budget // (4 * BATCH) and steps > 0
+            assert nodes == budget and moved == 0 and info["exchanges"] >= 3 and steps > 0
             assert ctx.last_plan()["path"] == 1
             got[cells] = (nodes, sols, fails)
     finally:
