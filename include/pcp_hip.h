@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PCP_ABI_VERSION 7
+#define PCP_ABI_VERSION 8
 
 /* Operand encodings for pcp_prop.var[i]. */
 #define PCP_CONST 0xFFFFFFFFu /* operand is a term::Constant (term/constant.rs:43-68); off[i] = its value   */
@@ -151,9 +151,9 @@ uint32_t pcp_abi_version(void);
  *       reference on interior values.
  *   ENUMERATE (search/branching/enumerate.rs:33-60: children `x = v` and `x != v`) needs no engine support in set mode — both children are
  *   exact set operations the caller applies to `bits` before propagating (keep bit v / clear bit v), as pcp_branch_device_set does for
- *   BinarySplit.  In interval mode `x != v` with v inside (lb, ub) is not a domain operation: it stays a per-node propagator, i.e. a unit
+ *   BinarySplit.  In interval mode `x != v` with v inside (lb, ub) is not a domain operation: it stays a per-node propagator — a unit
  *   pushed with pcp_model_push_props before the node's call and removed with pcp_model_truncate after it (what the host twins do for
- *   every branch constraint); batches of nodes with DIFFERENT per-node units are not offered. */
+ *   every branch constraint), or, for a BATCH of nodes with different such propagators each, pcp_propagate_device_units (ABI v8). */
 int32_t pcp_model_reset(pcp_ctx* ctx, uint32_t n_vars, uint32_t set_words);
 /* ≡ Store::alloc, append-only (propagation/store.rs:223-230). */
 int32_t pcp_model_push_props(pcp_ctx* ctx, uint32_t n, const pcp_prop* props);
@@ -248,6 +248,22 @@ int32_t pcp_unpack_rows(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, i
 int32_t pcp_branch_device_cells(pcp_ctx* ctx, uint32_t n_nodes, const uint32_t* cells, const uint8_t* status, uint32_t* child_cells,
                                 uint32_t* child_dirty, uint32_t* counts, void* hip_stream);
 int32_t pcp_propagate_device(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, void* hip_stream);
+/* ABI v8 — nodes with propagators of their OWN.  In the reference every branch appends ONE unary propagator to ONE node's cstore
+ * (Branch::distribute, search/branching/branch.rs:36-55); BinarySplit's  x <= v / x > v  and Enumerate's  x = v  narrow their variable once and are
+ * then entailed, so a driver folds them into the child's bounds (what pcp_branch_device does) — but Enumerate's  x != v  with v INSIDE the
+ * domain removes nothing on an Interval (x_neq_y.rs:82-93: only at a bound) and stays active until v reaches a bound
+ * (search/branching/enumerate.rs:48-59).  Such propagators travel with their node:
+ *   node_unit_off : device uint32 [n_nodes + 1], CSR offsets into node_units (NULL = no node has any: exactly pcp_propagate_device)
+ *   node_units    : device pcp_prop [node_unit_off[n_nodes]] — kind PCP_NEQ / PCP_EQ / PCP_LT over ONE variable and ONE Constant in either
+ *                   operand position (var[i] = PCP_CONST, off[i] = the value; the variable's off = its Addition offset); group fields ignored.
+ * They are scheduled with the model's propagators (every one once, then again while anything narrows) and count in the node's status: a
+ * node is PCP_TRUE only if its own propagators are entailed too.  Their liveness is not reported (`active` rows cover the model's units): a
+ * caller drops a node unit when its constant has left the domain.  A malformed unit refuses its node (PCP_STATUS_HULL, sticky flag).
+ * Interval mode, stores of at most 128 variables (interned constants included) and 2048 elementary filters — the one-wavefront-per-node
+ * kernel (plan.path 4) —, int32 rows; anything else: PCP_ERR_UNSUPPORTED.  (Set mode needs none of this: there x != v is an exact set
+ * operation on `bits`.) */
+int32_t pcp_propagate_device_units(pcp_ctx* ctx, uint32_t n_nodes, const pcp_device_batch* batch, const uint32_t* node_unit_off,
+                                   const pcp_prop* node_units, void* hip_stream);
 /* One context = one queue of launches: the device-side scratch behind a launch (counters, team words, `active` scratch, the tile tickets of the
  * persistent kernels) belongs to the context, so the launches of one context must not overlap on the device — enqueue them on one stream, or order
  * the streams; concurrent launches take one context each (the model is uploaded per context).  The tile tickets are guarded at run time as well:

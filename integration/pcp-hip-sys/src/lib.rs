@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_void};
 
-pub const PCP_ABI_VERSION: u32 = 7;
+pub const PCP_ABI_VERSION: u32 = 8;
 pub const PCP_CONST: u32 = 0xFFFF_FFFF; // operand is a term::Constant; off[i] = its value
 pub const PCP_NOVAR: u32 = 0xFFFF_FFFE; // operand slot unused
 pub const PCP_SUM: u32 = 0xC000_0000; //   var[i] = PCP_SUM | t: term::Sum number t (pcp_model_push_sum)
@@ -171,6 +171,10 @@ extern "C" {
     pub fn pcp_propagate(ctx: *mut pcp_ctx, n_nodes: u32, lb: *mut i32, ub: *mut i32, bits: *mut u64, active: *mut u64,
                          status: *mut u8, stats: *mut pcp_stats) -> i32; // Consistency::consistency
     pub fn pcp_propagate_device(ctx: *mut pcp_ctx, n_nodes: u32, batch: *const pcp_device_batch, hip_stream: *mut c_void) -> i32;
+    /// ABI v8: the same for nodes that carry unary propagators of their own (Enumerate's `x != v`, search/branching/enumerate.rs:48-59):
+    /// `node_unit_off` device u32 [n_nodes + 1], `node_units` device pcp_prop records (one variable against one Constant).
+    pub fn pcp_propagate_device_units(ctx: *mut pcp_ctx, n_nodes: u32, batch: *const pcp_device_batch, node_unit_off: *const u32,
+                                      node_units: *const pcp_prop, hip_stream: *mut c_void) -> i32;
     pub fn pcp_branch_device(ctx: *mut pcp_ctx, n_nodes: u32, lb: *const i32, ub: *const i32, active: *const u64, status: *const u8,
                              child_lb: *mut i32, child_ub: *mut i32, child_active: *mut u64, counts: *mut u32,
                              hip_stream: *mut c_void) -> i32; // Brancher<FirstSmallestVar, MiddleVal, BinarySplit>::enter

@@ -71,6 +71,8 @@ struct pcp_ctx {
   // scratch
   pcp_stats* d_stats = nullptr;
   unsigned long long* d_dbg = nullptr;  // [PCP_DBG_COUNT] diagnostic counters (pcp_debug_counters)
+  const uint32_t* cur_nu_off = nullptr;  // pcp_propagate_device_units: the call's node units (device pointers), for the duration of the call
+  const pcp_prop* cur_nu = nullptr;
   uint32_t* d_tile_ctr = nullptr; // pcp_neq.hip's tile tickets (NeqArgs::tile_ctr): zero between launches
   bool tickets_suspect = false;   // a HIP error was seen on this context since the tickets were last known to be zero: the next ticketed launch zeroes them first
   hipStream_t tickets_stream = nullptr;  // the stream of the last ticketed launch, and the event recorded behind it: a ticketed launch on ANOTHER stream waits
@@ -993,6 +995,9 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
     return rcn == 1 ? fail(c, PCP_ERR_UNSUPPORTED, "cell_format PCP_CELLS_PACKED16: the store does not fit LDS") : rcn;
   }
   if (c->n_vars && !c->set_words && (!bt->lb_in || !bt->ub_in || !bt->lb_out || !bt->ub_out)) return fail(c, PCP_ERR_ARG, "domain pointers must not be null");
+  const bool has_nu = c->cur_nu_off != nullptr;
+  if (has_nu && (c->set_words || c->has_formulas || c->dfs_sp))
+    return fail(c, PCP_ERR_UNSUPPORTED, "node units: interval mode, stores without formula propagators (set mode needs none: exact set operations on `bits`)");
 
   if (c->set_words) return propagate_set_device(c, n_nodes, bt, stream);
   const uint32_t P = (uint32_t)c->props.size();
@@ -1031,10 +1036,14 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
   }
   // a small store — at most 128 slots, 2048 records, no formulas: one wavefront per node (pcp_small.hip, plan.path 4).  Explicit rows and
   // implicit nodes alike.  Any option that asks for a particular geometry of the generic kernels keeps those kernels.
-  if (c->opt_small_path && S <= 128u && P <= 2048u && !c->opt_force_path && !c->opt_nodes_per_block && !c->opt_global_dom && !c->opt_team &&
-      (bt->active_in != nullptr || c->opt_implicit) && !(c->neq_model && c->opt_neq_path && bt->active_in == nullptr && n_nodes >= 64)) {
+  // (a call with node units takes this kernel whatever the options say: it is the one that reads them)
+  if (has_nu && !(S <= 128u && P <= 2048u && (bt->active_in != nullptr || c->opt_implicit)))
+    return fail(c, PCP_ERR_UNSUPPORTED, "node units: stores of at most 128 variables (incl. interned constants) and 2048 elementary filters (the one-wavefront-per-node kernel)");
+  if (has_nu || (c->opt_small_path && S <= 128u && P <= 2048u && !c->opt_force_path && !c->opt_nodes_per_block && !c->opt_global_dom && !c->opt_team &&
+      (bt->active_in != nullptr || c->opt_implicit) && !(c->neq_model && c->opt_neq_path && bt->active_in == nullptr && n_nodes >= 64))) {
     const uint32_t waves = 4;
     const size_t lds = lds_bytes_small(S, c->n_units, P, waves);
+    if (has_nu && !(lds && lds <= c->lds_max)) return fail(c, PCP_ERR_UNSUPPORTED, "node units: the store does not fit the one-wavefront-per-node kernel");
     if (lds && lds <= c->lds_max) {
       SmallArgs a;
       memset(&a, 0, sizeof(a));
@@ -1043,6 +1052,7 @@ int32_t pcp_propagate_device(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batc
       a.rec_unit = c->has_groups ? c->d_rec_unit : nullptr; a.n_units = c->n_units; a.n_nodes = n_nodes;
       if (c->n_alldiff && c->opt_small_alldiff) { a.ad_tab = c->d_ad_tab; a.ad_vars = c->d_ad_vars; a.ad_mask = c->d_ad_mask; }
       a.violation = c->d_retry + 1; a.dbg = c->d_dbg; a.sp_ptr = c->dfs_sp; a.stop_ptr = c->dfs_stop;
+      a.nu_off = c->cur_nu_off; a.nu = c->cur_nu;
       a.lb_in = bt->lb_in; a.ub_in = bt->ub_in; a.lb_out = bt->lb_out; a.ub_out = bt->ub_out;
       a.active_in = bt->active_in; a.active_out = bt->active_out; a.status = bt->status; a.stats = c->d_stats;
       LaunchPlan plan;
@@ -1556,6 +1566,19 @@ int32_t pcp_unpack_rows(pcp_ctx* c, uint32_t n_nodes, const uint32_t* cells, int
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, launch_unpack_rows(cells, lb, ub, (size_t)n_nodes * c->n_vars, reinterpret_cast<hipStream_t>(hip_stream)));
   return PCP_OK;
+}
+
+// ≡ Consistency::consistency for nodes whose cstores differ by a few propagators of their OWN (ABI v8): what Branch::distribute appends to one
+// node (search/branching/branch.rs:36-55) and cannot be folded into its bounds — Enumerate's x != v (enumerate.rs:48-59).
+int32_t pcp_propagate_device_units(pcp_ctx* c, uint32_t n_nodes, const pcp_device_batch* bt, const uint32_t* node_unit_off, const pcp_prop* node_units, void* hip_stream) {
+  if (!c || !bt) return PCP_ERR_ARG;
+  if (!node_unit_off) return pcp_propagate_device(c, n_nodes, bt, hip_stream);
+  if (!node_units) return fail(c, PCP_ERR_ARG, "node_units must not be null when node_unit_off is given");
+  if (bt->cell_format) return fail(c, PCP_ERR_UNSUPPORTED, "node units: int32 rows only");
+  c->cur_nu_off = node_unit_off; c->cur_nu = node_units;
+  const int32_t rc = pcp_propagate_device(c, n_nodes, bt, hip_stream);
+  c->cur_nu_off = nullptr; c->cur_nu = nullptr;
+  return rc;
 }
 
 int32_t pcp_branch_device(pcp_ctx* c, uint32_t n_nodes, const int32_t* lb, const int32_t* ub, const uint64_t* active,

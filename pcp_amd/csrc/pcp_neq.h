@@ -119,6 +119,8 @@ struct SmallArgs {
   unsigned long long* dbg;    // [kStatSlots][PCP_DBG_COUNT]
   const uint32_t* sp_ptr;     // host-stepped device-side DFS: the node to run is row *sp_ptr - 1 (see LaunchArgs)
   const uint32_t* stop_ptr;
+  const uint32_t* nu_off;     // pcp_propagate_device_units: [n_nodes + 1] CSR offsets into nu, or null
+  const pcp_prop* nu;         //   the nodes' own unary propagators (one variable against one Constant)
   const int32_t* lb_in;
   const int32_t* ub_in;
   int32_t* lb_out;

@@ -124,11 +124,44 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
     const LdsDom dm{dom, 1u, chg, &misc[S_FAIL], 1u, &ctr, a.m.sums};
     uint32_t s2 = 0, s3 = 0, rounds = 0;
     bool failed = __builtin_amdgcn_readfirstlane(misc[S_FAIL]) != 0;
+    // the node's OWN propagators (pcp_propagate_device_units): what a branch appends to ONE node's cstore and what cannot be folded into its
+    // bounds — Enumerate's  x != v  with v inside the domain (search/branching/enumerate.rs:48-59; it stays active until v reaches a bound).
+    // One variable against one Constant, kinds XNeqY / XEqY / XLessY; lane-strided like the records; `nu_open`: one of them is not entailed.
+    const uint32_t nu0 = a.nu_off ? a.nu_off[node] : 0u, nu1 = a.nu_off ? a.nu_off[node + 1] : 0u;
+    bool nu_open = false;
     while (!failed) {
       ++rounds;
       for (uint32_t w = lane; w < Wu; w += 64) ent[w] = live[w];  // a live unit counts as entailed until one of its members says otherwise
       wave_sync();
       const uint32_t before = ctr.narrow;
+      nu_open = false;
+      for (uint32_t i = nu0 + lane; i < nu1; i += 64) {
+        const pcp_prop p = a.nu[i];
+        // x + ox (kind) c  <=>  x (kind) K = c - ox;   c (kind) y + oy  <=>  y != K | y = K | y > K  with K = c - oy   (term/addition.rs:98, cmp/mod.rs:40-60)
+        const bool cy = p.var[1] == PCP_CONST, cx = p.var[0] == PCP_CONST;
+        const uint32_t v = cy ? p.var[0] : p.var[1];
+        if (cx == cy || v >= V || p.kind > PCP_LT) { dm.set_fail(); misc[S_OOB] = 1u; continue; }  // malformed: the node is refused
+        const long long K64 = cy ? (long long)p.off[1] - p.off[0] : (long long)p.off[0] - p.off[1];
+        const int K = (int)max(-(long long)kBoundMax - 2, min((long long)kBoundMax + 2, K64));  // (beyond every bound either way)
+        const uint32_t op = p.kind == PCP_NEQ ? 3u : p.kind == PCP_EQ ? 2u : (cy ? 0u : 1u);  // 0 "< K", 1 "> K", 2 "= K", 3 "!= K"
+        const int2 c_ = dom[v];
+        const int xl0 = -c_.x, xu0 = c_.y;
+        int xl = xl0, xu = xu0;
+        ++s2;
+        if (op == 0u) xu = min(xu0, K - 1);           // XLessY::propagate (x_less_y.rs:104-109) against Constant::update (term/constant.rs:49-52)
+        else if (op == 1u) xl = max(xl0, K + 1);
+        else if (op == 2u) { xl = max(xl0, K); xu = min(xu0, K); }  // XEqY (x_eq_y.rs:102-107)
+        else {                                        // XNeqY (x_neq_y.rs:82-93): a value is removed only at a bound
+          if (xl0 == xu0 && xl0 == K) { dm.set_fail(); continue; }
+          if (xl0 != xu0) { if (K == xl0) xl = xl0 + 1; else if (K == xu0) xu = xu0 - 1; }
+        }
+        if (xl > xu) { dm.set_fail(); continue; }
+        if (xl > xl0) dm.raise_lb(v, xl);
+        if (xu < xu0) dm.lower_ub(v, xu);
+        // is_subsumed() on what propagate() left (store.rs:166-175)
+        const bool entailed = op == 0u ? xu < K : op == 1u ? xl > K : op == 2u ? (xl == K && xu == K) : (K < xl || K > xu);
+        nu_open |= !entailed;
+      }
       unsigned long long grouped = 0;  // (wave-uniform) the all-different units filtered as a group this round: bit k = entry k of ad_tab
       for (uint32_t k = 0; k < n_ad; ++k) {
         const uint32_t au = adt[1 + 3 * k], cnt = adt[2 + 3 * k], v0 = adt[3 + 3 * k];
@@ -201,6 +234,11 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
       if (!__ballot(ctr.narrow != before)) break;
     }
 
+    if (__builtin_amdgcn_readfirstlane(misc[S_OOB]) != 0) {  // a malformed node unit: the node is refused, its outputs left alone
+      if (lane == 0) { a.status[st_base + node] = kStatusRetry; atomicMax(a.violation, 1u); }
+      wave_sync();
+      continue;
+    }
     // ---- write back, unlink the entailed units (store.rs:200-207), status (store.rs:250-256) --------------------------------------------------
     bool emptied = false;
     for (uint32_t v = lane; v < V; v += 64) {
@@ -221,7 +259,7 @@ __global__ void __launch_bounds__(256) smallfix_kernel(const SmallArgs a) {
         const uint64_t lo = live[2 * w], hi = (2 * w + 1 < Wu) ? live[2 * w + 1] : 0u;
         a.active_out[(size_t)node * words64 + w] = lo | (hi << 32);
       }
-    const bool unknown = __ballot(any_live) != 0;
+    const bool unknown = __ballot(any_live || nu_open) != 0;
     if (lane == 0) a.status[st_base + node] = failed ? (uint8_t)PCP_FALSE : (unknown ? (uint8_t)PCP_UNKNOWN : (uint8_t)PCP_TRUE);
     for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_down(s2, o); s3 += __shfl_down(s3, o); ctr.narrow += __shfl_down(ctr.narrow, o); }
     acc_s2 += s2; acc_s3 += s3; acc_narrow += ctr.narrow; acc_waves += rounds ? rounds : 1; acc_nodes += 1; acc_failed += failed ? 1 : 0;

@@ -25,7 +25,7 @@ ERRORS = {-1: "PCP_ERR_ARG", -2: "PCP_ERR_CONTRACT", -3: "PCP_ERR_HIP", -4: "PCP
 ABI_SYMBOLS = [
     "pcp_ctx_create", "pcp_ctx_destroy", "pcp_last_error", "pcp_strerror", "pcp_abi_version",
     "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull",
-    "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
+    "pcp_propagate", "pcp_propagate_device", "pcp_propagate_device_units", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option",
 ]
 
 
@@ -131,7 +131,7 @@ def load_library():
     L.pcp_last_plan.argtypes = [vp, C.POINTER(PcpPlan)]
     L.pcp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     for f in ("pcp_ctx_create", "pcp_model_reset", "pcp_model_push_props", "pcp_model_push_formula", "pcp_model_push_sum", "pcp_model_truncate", "pcp_model_n_units", "pcp_model_set_hull", "pcp_model_set_hull",
-              "pcp_propagate", "pcp_propagate_device", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
+              "pcp_propagate", "pcp_propagate_device", "pcp_propagate_device_units", "pcp_branch_device", "pcp_branch_device_hint", "pcp_pack_rows", "pcp_unpack_rows", "pcp_branch_device_cells", "pcp_branch_device_set", "pcp_dfs_device", "pcp_dfs_forest_device", "pcp_dfs_forest_device_set", "pcp_dfs_forest_split_set", "pcp_stats_reset", "pcp_stats_read", "pcp_debug_counters", "pcp_last_kernel_ms", "pcp_last_plan", "pcp_set_option"):
         getattr(L, f).restype = i32
     _lib = L
     return L
@@ -298,6 +298,15 @@ class Context:
         bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), p(bits_in), p(bits_out), p(dirty),
                          1 if cells else 0, 0)
         self._check(self._L.pcp_propagate_device(self._h, n_nodes, C.byref(bt), C.c_void_p(stream_ptr)))
+
+    def propagate_device_units(self, n_nodes: int, lb_in, ub_in, lb_out, ub_out, active_in, active_out, status, unit_off, units, stream_ptr: int = 0):
+        """pcp_propagate_device_units (ABI v8): the batch of `propagate_device` where node i also carries its own unary propagators
+        units[unit_off[i] : unit_off[i + 1]] — `unit_off` an int32 device tensor [n + 1], `units` a uint8 device tensor holding the pcp_prop
+        records (model.PROP_DTYPE bytes).  Enumerate's x != v children (search/branching/enumerate.rs:48-59) in one launch."""
+        def p(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        bt = DeviceBatch(p(lb_in), p(ub_in), p(lb_out), p(ub_out), p(active_in), p(active_out), p(status), None, None, None, 0, 0)
+        self._check(self._L.pcp_propagate_device_units(self._h, n_nodes, C.byref(bt), p(unit_off), p(units), C.c_void_p(stream_ptr)))
 
     def pack_rows(self, lb, ub, cells=None, stream_ptr: int = 0):
         """pcp_pack_rows: int32 bounds rows [n,V] -> rows of packed cells (an int32 [n,V] tensor whose bits are the cells)."""

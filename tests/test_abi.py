@@ -26,7 +26,7 @@ def test_header_symbols_are_exported():
     assert declared == set(E.ABI_SYMBOLS), declared ^ set(E.ABI_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), f"libpcp_hip.so does not export {name}"
-    assert L.pcp_abi_version() == 7
+    assert L.pcp_abi_version() == 8
 
 
 def test_prop_struct_layout_matches_header():
