@@ -963,6 +963,10 @@ __device__ __forceinline__ bool neq_fast_test(const Tile& tl, const uint32_t* __
 #pragma unroll
     for (int g = 0; g < 4; ++g) c[g] = *reinterpret_cast<const uint4*>(dom + rv + 4 * g);  // the walked variable's cells in the sixteen nodes
     const bool all4 = qm == 15u;  // (uniform) the first pass of a frontier tile: every quad; a later pass: the quads of the nodes that narrowed
+    uint32_t dif = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dif |= (c[g].x ^ c[0].x) | (c[g].y ^ c[0].x) | (c[g].z ^ c[0].x) | (c[g].w ^ c[0].x);
+    const bool same = PCP_NEQ_XOR && __builtin_amdgcn_readfirstlane(dif) == 0u;  // (every lane read the same cells: wave-uniform)
     const uint32_t nm = (uint32_t)__popc(M);
     // a lane's flagged entry (one is kept; a second one in the same lane and list — entries 512 apart both at a bound — sets `more`: the caller
     // runs another pass over every node, which finds it)
@@ -974,7 +978,18 @@ __device__ __forceinline__ bool neq_fast_test(const Tile& tl, const uint32_t* __
       const bool valid = j * tl.nth + tl.tid < dg;
       const uint32_t ro = tl.rowof(pay_other(q[j])), K = pack_mt(pay_t(q[j]));
       uint32_t acc = 0xffffffffu;
-      if (all4) {
+      if (all4 && same) {
+        // the walked variable has ONE cell in all sixteen nodes (the nodes of a frontier tile are siblings and cousins: they hold their common
+        // ancestors' queens at the same values): what the other side must match is a property of the entry (neq_target16), and an (entry, node)
+        // test is one exclusive-or and one packed minimum
+        const uint32_t T = neq_target16(c[0].x, K);
+        uint4 o[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[g] = *reinterpret_cast<const uint4*>(dom + ro + 4 * g);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc = pk_min_u16(acc, pk_min_u16(pk_min_u16(o[g].x ^ T, o[g].y ^ T), pk_min_u16(o[g].z ^ T, o[g].w ^ T)));
+      } else if (all4) {
         uint4 o[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) o[g] = *reinterpret_cast<const uint4*>(dom + ro + 4 * g);
@@ -1768,7 +1783,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
           if (bits) atomicOr(&misc[vw], bits);
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane(misc[vw]);
-          if (pass == 0) { PCP_TR(8); PCP_TR(9); PCP_TR(11); }
+          if (pass == 0) { PCP_TR(8); PCP_TR(9); PCP_TR(11); } else { PCP_TR(4); }  // (profiling: a later pass re-uses stamp 4 — "pass voted")
           if (vote == 0u) {
             if (pass == 0) { fstate = 3; break; }
             // quiet again: the nodes that moved get their statuses from their final domains — from the entries requested for them before
@@ -1777,7 +1792,9 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
             if (tid == 0) atomicAnd(&misc[N_UNK], ~moved);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             if (!no_status && neq_status_finish(tf, sp, moved, true)) neq_status_scan<PACKED, DFS>(tf, pay, false, moved);
+            PCP_TR(5);  // (profiling, tiles that narrowed: statuses done)
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            PCP_TR(6);
             fstate = 3;
             break;
           }

@@ -63,6 +63,13 @@ for rep in range(3):
         for x in range(8):
             sel = np.arange(lo, hi)[(np.arange(lo, hi) % g_) % 8 == x]
             print(f"     xcd {x}: ticks median {np.median(dur[sel]):8.0f} max {dur[sel].max():8.0f}   end us median {np.median(rte[sel]):6.1f} max {rte[sel].max():6.1f}")
+    # the tiles that narrowed something (the lean round 0 ran a second pass: stamp 4 is later than stamp 11): where their extra time goes
+    w0a = t[:, 0, :15] - t[:, 0, :1]
+    rare = np.nonzero(w0a[:, 4] > w0a[:, 11])[0]
+    if len(rare):
+        d = lambda a, b: f"{np.median(w0a[rare, b] - w0a[rare, a]):8.0f}"
+        print(f"  {len(rare)} tiles ran a second pass (median ticks): pass-0 vote -> pass-1 vote {d(11, 4)}   -> statuses again {d(4, 5)}   -> barrier {d(5, 6)}   -> write-back done (12) {d(6, 12)}"
+              f"   -> its barrier (13) {d(12, 13)}   -> end {d(13, 14)};   all others 11 -> 12: {np.median(np.delete(w0a[:, 12] - w0a[:, 11], rare)):8.0f}")
     # per phase, per generation: distribution over tiles of (released k) - (released k-1) for the barrier-delimited phases
     for lo, hi, what in ((0, g_, "first tiles"), (g_, tiles, "second tiles")):
         if hi <= lo:
