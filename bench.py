@@ -326,6 +326,11 @@ def c5_legs(args, torch, dist, world, rank, dev, n):
             print(out["c5_error"], file=sys.stderr, flush=True)
     trees = args.trees if args.trees else 4096
     spl = args.steps_per_launch if args.steps_per_launch else 1024
+    # The forest's stacks grow on demand INSIDE the timed region (with a process group nothing is reserved: 4 -> 8 -> 16 GB): take that memory from
+    # the driver once, outside it, and hand it to torch's caching allocator, so that the timed growth steps are splits of a cached block and not
+    # hipMalloc calls (on one box of round 6's last pass the same leg took 0.9 s instead of 34 ms, twice in a row, for exactly the same launches)
+    pre = torch.empty(int(min(torch.cuda.mem_get_info(dev)[0] // 2, 64 << 30)), dtype=torch.uint8, device=dev)
+    del pre
     forest_search(ctx, lb0, ub0, node_limit=4 * trees * world, n_trees=trees, steps_per_launch=4, rank=rank, world=world, dist=dist)
     finfo = {}
     fr, dtf = timed(lambda: forest_search(ctx, lb0, ub0, node_limit=min(8 * budget, 2_097_152), n_trees=trees, steps_per_launch=spl, rank=rank, world=world, dist=dist, info=finfo))
