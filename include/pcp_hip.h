@@ -398,6 +398,9 @@ typedef enum {
   PCP_DBG_NEQ_TILES = 2,   /* path 1: tiles run (a persistent workgroup runs several)                                         */
   PCP_DBG_NEQ_OVERLAP = 3, /* path 1: tiles whose rows were already in flight while the previous tile's rounds ran            */
   PCP_DBG_SMALL_NODES = 4, /* path 4: nodes run by the small-store kernel                                                     */
+  PCP_DBG_NEQ_LEAN = 8,           /* path 1: tiles whose round 0 took the lean form (full 16-node tiles with at most four assigned variables) */
+  PCP_DBG_NEQ_LEAN_PASSES = 9,    /* path 1: passes of that form beyond a tile's first (tiles in which a node narrowed)                      */
+  PCP_DBG_NEQ_LEAN_HANDOVER = 10, /* path 1: lean tiles handed to the general rounds (a narrowing assigned or emptied a variable)              */
   PCP_DBG_COUNT = 16
 } pcp_dbg_counter;
 int32_t pcp_debug_counters(pcp_ctx* ctx, uint64_t* out, uint32_t n, void* hip_stream);

@@ -120,7 +120,7 @@ __host__ __device__ inline NeqCarve neq_carve(uint32_t S, uint32_t V, uint32_t B
   c.chg = o; o = up(o + (size_t)B * Wv * 4);
   c.list = o; o = up(o + (size_t)kListCap * 16);
   c.adj = o; o = up(o + ((size_t)V + 1) * 4);
-  c.misc = o; o = up(o + (2 * 48 + 16) * 4);  // two copies: a persistent workgroup's next tile clears ITS copy while stragglers still read the last tile's; then seven u64 sums over the workgroup's tiles
+  c.misc = o; o = up(o + (2 * 48 + 20) * 4);  // two copies: a persistent workgroup's next tile clears ITS copy while stragglers still read the last tile's; then seven u64 sums over the workgroup's tiles
   // the windows take what is left of the CU's LDS divided by the workgroups that are to share it (two by default; one when the
   // tile needs more than its share)
   // (256 bytes short of an even share: __syncthreads_or and friends take a few bytes of static LDS on top of the dynamic carve)
@@ -1642,7 +1642,10 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
   // a persistent workgroup's counters over its tiles: seven u64 in LDS behind the two copies of the status words, touched by thread 0 only
   // (in registers they cost the tile loop fourteen VGPRs it does not have)
   unsigned long long* const accl = reinterpret_cast<unsigned long long*>(misc_base + 2 * 48);
-  if (!DFS && tid == 0) { for (int i = 0; i < 7; ++i) accl[i] = 0ull; }
+  // ... and, behind the next-tile word, three diagnostic counts of the lean round 0 (pcp_debug_counters): tiles that took it, passes beyond the
+  // first, tiles it handed to the general rounds — thread 0 only
+  uint32_t* const lean_ctr = misc_base + 2 * 48 + 16;
+  if (!DFS && tid == 0) { for (int i = 0; i < 7; ++i) accl[i] = 0ull; lean_ctr[0] = lean_ctr[1] = lean_ctr[2] = 0u; }
   // A persistent workgroup's per-thread counters (narrowings, pairs tested, full filter runs, wake-ups) are carried over its tiles in
   // registers and added up ONCE, behind the last tile: the wave sums, the LDS atomics and the barrier they needed were 1 500 cycles of every
   // tile.  (Not in profiling builds, whose timers read the per-tile words.)
@@ -1784,6 +1787,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           const uint32_t vote = (uint32_t)__builtin_amdgcn_readfirstlane(misc[vw]);
           if (pass == 0) { PCP_TR(8); PCP_TR(9); PCP_TR(11); } else { PCP_TR(4); }  // (profiling: a later pass re-uses stamp 4 — "pass voted")
+          if (tid == 0) { if (pass == 0) ++lean_ctr[0]; else ++lean_ctr[1]; }
           if (vote == 0u) {
             if (pass == 0) { fstate = 3; break; }
             // quiet again: the nodes that moved get their statuses from their final domains — from the entries requested for them before
@@ -1803,7 +1807,7 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
             // the general rounds, from round 1: the marks of the narrowings are set; staging's marks of the assigned variables are still set
             // too (their lists run once more: correct, and this is a tile in a thousand)
             fstate = 1;
-            if (tid == 0) misc[N_UNK] = 0;
+            if (tid == 0) { misc[N_UNK] = 0; ++lean_ctr[2]; }
             bar();
             break;
           }
@@ -2012,6 +2016,11 @@ __global__ void __launch_bounds__(DFS ? 512 : 1024) __attribute__((amdgpu_waves_
       // every workgroup drew the ticket that ended it before it comes here: the last one to arrive leaves the words zero for the next launch
       __threadfence();
       if (atomicAdd(tile_ctr + 32u * 8u, 1u) == gridDim.x - 1u) { for (uint32_t i = 0; i <= 8u; ++i) atomicExch(tile_ctr + 32u * i, 0u); }
+    }
+    if (!DFS && a.dbg && !PCP_NEQ_PROFILE) {  // (profiling builds keep phase timers in these slots)
+      if (lean_ctr[0]) atomicAdd(&a.dbg[PCP_DBG_NEQ_LEAN], (unsigned long long)lean_ctr[0]);
+      if (lean_ctr[1]) atomicAdd(&a.dbg[PCP_DBG_NEQ_LEAN_PASSES], (unsigned long long)lean_ctr[1]);
+      if (lean_ctr[2]) atomicAdd(&a.dbg[PCP_DBG_NEQ_LEAN_HANDOVER], (unsigned long long)lean_ctr[2]);
     }
     if (!DFS && a.dbg) atomicAdd(&a.dbg[PCP_DBG_NEQ_TILES], (unsigned long long)(DFS ? 0u : dfs_it + 1u));  // the tiles this workgroup ran (by stride or by ticket)
   }

@@ -498,7 +498,7 @@ class Context:
         self._check(self._L.pcp_stats_read(self._h, C.byref(st), C.c_void_p(stream_ptr)))
         return st.as_dict()
 
-    DBG = {"big_dense": 0, "big_sparse": 1, "neq_tiles": 2, "neq_overlap": 3, "small_nodes": 4}
+    DBG = {"big_dense": 0, "big_sparse": 1, "neq_tiles": 2, "neq_overlap": 3, "small_nodes": 4, "neq_lean": 8, "neq_lean_passes": 9, "neq_lean_handover": 10}
 
     def debug_counters(self, stream_ptr: int = 0) -> dict:
         """Kernel-internal diagnostic counters since the last stats_reset (pcp_debug_counters, ABI v6): which code paths ran."""
