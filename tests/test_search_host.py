@@ -574,3 +574,54 @@ def test_two_rank_node_budget_drops_no_status_gloo(limit):
     open_left = sum(r[5] for r in res)
     assert nodes == sum(r[2] for r in res) and sols == sum(r[3] for r in res) and fails == sum(r[4] for r in res)
     assert 2 * (sols + fails) == nodes + 1 - open_left, (nodes, sols, fails, open_left)
+
+
+class _FakeGroup:
+    """A process group of `world` ranks seen from rank 0, for the exchange POLICY alone (no communication): the other ranks always report
+    `others` open nodes each and nothing else."""
+
+    def __init__(self, world, others):
+        self.world, self.others, self.calls = world, others, 0
+
+    def get_world_size(self):
+        return self.world
+
+    def get_rank(self):
+        return 0
+
+    class ReduceOp:
+        SUM = "sum"
+
+    def all_reduce(self, t, op=None):  # (the final totals: one rank's are the totals)
+        self.final = True
+
+    def all_gather_into_tensor(self, out, inp):
+        self.calls += 1
+        out.view(self.world, 3)[0] = inp
+        for r in range(1, self.world):
+            out.view(self.world, 3)[r, 0] = self.others
+            out.view(self.world, 3)[r, 1] = 0
+            out.view(self.world, 3)[r, 2] = 0
+
+
+def test_exchange_is_one_collective_and_backs_off_while_nobody_starves():
+    """Round 6: an exchange is ONE collective — every rank's (open nodes, solutions, nodes) — and its interval doubles, up to eight
+    times `rounds_per_exchange`, while every rank holds at least two rounds' worth of open nodes; the search it drives is still the reference's tree."""
+    import torch
+    from oracle_ctx import OracleDeviceCtx
+    from pcp_amd import distributed as D
+    from pcp_amd.search_device import DeviceSearch
+    n = 8
+    lb0, ub0 = np.ones(n, np.int32), np.full(n, n, np.int32)
+    ctx = OracleDeviceCtx(n, M.nqueens_props(n))
+    ds = DeviceSearch(ctx, batch=2, capacity=4096, device=torch.device("cpu"), implicit=True)
+    grp = _FakeGroup(1, 0)
+    info = {}
+    tot = D.parallel_search_device(ds, lb0, ub0, grp, all_solutions=True, rounds_per_exchange=1, info=info)
+    assert tot[:3] == (779, 92, 298) and tot[4] == 0
+    rounds = ds.stats.rounds
+    assert grp.calls == info["exchanges"]  # one collective per exchange, nothing else
+    # with an exchange per round there would be `rounds` of them; the interval grew to 8 rounds wherever the stack held >= 2 rounds of nodes
+    assert info["exchanges"] < rounds // 3, (info["exchanges"], rounds)
+    # the policy itself, on gathered sizes: moves only when somebody is about to run short
+    assert D.plan_moves([100, 3]) and D.plan_moves([100, 100]) == []
