@@ -1173,7 +1173,14 @@ struct StageTile16Args {
   uint32_t wv, nwv;
 };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kStage16UF = 8;
+#ifndef PCP_STAGE_UF
+#define PCP_STAGE_UF 4
+#endif
+// wave-tasks (one 16-byte load of lb and one of ub per lane each) in flight per wavefront in a full tile's staging loop.  FOUR, i.e. two rounds of
+// loads per tile at 1000 variables on 512 threads: with all eight at once (the whole tile requested in one go: rounds 4-5) every CU of the chip puts
+// 256 KB into the memory system's queues at the same moment and who is served last waits for everybody — 8 / 4 / 3 / 2 in flight, one box, two runs each:
+// 41.0-41.5 / 40.0-40.8 / 40.4-41.2 / 41.0-42.3 us for the headline launch, 28.0 / 27.3 / 27.0 / 27.1 for one generation of tiles (tools/ab_variants.sh).
+constexpr int kStage16UF = PCP_STAGE_UF;
 template <bool CELLS>
 __device__ __forceinline__ uint32_t stage_tile16(const StageTile16Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_[];
